@@ -1,0 +1,72 @@
+/* C ABI of libwavelets_hip.so - the MI355X (gfx950) separable 2-D wavelet filterbank engine.
+ *
+ * This is the drop-in boundary of DESIGN.md section (b).  The reference
+ * (fbcotter/pytorch_wavelets v1.3.0) has no FFI: its per-scale operators are the
+ * torch.autograd.Function classes named next to each entry point below, and their bodies are
+ * ATen calls.  A maintainer of the reference replaces each Function's forward/backward body with
+ * one call into this library (ctypes stub in INTEGRATION.md).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every data/tap pointer is a DEVICE pointer (HBM), tensors
+ *     are dense NCHW with N and C collapsed into `planes`; nothing is allocated or freed here.
+ *   - `dtype`: WL_F32 0, WL_F16 1 (fp32 accumulate), WL_F64 2.  Taps are float for F32/F16 data
+ *     and double for F64 data, in the order the reference's module buffers hold them
+ *     (analysis/DTCWT taps reversed, synthesis taps unreversed).
+ *   - `mode`: the reference's integer codes (dwt/lowlevel.py:274-290): 0 zero, 1 symmetric,
+ *     2 periodization, 4 reflect, 6 periodic.
+ *   - `stream`: a hipStream_t (NULL = default stream).  Launches are asynchronous; no host sync.
+ *   - return value: 0 on success, WL_ERR_* (<0) for argument errors, a positive hipError_t if the
+ *     launch failed.  No exceptions cross the ABI, no global mutable state: re-entrant.
+ */
+#ifndef WAVELETS_HIP_H
+#define WAVELETS_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WL_F32 0
+#define WL_F16 1
+#define WL_F64 2
+
+#define WL_ERR_MODE (-1)        /* unknown / unsupported padding mode                         */
+#define WL_ERR_SHAPE (-2)       /* inconsistent sizes                                         */
+#define WL_ERR_UNSUPPORTED (-3) /* valid for the reference but not implemented by this engine */
+#define WL_ERR_DTYPE (-4)
+#define WL_ERR_TAPS (-5)        /* tap count out of range (1..WL_MAX_TAPS)                    */
+#define WL_MAX_TAPS 128
+
+/* library version (major*10000 + minor*100 + patch) and build flavour ("hip-gfx950" / "emu") */
+int wl_version(void);
+const char* wl_backend(void);
+
+/* Coefficient count of one 1-D analysis level: (n+L-1)/2, or (n+1)/2 for periodization.
+ * Replaces pywt.dwt_coeff_len at dwt/lowlevel.py:153. */
+int wl_dwt_coeff_len(int n, int L, int mode);
+
+/* One 2-D analysis level = AFB2D.forward (dwt/lowlevel.py:336-347: afb1d along W, afb1d along H,
+ * reshape + two .contiguous() copies), also SFB2D.backward (dwt/lowlevel.py:683-694).
+ *   x (planes,H,W) -> ll (planes,Kh,Kw), highs (planes,3,Kh,Kw) with band order
+ *   [W-lo/H-hi, W-hi/H-lo, W-hi/H-hi];  Kh = wl_dwt_coeff_len(H,Lh,mode), Kw likewise.
+ *   h_w_*: the pair applied along W (first pair of AFB2D.forward), h_h_*: the pair along H. */
+int wl_dwt2d_analysis(const void* x, void* ll, void* highs, int dtype, int64_t planes, int H, int W,
+                      const void* h_w_lo, const void* h_w_hi, int Lw,
+                      const void* h_h_lo, const void* h_h_hi, int Lh, int mode, void* stream);
+
+/* One 2-D synthesis level = SFB2D.forward (dwt/lowlevel.py:671-680: three sfb1d = six
+ * conv_transpose2d + three adds), also AFB2D.backward (dwt/lowlevel.py:350-365, the crop is done
+ * by passing a smaller OH/OW).
+ *   ll (planes,Kh,Kw) read through explicit strides (elements) so that the reference's
+ *   "unpad" slice ll[..., :-1, :] (dwt/transform2d.py:142-145) needs no copy;
+ *   highs (planes,3,Kh,Kw) dense or NULL (= zeros, dwt/transform2d.py:137-139);
+ *   y (planes,OH,OW) with OH <= 2*Kh-Lh+2 (2*Kh for periodization), OW likewise. */
+int wl_dwt2d_synthesis(const void* ll, int64_t ll_plane_stride, int ll_row_stride, const void* highs,
+                       void* y, int dtype, int64_t planes, int Kh, int Kw, int OH, int OW,
+                       const void* g_w_lo, const void* g_w_hi, int Lw,
+                       const void* g_h_lo, const void* g_h_hi, int Lh, int mode, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVELETS_HIP_H */

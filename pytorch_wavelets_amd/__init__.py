@@ -1,1 +1,16 @@
+"""pytorch_wavelets_amd - MI355X-native (gfx950) 2-D wavelet filterbank engine.
+
+Drop-in for the DWT / DTCWT hot path of fbcotter/pytorch_wavelets: the same nn.Module API and
+(yl, yh) tensor layout, computed by hand-written HIP kernels behind a C ABI
+(include/wavelets_hip.h).  There is no CPU path: tensors must live on a cuda (ROCm) device.
+"""
 __version__ = '0.1.0'
+
+from .dwt.transform2d import DWTForward, DWTInverse   # noqa: E402,F401
+
+DWT = DWTForward
+IDWT = DWTInverse
+DWT2D = DWT
+IDWT2D = IDWT
+
+__all__ = ['__version__', 'DWTForward', 'DWTInverse', 'DWT', 'IDWT', 'DWT2D', 'IDWT2D']

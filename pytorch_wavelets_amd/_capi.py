@@ -1,0 +1,24 @@
+"""ctypes prototypes for the C ABI declared in include/wavelets_hip.h."""
+import ctypes as C
+
+P = C.c_void_p
+I = C.c_int
+L = C.c_int64
+
+PROTOTYPES = {
+    'wl_version': (I, []),
+    'wl_backend': (C.c_char_p, []),
+    'wl_dwt_coeff_len': (I, [I, I, I]),
+    'wl_dwt2d_analysis': (I, [P, P, P, I, L, I, I, P, P, I, P, P, I, I, P]),
+    'wl_dwt2d_synthesis': (I, [P, L, I, P, P, I, L, I, I, I, I, P, P, I, P, P, I, I, P]),
+}
+
+
+def bind(lib):
+    """Attach argtypes/restype for every exported entry point; raises AttributeError when the
+    library does not export a symbol the header declares."""
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib

@@ -1,0 +1,36 @@
+// HIP launch backend (the product).  One generic __global__ wrapper per kernel functor.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "wl_common.h"
+
+#define WL_BACKEND_NAME "hip-gfx950"
+
+template <typename K>
+__global__ void __launch_bounds__(K::kThreads) wl_kernel(const typename K::Args a) {
+    extern __shared__ __attribute__((aligned(16))) char wl_smem[];
+    WlCtx ctx;
+    ctx.tid = threadIdx.x;
+    ctx.nthreads = K::kThreads;
+    ctx.bid = blockIdx.x;
+    ctx.smem = wl_smem;
+    K::run(a, ctx);
+}
+
+template <typename K>
+static int wl_launch(const typename K::Args& a, int64_t nblocks, size_t lds, void* stream) {
+    if (nblocks <= 0) return 0;
+    if (nblocks > 2147483647LL || lds > 160 * 1024) return -2;
+    if (lds > 48 * 1024) {
+        // opt in to large dynamic LDS once per kernel (idempotent, cheap)
+        static thread_local size_t granted = 0;
+        if (lds > granted) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wl_kernel<K>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            granted = 160 * 1024;
+        }
+    }
+    hipLaunchKernelGGL(wl_kernel<K>, dim3((unsigned)nblocks), dim3(K::kThreads), lds,
+                       reinterpret_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}

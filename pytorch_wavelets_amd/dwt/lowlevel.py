@@ -1,0 +1,166 @@
+"""Per-scale DWT operators (layer L2 of SURVEY.md): the autograd Functions the reference exposes in
+``pytorch_wavelets/dwt/lowlevel.py``, with the same names, argument order, mode codes and error
+text - but each forward/backward is ONE fused gfx950 kernel launch through the C ABI instead of
+a chain of ATen gathers / grouped convs / copies.
+"""
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from .. import ops
+
+_MODE_TO_INT = {'zero': 0, 'symmetric': 1, 'per': 2, 'periodization': 2, 'constant': 3, 'reflect': 4,
+                'replicate': 5, 'periodic': 6}
+_INT_TO_MODE = {0: 'zero', 1: 'symmetric', 2: 'periodization', 3: 'constant', 4: 'reflect',
+                5: 'replicate', 6: 'periodic'}
+_FILTERBANK_MODES = (0, 1, 2, 4, 6)   # the ones afb1d/sfb1d accept upstream (dwt/lowlevel.py:134-170)
+
+
+def mode_to_int(mode):
+    """Reference dwt/lowlevel.py:274-290."""
+    try:
+        return _MODE_TO_INT[mode]
+    except (KeyError, TypeError):
+        raise ValueError("Unkown pad type: {}".format(mode))
+
+
+def int_to_mode(mode):
+    """Reference dwt/lowlevel.py:293-309."""
+    try:
+        return _INT_TO_MODE[mode]
+    except (KeyError, TypeError):
+        raise ValueError("Unkown pad type: {}".format(mode))
+
+
+def _check_bank_mode(mode):
+    if mode not in _FILTERBANK_MODES:
+        raise ValueError("Unkown pad type: {}".format(int_to_mode(mode)))
+
+
+class AFB2D(Function):
+    """One level of 2-D analysis.  ``AFB2D.apply(x, h0_row, h1_row, h0_col, h1_col, mode_int)
+    -> (low (N,C,H',W'), highs (N,C,3,H',W'))``; the *row* pair filters along W, the *col* pair
+    along H (reference dwt/lowlevel.py:336-347).  Backward = synthesis with the same stored taps,
+    cropped to the input size (reference :350-365, quirk Q9 reproduced)."""
+
+    @staticmethod
+    def forward(ctx, x, h0_row, h1_row, h0_col, h1_col, mode):
+        _check_bank_mode(mode)
+        ctx.save_for_backward(h0_row, h1_row, h0_col, h1_col)
+        ctx.shape = x.shape[-2:]
+        ctx.mode = mode
+        return ops.afb2d(x, h0_row, h1_row, h0_col, h1_col, mode)
+
+    @staticmethod
+    def backward(ctx, low, highs):
+        dx = None
+        if ctx.needs_input_grad[0]:
+            h0_row, h1_row, h0_col, h1_col = ctx.saved_tensors
+            dx = ops.sfb2d(low, highs, h0_row, h1_row, h0_col, h1_col, ctx.mode,
+                           out_hw=tuple(ctx.shape))
+        return dx, None, None, None, None, None
+
+
+class SFB2D(Function):
+    """One level of 2-D synthesis.  ``SFB2D.apply(low, highs, g0_row, g1_row, g0_col, g1_col,
+    mode_int) -> y`` (reference dwt/lowlevel.py:671-680).  Backward = analysis with the stored
+    synthesis taps (reference :683-694)."""
+
+    @staticmethod
+    def forward(ctx, low, highs, g0_row, g1_row, g0_col, g1_col, mode):
+        _check_bank_mode(mode)
+        ctx.mode = mode
+        ctx.save_for_backward(g0_row, g1_row, g0_col, g1_col)
+        ctx.has_highs = highs is not None
+        return ops.sfb2d(low, highs, g0_row, g1_row, g0_col, g1_col, mode)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dlow, dhigh = None, None
+        if ctx.needs_input_grad[0] or (ctx.has_highs and ctx.needs_input_grad[1]):
+            g0_row, g1_row, g0_col, g1_col = ctx.saved_tensors
+            dlow, dhigh = ops.afb2d(dy, g0_row, g1_row, g0_col, g1_col, ctx.mode)
+            if not ctx.has_highs:
+                dhigh = None
+        return dlow, dhigh, None, None, None, None, None
+
+
+def afb2d(x, filts, mode='zero'):
+    """Function-level analysis (reference dwt/lowlevel.py:427-472): ``filts`` is a 2- or 4-tuple
+    of arrays / tensors (h0_col, h1_col[, h0_row, h1_row]); here the *col* pair really filters
+    along H (the Module path swaps them, quirk Q1).  Returns (N, 4C, H', W')."""
+    tensorize = [not isinstance(f, torch.Tensor) for f in filts]
+    if len(filts) == 2:
+        h0, h1 = filts
+        if True in tensorize:
+            h0_col, h1_col, h0_row, h1_row = prep_filt_afb2d(h0, h1, device=x.device)
+        else:
+            h0_col, h0_row, h1_col, h1_row = h0, h0.transpose(2, 3), h1, h1.transpose(2, 3)
+    elif len(filts) == 4:
+        if True in tensorize:
+            h0_col, h1_col, h0_row, h1_row = prep_filt_afb2d(*filts, device=x.device)
+        else:
+            h0_col, h1_col, h0_row, h1_row = filts
+    else:
+        raise ValueError("Unknown form for input filts")
+    low, highs = AFB2D.apply(x, h0_row, h1_row, h0_col, h1_col, mode_to_int(mode))
+    n, c = low.shape[:2]
+    return torch.cat([low[:, :, None], highs], dim=2).reshape(n, 4 * c, low.shape[-2], low.shape[-1])
+
+
+def sfb2d(ll, lh, hl, hh, filts, mode='zero'):
+    """Function-level synthesis (reference dwt/lowlevel.py:600-644)."""
+    tensorize = [not isinstance(f, torch.Tensor) for f in filts]
+    if len(filts) == 2:
+        g0, g1 = filts
+        if True in tensorize:
+            g0_col, g1_col, g0_row, g1_row = prep_filt_sfb2d(g0, g1, device=ll.device)
+        else:
+            g0_col, g0_row, g1_col, g1_row = g0, g0.transpose(2, 3), g1, g1.transpose(2, 3)
+    elif len(filts) == 4:
+        if True in tensorize:
+            g0_col, g1_col, g0_row, g1_row = prep_filt_sfb2d(*filts, device=ll.device)
+        else:
+            g0_col, g1_col, g0_row, g1_row = filts
+    else:
+        raise ValueError("Unknown form for input filts")
+    highs = torch.stack([lh, hl, hh], dim=2)
+    return SFB2D.apply(ll, highs, g0_row, g1_row, g0_col, g1_col, mode_to_int(mode))
+
+
+# ---- filter preparation (buffer shapes/orders are part of the state_dict contract) -----------------
+def _vec(h, reverse, device):
+    h = np.array(h, dtype=np.float64).ravel()
+    if reverse:
+        h = h[::-1].copy()
+    return torch.tensor(h, device=device, dtype=torch.get_default_dtype())
+
+
+def prep_filt_afb1d(h0, h1, device=None):
+    """Analysis taps are stored reversed, shape (1,1,L) (reference dwt/lowlevel.py:956-975)."""
+    return _vec(h0, True, device).reshape(1, 1, -1), _vec(h1, True, device).reshape(1, 1, -1)
+
+
+def prep_filt_sfb1d(g0, g1, device=None):
+    """Synthesis taps are stored as given (reference dwt/lowlevel.py:902-922)."""
+    return _vec(g0, False, device).reshape(1, 1, -1), _vec(g1, False, device).reshape(1, 1, -1)
+
+
+def _to_2d(col0, col1, row0, row1):
+    return (col0.reshape(1, 1, -1, 1), col1.reshape(1, 1, -1, 1),
+            row0.reshape(1, 1, 1, -1), row1.reshape(1, 1, 1, -1))
+
+
+def prep_filt_afb2d(h0_col, h1_col, h0_row=None, h1_row=None, device=None):
+    """(h0_col, h1_col, h0_row, h1_row) with shapes (1,1,L,1) / (1,1,1,L)
+    (reference dwt/lowlevel.py:925-953)."""
+    c0, c1 = prep_filt_afb1d(h0_col, h1_col, device)
+    r0, r1 = (c0, c1) if h0_row is None else prep_filt_afb1d(h0_row, h1_row, device)
+    return _to_2d(c0, c1, r0, r1)
+
+
+def prep_filt_sfb2d(g0_col, g1_col, g0_row=None, g1_row=None, device=None):
+    """(g0_col, g1_col, g0_row, g1_row) (reference dwt/lowlevel.py:870-899)."""
+    c0, c1 = prep_filt_sfb1d(g0_col, g1_col, device)
+    r0, r1 = (c0, c1) if g0_row is None else prep_filt_sfb1d(g0_row, g1_row, device)
+    return _to_2d(c0, c1, r0, r1)

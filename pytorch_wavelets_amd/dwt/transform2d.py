@@ -1,0 +1,77 @@
+"""DWTForward / DWTInverse with the reference's constructor signature, buffer names, (yl, yh)
+layout and quirks (pytorch_wavelets/dwt/transform2d.py:7-148), running on the gfx950 engine."""
+import torch
+import torch.nn as nn
+
+from .. import filters
+from . import lowlevel
+
+
+def _resolve_bank(wave, lo_attr, hi_attr):
+    """str | Wavelet-like | (f0, f1) | (f0_col, f1_col, f0_row, f1_row) -> four tap vectors."""
+    if isinstance(wave, str):
+        wave = filters.Wavelet(wave)
+    if filters.is_wavelet_like(wave):
+        c0, c1 = getattr(wave, lo_attr), getattr(wave, hi_attr)
+        return c0, c1, c0, c1
+    if len(wave) == 2:
+        return wave[0], wave[1], wave[0], wave[1]
+    if len(wave) == 4:
+        return wave[0], wave[1], wave[2], wave[3]
+    raise ValueError("wave must be a name, a Wavelet, or a tuple of 2 or 4 filters")
+
+
+class DWTForward(nn.Module):
+    """2-D multi-level DWT.  ``DWTForward(J=1, wave='db1', mode='zero')(x) -> (yl, yh)`` with
+    ``yh[j]`` of shape (N, C, 3, H_j, W_j), finest scale first (reference transform2d.py:7-74)."""
+
+    def __init__(self, J=1, wave='db1', mode='zero'):
+        super().__init__()
+        h0_col, h1_col, h0_row, h1_row = _resolve_bank(wave, 'dec_lo', 'dec_hi')
+        filts = lowlevel.prep_filt_afb2d(h0_col, h1_col, h0_row, h1_row)
+        self.register_buffer('h0_col', filts[0])
+        self.register_buffer('h1_col', filts[1])
+        self.register_buffer('h0_row', filts[2])
+        self.register_buffer('h1_row', filts[3])
+        self.J = J
+        self.mode = mode
+
+    def forward(self, x):
+        yh = []
+        ll = x
+        mode = lowlevel.mode_to_int(self.mode)
+        for _ in range(self.J):
+            # NB argument order: the module's *col* pair lands in AFB2D's row slots (quirk Q1,
+            # reference transform2d.py:70-71)
+            ll, high = lowlevel.AFB2D.apply(ll, self.h0_col, self.h1_col, self.h0_row, self.h1_row, mode)
+            yh.append(high)
+        return ll, yh
+
+
+class DWTInverse(nn.Module):
+    """2-D multi-level inverse DWT.  ``DWTInverse(wave='db1', mode='zero')((yl, yh)) -> x``;
+    ``None`` entries of ``yh`` are zeros (reference transform2d.py:77-148)."""
+
+    def __init__(self, wave='db1', mode='zero'):
+        super().__init__()
+        g0_col, g1_col, g0_row, g1_row = _resolve_bank(wave, 'rec_lo', 'rec_hi')
+        filts = lowlevel.prep_filt_sfb2d(g0_col, g1_col, g0_row, g1_row)
+        self.register_buffer('g0_col', filts[0])
+        self.register_buffer('g1_col', filts[1])
+        self.register_buffer('g0_row', filts[2])
+        self.register_buffer('g1_row', filts[3])
+        self.mode = mode
+
+    def forward(self, coeffs):
+        yl, yh = coeffs
+        ll = yl
+        mode = lowlevel.mode_to_int(self.mode)
+        for h in yh[::-1]:
+            if h is not None:
+                # 'unpad': drop the extra row/col an odd-sized finer level produced
+                if ll.shape[-2] > h.shape[-2]:
+                    ll = ll[..., :-1, :]
+                if ll.shape[-1] > h.shape[-1]:
+                    ll = ll[..., :-1]
+            ll = lowlevel.SFB2D.apply(ll, h, self.g0_col, self.g1_col, self.g0_row, self.g1_row, mode)
+        return ll
