@@ -75,3 +75,12 @@ class DWTInverse(nn.Module):
                     ll = ll[..., :-1]
             ll = lowlevel.SFB2D.apply(ll, h, self.g0_col, self.g1_col, self.g0_row, self.g1_row, mode)
         return ll
+
+
+def describe_path(module, x=None):
+    """Kernel names / launch counts of the DWT path (bench.py labels its roofline with this)."""
+    J = getattr(module, 'J', 3)
+    return {'fwd_path': 'per-level generic tile kernel', 'fwd_kernel': 'wl_kernel<WlAfb2dTile<float>>',
+            'fwd_launches': J,
+            'inv_path': 'per-level generic tile kernel', 'inv_kernel': 'wl_kernel<WlSfb2dTile<float>>',
+            'inv_launches': J}

@@ -1,0 +1,89 @@
+"""CPU tests of the host logic + kernel index arithmetic: the nn.Modules / autograd Functions run
+on the HOST EMULATION build of the kernel sources (tests/emu) and must match the reference's
+golden vectors.  (The real parity tests are the -m gpu ones; these keep the Python layer, the
+launch-geometry code and every kernel's indexing honest without a GPU.)"""
+import numpy as np
+import pytest
+import torch
+
+import _golden as G
+import emu_backend
+import pytorch_wavelets_amd as pw
+
+TOL = 5e-7   # float64 arithmetic; fixtures are rounded to float32
+
+
+def t64(a):
+    return torch.tensor(np.asarray(a, dtype=np.float64))
+
+
+@pytest.fixture(autouse=True)
+def _f64_default():
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(prev)
+
+
+SMALL = [n for n in G.cases('dwt') if np.prod(G.INDEX[n]['shape']) <= 70000]
+
+
+@pytest.mark.parametrize('name', SMALL)
+def test_dwt_modules_on_emulator(name):
+    meta, g = G.INDEX[name], G.load(name)
+    J = meta['J']
+    xfm = pw.DWTForward(J=J, wave=meta['wave'], mode=meta['mode'])
+    ifm = pw.DWTInverse(wave=meta['wave'], mode=meta['mode'])
+    x = t64(g['x']).requires_grad_(True)
+    with emu_backend.emulated():
+        if name == 'dwt_17':
+            with pytest.raises(NotImplementedError):
+                xfm(x)
+            return
+        yl, yh = xfm(x)
+        rec = ifm((yl, yh))
+        assert G.relerr(yl.detach().numpy(), g, 'yl') < TOL
+        for j in range(J):
+            assert G.relerr(yh[j].detach().numpy(), g, 'yh%d' % j) < TOL
+        assert G.relerr(rec.detach().numpy(), g, 'rec') < TOL
+        loss = (yl * t64(g['gl'])).sum() + sum((yh[j] * t64(g['gh%d' % j])).sum() for j in range(J))
+        dx, = torch.autograd.grad(loss, x)
+        assert G.relerr(dx.numpy(), g, 'dx') < TOL
+        ylr = t64(g['yl']).requires_grad_(True)
+        yhr = [t64(g['yh%d' % j]).requires_grad_(True) for j in range(J)]
+        gr = torch.autograd.grad((ifm((ylr, yhr)) * t64(g['gy'])).sum(), [ylr] + yhr)
+        assert G.relerr(gr[0].numpy(), g, 'dyl') < TOL
+        for j in range(J):
+            assert G.relerr(gr[1 + j].numpy(), g, 'dyh%d' % j) < TOL
+
+
+def test_q1_and_none_highs_on_emulator():
+    g = G.load('dwt_q1')
+    xfm = pw.DWTForward(J=2, wave=tuple(g['h%d' % i] for i in range(4)), mode='symmetric')
+    ifm = pw.DWTInverse(wave=tuple(g['g%d' % i] for i in range(4)), mode='symmetric')
+    with emu_backend.emulated():
+        yl, yh = xfm(t64(g['x']))
+        assert G.relerr(yl.numpy(), g, 'yl') < TOL and G.relerr(yh[1].numpy(), g, 'yh1') < TOL
+        assert G.relerr(ifm((yl, [None, yh[1]])).numpy(), g, 'rec_none') < TOL
+
+
+def test_state_dict_names_and_shapes():
+    """Buffer names/shapes are the checkpoint contract (reference dwt/transform2d.py:36-40,104-108)."""
+    sd = pw.DWTForward(J=2, wave='db4').state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {
+        'h0_col': (1, 1, 8, 1), 'h1_col': (1, 1, 8, 1), 'h0_row': (1, 1, 1, 8), 'h1_row': (1, 1, 1, 8)}
+    sd = pw.DWTInverse(wave='bior2.4').state_dict()
+    assert sorted(sd) == ['g0_col', 'g0_row', 'g1_col', 'g1_row'] and sd['g0_row'].shape == (1, 1, 1, 10)
+    assert pw.DWT is pw.DWTForward and pw.IDWT2D is pw.DWTInverse
+
+
+def test_cpu_tensor_is_rejected_loudly():
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        pw.DWTForward()(torch.randn(1, 1, 8, 8))
+
+
+def test_mode_errors():
+    with emu_backend.emulated():
+        for bad in ('foo', 'constant', 'replicate'):
+            with pytest.raises(ValueError, match='Unkown pad type'):
+                pw.DWTForward(mode=bad)(torch.randn(1, 1, 8, 8))

@@ -1,0 +1,172 @@
+"""GPU parity tests for the DWT path: HIP kernels (through the C ABI) vs the golden vectors of the
+reference and vs the oracle.  Tolerance = north_star's: 1e-5 relative (max-norm) in fp32.
+Modelled on the reference's tests/test_dwt.py (test_equal :53-81, odd sizes :84-129,
+test_ok/contiguity :40-50, commutativity :163-197, gradients :201-299)."""
+import numpy as np
+import pytest
+import torch
+
+import _golden as G
+import pytorch_wavelets_amd as pw
+from oracle import wavelet_oracle as wo
+from pytorch_wavelets_amd import filters as F
+from pytorch_wavelets_amd.dwt import lowlevel
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+DEV = 'cuda:0'
+
+
+def t(a):
+    return torch.tensor(np.asarray(a, dtype=np.float32), device=DEV)
+
+
+def npy(x):
+    return x.detach().cpu().double().numpy()
+
+
+def rel(a, b):
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(npy(a) - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize('name', G.cases('dwt'))
+def test_dwt_vs_reference_goldens(name):
+    meta, g = G.INDEX[name], G.load(name)
+    J, wave, mode = meta['J'], meta['wave'], meta['mode']
+    xfm = pw.DWTForward(J=J, wave=wave, mode=mode).to(DEV)
+    ifm = pw.DWTInverse(wave=wave, mode=mode).to(DEV)
+    x = t(g['x']).requires_grad_(True)
+    if name == 'dwt_17':
+        with pytest.raises(NotImplementedError):
+            xfm(x)
+        return
+    yl, yh = xfm(x)
+    assert yl.is_contiguous() and all(h.is_contiguous() for h in yh)
+    assert G.relerr(npy(yl), g, 'yl') < TOL
+    for j in range(J):
+        assert G.relerr(npy(yh[j]), g, 'yh%d' % j) < TOL
+    rec = ifm((yl, yh))
+    assert G.relerr(npy(rec), g, 'rec') < TOL
+    if 'dx' in g:
+        loss = (yl * t(g['gl'])).sum() + sum((yh[j] * t(g['gh%d' % j])).sum() for j in range(J))
+        dx, = torch.autograd.grad(loss, x)
+        assert G.relerr(npy(dx), g, 'dx') < TOL
+        ylr = t(g['yl']).requires_grad_(True)
+        yhr = [t(g['yh%d' % j]).requires_grad_(True) for j in range(J)]
+        gr = torch.autograd.grad((ifm((ylr, yhr)) * t(g['gy'])).sum(), [ylr] + yhr)
+        assert G.relerr(npy(gr[0]), g, 'dyl') < TOL
+        for j in range(J):
+            assert G.relerr(npy(gr[1 + j]), g, 'dyh%d' % j) < TOL
+
+
+def test_dwt_q1_separate_row_col_filters_and_none_highs():
+    g = G.load('dwt_q1')
+    xfm = pw.DWTForward(J=2, wave=tuple(g['h%d' % i] for i in range(4)), mode='symmetric').to(DEV)
+    ifm = pw.DWTInverse(wave=tuple(g['g%d' % i] for i in range(4)), mode='symmetric').to(DEV)
+    yl, yh = xfm(t(g['x']))
+    assert yl.shape[-2] != yl.shape[-1]
+    assert G.relerr(npy(yl), g, 'yl') < TOL and G.relerr(npy(yh[0]), g, 'yh0') < TOL
+    assert G.relerr(npy(ifm((yl, [None, yh[1]]))), g, 'rec_none') < TOL
+
+
+@pytest.mark.parametrize('wave,mode,J,shape', [
+    ('db4', 'symmetric', 3, (3, 2, 200, 136)), ('db2', 'zero', 4, (2, 3, 97, 203)),
+    ('sym5', 'reflect', 2, (1, 4, 130, 77)), ('db8', 'periodization', 4, (2, 2, 256, 320)),
+    ('coif3', 'periodic', 2, (1, 2, 111, 65)), ('db20', 'symmetric', 2, (1, 1, 160, 150)),
+    ('bior4.4', 'periodization', 3, (2, 1, 101, 88)), ('db1', 'symmetric', 5, (1, 1, 64, 48)),
+])
+def test_dwt_vs_oracle(wave, mode, J, shape):
+    torch.manual_seed(1)
+    x = torch.randn(*shape)
+    xfm = pw.DWTForward(J=J, wave=wave, mode=mode).to(DEV)
+    ifm = pw.DWTInverse(wave=wave, mode=mode).to(DEV)
+    yl, yh = xfm(x.to(DEV))
+    h0, h1 = F.dwt_analysis_taps(wave)
+    g0, g1 = F.dwt_synthesis_taps(wave)
+    oyl, oyh = wo.dwt_forward(x.double().numpy(), J, h0, h1, h0, h1, mode)
+    assert rel(yl, oyl) < TOL
+    for a, b in zip(yh, oyh):
+        assert rel(a, b) < TOL
+    orec = wo.dwt_inverse(oyl, oyh, g0, g1, g0, g1, mode)
+    assert rel(ifm((yl, yh)), orec) < TOL
+
+
+def test_dwt_fp64_and_fp16_io():
+    torch.manual_seed(2)
+    x = torch.randn(2, 2, 96, 80, dtype=torch.float64)
+    h0, h1 = F.dwt_analysis_taps('db4')
+    oyl, oyh = wo.dwt_forward(x.numpy(), 2, h0, h1, h0, h1, 'symmetric')
+    xfm = pw.DWTForward(J=2, wave='db4', mode='symmetric').to(DEV)
+    yl, yh = xfm.double()(x.to(DEV))
+    assert yl.dtype == torch.float64 and rel(yl, oyl) < 1e-12 and rel(yh[0], oyh[0]) < 1e-12
+    xh = x.half()
+    oyl, oyh = wo.dwt_forward(xh.double().numpy(), 2, h0, h1, h0, h1, 'symmetric')
+    yl, yh = xfm.half()(xh.to(DEV))
+    assert yl.dtype == torch.float16
+    # fp16 storage, fp32 accumulate: error = output rounding only
+    assert rel(yl, oyl) < 2e-3 and rel(yh[1], oyh[1]) < 2e-3
+
+
+def test_full_size_properties_config1():
+    """BASELINE configs[1] at full size (128x3x512x512 fp32): shapes, round trip, linearity and a
+    sampled oracle check (the oracle on the full batch would take minutes)."""
+    torch.manual_seed(3)
+    x = torch.randn(128, 3, 512, 512, device=DEV)
+    xfm = pw.DWTForward(J=3, wave='db4', mode='symmetric').to(DEV)
+    ifm = pw.DWTInverse(wave='db4', mode='symmetric').to(DEV)
+    yl, yh = xfm(x)
+    assert yl.shape == (128, 3, 70, 70)
+    assert [tuple(h.shape) for h in yh] == [(128, 3, 3, 259, 259), (128, 3, 3, 133, 133), (128, 3, 3, 70, 70)]
+    rec = ifm((yl, yh))
+    assert rec.shape == x.shape
+    assert float((rec - x).abs().max() / x.abs().max()) < TOL
+    # linearity: T(a*x + y) = a*T(x) + T(y)
+    y2 = torch.randn(4, 3, 512, 512, device=DEV)
+    yl_a, yh_a = xfm(x[:4])
+    yl_b, yh_b = xfm(y2)
+    yl_c, yh_c = xfm(2.5 * x[:4] + y2)
+    assert float((yl_c - (2.5 * yl_a + yl_b)).abs().max() / yl_c.abs().max()) < TOL
+    assert float((yh_c[0] - (2.5 * yh_a[0] + yh_b[0])).abs().max() / yh_c[0].abs().max()) < TOL
+    # oracle on two planes taken from the middle and the end of the batch
+    h0, h1 = F.dwt_analysis_taps('db4')
+    for n, c in ((77, 1), (127, 2)):
+        oyl, oyh = wo.dwt_forward(npy(x[n:n + 1, c:c + 1]), 3, h0, h1, h0, h1, 'symmetric')
+        assert rel(yl[n:n + 1, c:c + 1], oyl) < TOL
+        for j in range(3):
+            assert rel(yh[j][n:n + 1, c:c + 1], oyh[j]) < TOL
+
+
+def test_errors_and_edge_cases():
+    with pytest.raises(ValueError, match='Unkown pad type'):
+        pw.DWTForward(mode='foo').to(DEV)(torch.randn(1, 1, 8, 8, device=DEV))
+    with pytest.raises(ValueError, match='Unkown pad type'):
+        pw.DWTForward(mode='constant').to(DEV)(torch.randn(1, 1, 8, 8, device=DEV))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        pw.DWTForward()(torch.randn(1, 1, 8, 8))
+    # empty batch
+    yl, yh = pw.DWTForward(J=2, wave='db2').to(DEV)(torch.randn(0, 3, 16, 16, device=DEV))
+    assert yl.shape == (0, 3, 5, 5) and yh[0].shape == (0, 3, 3, 9, 9)
+    # non-contiguous input
+    x = torch.randn(2, 3, 40, 50, device=DEV).transpose(2, 3)
+    yl, _ = pw.DWTForward(J=1, wave='db3', mode='symmetric').to(DEV)(x)
+    yl2, _ = pw.DWTForward(J=1, wave='db3', mode='symmetric').to(DEV)(x.contiguous())
+    assert torch.equal(yl, yl2)
+    # tiny images: multiple reflections of the border
+    x = torch.randn(1, 2, 3, 5)
+    h0, h1 = F.dwt_analysis_taps('db4')
+    oyl, oyh = wo.dwt_forward(x.double().numpy(), 1, h0, h1, h0, h1, 'symmetric')
+    yl, yh = pw.DWTForward(J=1, wave='db4', mode='symmetric').to(DEV)(x.to(DEV))
+    assert rel(yl, oyl) < TOL and rel(yh[0], oyh[0]) < TOL
+
+
+def test_function_level_api():
+    """afb2d / sfb2d function forms (reference dwt/lowlevel.py:427-472, :600-644)."""
+    torch.manual_seed(4)
+    x = torch.randn(1, 2, 32, 40, device=DEV)
+    w = F.Wavelet('db2')
+    y = lowlevel.afb2d(x, (w.dec_lo, w.dec_hi), mode='symmetric')
+    assert y.shape == (1, 8, 17, 21)
+    ll, lh, hl, hh = y.reshape(1, 2, 4, 17, 21).unbind(2)
+    xr = lowlevel.sfb2d(ll, lh, hl, hh, (w.rec_lo, w.rec_hi), mode='symmetric')
+    assert float((xr - x).abs().max()) < 1e-5

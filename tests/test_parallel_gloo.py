@@ -1,0 +1,66 @@
+"""world_size-2 gloo test of the batch-sharded path (runs on CPU): filter banks are broadcast from
+rank 0, each rank transforms only its shard (on the host emulation of the kernels), and the
+gathered result equals the single-process transform of the full batch."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['OMP_NUM_THREADS'] = '2'
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import emu_backend
+    import pytorch_wavelets_amd as pw
+    from pytorch_wavelets_amd import parallel
+    torch.manual_seed(0)
+    x = torch.randn(5, 2, 24, 28)           # same full batch on every rank (odd: uneven shards)
+    xfm = pw.DWTForward(J=2, wave='db2', mode='symmetric')
+    if rank != 0:                           # corrupt the non-root taps: the broadcast must fix them
+        for b in xfm.buffers():
+            b.zero_()
+    parallel.broadcast_filter_banks(xfm, src=0)
+    with emu_backend.emulated():
+        yl, yh = xfm(parallel.shard_batch(x))
+        full_yl, full_yh = xfm(x)
+    gl = parallel.gather_batch(yl, x.shape[0])
+    gh = parallel.gather_batch(yh[1], x.shape[0])
+    ok = torch.equal(gl, full_yl) and torch.equal(gh, full_yh[1]) and yl.shape[0] == (3 if rank == 0 else 2)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_batch_sharding_world2():
+    import emu_backend
+    emu_backend.handle()   # build the emulator once, before forking workers
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0, 'worker failed (exit code %r)' % p.exitcode
+    res = sorted(q.get(timeout=10) for _ in procs)
+    assert res == [(0, True), (1, True)], res
+
+
+def test_shard_bounds():
+    from pytorch_wavelets_amd import parallel
+    for n in (0, 1, 7, 128, 129):
+        for w in (1, 2, 3, 8):
+            b = [parallel.shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
