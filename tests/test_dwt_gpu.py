@@ -97,9 +97,16 @@ def test_dwt_fp64_and_fp16_io():
     x = torch.randn(2, 2, 96, 80, dtype=torch.float64)
     h0, h1 = F.dwt_analysis_taps('db4')
     oyl, oyh = wo.dwt_forward(x.numpy(), 2, h0, h1, h0, h1, 'symmetric')
-    xfm = pw.DWTForward(J=2, wave='db4', mode='symmetric').to(DEV)
-    yl, yh = xfm.double()(x.to(DEV))
+    # like upstream, buffers are created in the default dtype: build the module under a float64
+    # default to get full-precision taps (tests/test_dwt.py:132-160 upstream does the same)
+    torch.set_default_dtype(torch.float64)
+    try:
+        xfm64 = pw.DWTForward(J=2, wave='db4', mode='symmetric').to(DEV)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    yl, yh = xfm64(x.to(DEV))
     assert yl.dtype == torch.float64 and rel(yl, oyl) < 1e-12 and rel(yh[0], oyh[0]) < 1e-12
+    xfm = pw.DWTForward(J=2, wave='db4', mode='symmetric').to(DEV)
     xh = x.half()
     oyl, oyh = wo.dwt_forward(xh.double().numpy(), 2, h0, h1, h0, h1, 'symmetric')
     yl, yh = xfm.half()(xh.to(DEV))
