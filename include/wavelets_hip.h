@@ -66,6 +66,17 @@ int wl_dwt2d_synthesis(const void* ll, int64_t ll_plane_stride, int ll_row_strid
                        const void* g_w_lo, const void* g_w_hi, int Lw,
                        const void* g_h_lo, const void* g_h_hi, int Lh, int mode, void* stream);
 
+/* `nlev` (1..4) analysis levels in ONE launch = the body of DWTForward.forward's level loop
+ * (dwt/transform2d.py:63-74): x (planes,H,W) -> yh[j] (planes,3,H_j,W_j) for j < nlev and the last
+ * level's low-pass yl; the intermediate LL_j stay in LDS.  `yh` is a HOST array of nlev device
+ * pointers.  Same taps (length L) on both axes of every level, F32/F16 data, float taps.
+ * zero / symmetric / reflect for nlev > 1, any mode for nlev == 1.  `strips` = workgroups per
+ * plane (0 = choose).  Returns WL_ERR_UNSUPPORTED when the configuration is outside this kernel's
+ * envelope (the caller then uses wl_dwt2d_analysis level by level). */
+int wl_dwt2d_analysis_fused(const void* x, void* yl, void* const* yh, int dtype, int64_t planes, int H,
+                            int W, int nlev, const void* h_w_lo, const void* h_w_hi, const void* h_h_lo,
+                            const void* h_h_hi, int L, int mode, int strips, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

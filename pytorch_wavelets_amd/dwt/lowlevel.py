@@ -85,6 +85,49 @@ class SFB2D(Function):
         return dlow, dhigh, None, None, None, None, None
 
 
+class AFB2DMulti(Function):
+    """J analysis levels as ONE autograd node: ``AFB2DMulti.apply(x, h0_row, h1_row, h0_col, h1_col,
+    mode_int, J) -> (yl, yh_0, ..., yh_{J-1})``.
+
+    Forward = the fused streaming kernel (up to 4 levels per launch, LL_j never leave LDS) when it
+    covers the configuration, else J single-level launches.  Backward = the chain of J
+    AFB2D.backward steps of the reference (synthesis with the stored analysis taps + crop,
+    dwt/lowlevel.py:350-365), coarsest level first."""
+
+    @staticmethod
+    def forward(ctx, x, h0_row, h1_row, h0_col, h1_col, mode, J):
+        _check_bank_mode(mode)
+        ctx.save_for_backward(h0_row, h1_row, h0_col, h1_col)
+        ctx.mode = mode
+        shapes, yh, ll, done = [], [], x, 0
+        while done < J:
+            n = min(4, J - done)
+            res = ops.afb2d_fused(ll, h0_row, h1_row, h0_col, h1_col, mode, n) if n > 1 or J == 1 else None
+            if res is None:
+                n = 1
+                shapes.append(tuple(ll.shape[-2:]))
+                ll, high = ops.afb2d(ll, h0_row, h1_row, h0_col, h1_col, mode)
+                yh.append(high)
+            else:
+                shapes.append(tuple(ll.shape[-2:]))
+                ll, highs = res
+                shapes.extend(tuple(h.shape[-2:]) for h in highs[:-1])
+                yh.extend(highs)
+            done += n
+        ctx.shapes = shapes
+        return (ll,) + tuple(yh)
+
+    @staticmethod
+    def backward(ctx, dyl, *dyh):
+        dx = None
+        if ctx.needs_input_grad[0]:
+            h0_row, h1_row, h0_col, h1_col = ctx.saved_tensors
+            dx = dyl
+            for j in range(len(dyh) - 1, -1, -1):
+                dx = ops.sfb2d(dx, dyh[j], h0_row, h1_row, h0_col, h1_col, ctx.mode, out_hw=ctx.shapes[j])
+        return dx, None, None, None, None, None, None
+
+
 def afb2d(x, filts, mode='zero'):
     """Function-level analysis (reference dwt/lowlevel.py:427-472): ``filts`` is a 2- or 4-tuple
     of arrays / tensors (h0_col, h1_col[, h0_row, h1_row]); here the *col* pair really filters

@@ -37,15 +37,13 @@ class DWTForward(nn.Module):
         self.mode = mode
 
     def forward(self, x):
-        yh = []
-        ll = x
         mode = lowlevel.mode_to_int(self.mode)
-        for _ in range(self.J):
-            # NB argument order: the module's *col* pair lands in AFB2D's row slots (quirk Q1,
-            # reference transform2d.py:70-71)
-            ll, high = lowlevel.AFB2D.apply(ll, self.h0_col, self.h1_col, self.h0_row, self.h1_row, mode)
-            yh.append(high)
-        return ll, yh
+        if self.J < 1:
+            return x, []
+        # NB argument order: the module's *col* pair lands in the row slots (quirk Q1, reference
+        # transform2d.py:70-71).  All J levels are one autograd node / (up to) one kernel launch.
+        outs = lowlevel.AFB2DMulti.apply(x, self.h0_col, self.h1_col, self.h0_row, self.h1_row, mode, self.J)
+        return outs[0], list(outs[1:])
 
 
 class DWTInverse(nn.Module):
@@ -80,7 +78,7 @@ class DWTInverse(nn.Module):
 def describe_path(module, x=None):
     """Kernel names / launch counts of the DWT path (bench.py labels its roofline with this)."""
     J = getattr(module, 'J', 3)
-    return {'fwd_path': 'per-level generic tile kernel', 'fwd_kernel': 'wl_kernel<WlAfb2dTile<float>>',
-            'fwd_launches': J,
+    return {'fwd_path': 'fused %d-level streaming kernel (LL_j in LDS)' % J,
+            'fwd_kernel': 'wl_kernel<WlAfbStream<float, 8>>', 'fwd_launches': (J + 3) // 4,
             'inv_path': 'per-level generic tile kernel', 'inv_kernel': 'wl_kernel<WlSfb2dTile<float>>',
             'inv_launches': J}

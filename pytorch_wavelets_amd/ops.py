@@ -78,3 +78,32 @@ def sfb2d(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None):
                                        _stream(ll))
     _lib.check(rc, 'wl_dwt2d_synthesis')
     return y
+
+
+def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=0):
+    """`nlev` analysis levels in one launch (LL_j stay in LDS).  Returns (yl, [yh_0..]) or None when
+    the streaming kernel does not cover the configuration (caller goes level by level)."""
+    import ctypes
+    _check_tensor(x, 'x')
+    if x.dtype == torch.float64 or nlev < 1 or nlev > 4:
+        return None
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    hwl, hwh, hhl, hhh = (_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi))
+    L = hwl.numel()
+    if hhl.numel() != L:
+        return None
+    yh = []
+    h, w = H, W
+    for _ in range(nlev):
+        h, w = coeff_len(h, L, mode), coeff_len(w, L, mode)
+        yh.append(torch.empty((N, C, 3, h, w), dtype=x.dtype, device=x.device))
+    yl = torch.empty((N, C, h, w), dtype=x.dtype, device=x.device)
+    ptrs = (ctypes.c_void_p * nlev)(*[t.data_ptr() for t in yh])
+    rc = _backend().wl_dwt2d_analysis_fused(x.data_ptr(), yl.data_ptr(), ptrs, _DTYPES[x.dtype], N * C, H, W,
+                                            nlev, hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(),
+                                            hhh.data_ptr(), L, mode, strips, _stream(x))
+    if rc == -3:
+        return None
+    _lib.check(rc, 'wl_dwt2d_analysis_fused')
+    return yl, yh
