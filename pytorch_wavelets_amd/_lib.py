@@ -8,7 +8,7 @@ import os
 from . import _capi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libwavelets_hip.so')
+LIB_PATH = os.environ.get('WL_LIB') or os.path.join(_HERE, 'csrc', 'libwavelets_hip.so')   # WL_LIB: A/B builds
 _LIB = None
 
 

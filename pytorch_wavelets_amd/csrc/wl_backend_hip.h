@@ -6,7 +6,7 @@
 #define WL_BACKEND_NAME "hip-gfx950"
 
 template <typename K>
-__global__ void __launch_bounds__(K::kThreads) wl_kernel(const typename K::Args a) {
+__global__ void __launch_bounds__(K::kThreads, K::kMinWaves) wl_kernel(const typename K::Args a) {
     extern __shared__ __attribute__((aligned(16))) char wl_smem[];
     WlCtx ctx;
     ctx.tid = threadIdx.x;

@@ -85,12 +85,17 @@ class SFB2D(Function):
         return dlow, dhigh, None, None, None, None, None
 
 
+import os as _os
+_STREAM = bool(_os.environ.get('WL_STREAM'))           # experimental streaming kernels instead of tiles
+_FUSE_DEEP = bool(_os.environ.get('WL_STREAM_FUSE'))   # ... with levels 2..4 fused in one launch
+
+
 class AFB2DMulti(Function):
     """J analysis levels as ONE autograd node: ``AFB2DMulti.apply(x, h0_row, h1_row, h0_col, h1_col,
     mode_int, J) -> (yl, yh_0, ..., yh_{J-1})``.
 
-    Forward = the fused streaming kernel (up to 4 levels per launch, LL_j never leave LDS) when it
-    covers the configuration, else J single-level launches.  Backward = the chain of J
+    Forward = one specialised tile-kernel launch per level (generic kernel for unusual tap counts /
+    float64); the experimental streaming kernels are selected with WL_STREAM=1.  Backward = the chain of J
     AFB2D.backward steps of the reference (synthesis with the stored analysis taps + crop,
     dwt/lowlevel.py:350-365), coarsest level first."""
 
@@ -101,8 +106,16 @@ class AFB2DMulti(Function):
         ctx.mode = mode
         shapes, yh, ll, done = [], [], x, 0
         while done < J:
-            n = min(4, J - done)
-            res = ops.afb2d_fused(ll, h0_row, h1_row, h0_col, h1_col, mode, n) if n > 1 or J == 1 else None
+            # default: one specialised tile-kernel launch per level (wl_dwt2d_analysis).  WL_STREAM=1 selects
+            # the streaming kernels instead (level 1 alone, then up to three levels fused with WL_STREAM_FUSE=1):
+            # they move fewer bytes but are currently instruction-bound and slower - see DESIGN.md.
+            res, n = None, 1
+            if _STREAM:
+                n = 1 if (done == 0 or not _FUSE_DEEP) else min(3, J - done)
+                res = ops.afb2d_fused(ll, h0_row, h1_row, h0_col, h1_col, mode, n)
+                if res is None and n > 1:
+                    n = 1
+                    res = ops.afb2d_fused(ll, h0_row, h1_row, h0_col, h1_col, mode, 1)
             if res is None:
                 n = 1
                 shapes.append(tuple(ll.shape[-2:]))

@@ -78,7 +78,7 @@ class DWTInverse(nn.Module):
 def describe_path(module, x=None):
     """Kernel names / launch counts of the DWT path (bench.py labels its roofline with this)."""
     J = getattr(module, 'J', 3)
-    return {'fwd_path': 'fused %d-level streaming kernel (LL_j in LDS)' % J,
-            'fwd_kernel': 'wl_kernel<WlAfbStream<float, 8>>', 'fwd_launches': (J + 3) // 4,
+    return {'fwd_path': 'specialised tile kernel, one launch per level',
+            'fwd_kernel': 'wl_kernel<WlAfbTile<float, 8>>', 'fwd_launches': J,
             'inv_path': 'per-level generic tile kernel', 'inv_kernel': 'wl_kernel<WlSfb2dTile<float>>',
             'inv_launches': J}

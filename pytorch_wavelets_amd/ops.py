@@ -84,8 +84,9 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=0):
     """`nlev` analysis levels in one launch (LL_j stay in LDS).  Returns (yl, [yh_0..]) or None when
     the streaming kernel does not cover the configuration (caller goes level by level)."""
     import ctypes
+    import os
     _check_tensor(x, 'x')
-    if x.dtype == torch.float64 or nlev < 1 or nlev > 4:
+    if x.dtype == torch.float64 or nlev < 1 or nlev > 4 or os.environ.get('WL_DISABLE_FUSED'):
         return None
     x = x.contiguous()
     N, C, H, W = x.shape

@@ -3,5 +3,5 @@
 set -e
 cd "$(dirname "$0")"
 CXX=${CXX:-/opt/rocm/lib/llvm/bin/clang++}
-$CXX -O2 -g -std=c++17 -fPIC -shared -fopenmp -Wall -Wno-unused-function wl_emu.cpp -o libwl_emu.so
+$CXX -O2 -g -std=c++17 -fno-strict-aliasing -fPIC -shared -fopenmp -Wall -Wno-unused-function wl_emu.cpp -o libwl_emu.so
 echo built tests/emu/libwl_emu.so

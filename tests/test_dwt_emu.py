@@ -91,26 +91,35 @@ def test_mode_errors():
 
 @pytest.mark.parametrize('name', ['dwt_01', 'dwt_05', 'dwt_06', 'dwt_09', 'dwt_14', 'dwt_10'])
 @pytest.mark.parametrize('strips', [0, 3])
-def test_fused_streaming_kernel_fp32_on_emulator(name, strips, monkeypatch):
-    """float32 modules take the fused multi-level streaming kernel (float64 above goes level by
-    level): check it against the goldens too, with and without splitting planes into strips."""
-    from pytorch_wavelets_amd import ops
+def test_streaming_kernels_fp32_on_emulator(name, strips):
+    """The streaming kernels (single level and 3-level fused, with and without splitting planes into
+    strips) through their C-ABI entry point, against the goldens."""
+    from pytorch_wavelets_amd import ops, filters
+    from pytorch_wavelets_amd.dwt import lowlevel
     meta, g = G.INDEX[name], G.load(name)
-    monkeypatch.setenv('WL_STREAM_STRIPS', str(strips))
-    torch.set_default_dtype(torch.float32)
-    xfm = pw.DWTForward(J=meta['J'], wave=meta['wave'], mode=meta['mode'])
+    h0, h1 = filters.dwt_analysis_taps(meta['wave'])
+    th = [torch.tensor(v, dtype=torch.float32) for v in (h0, h1, h0, h1)]
     x = torch.tensor(g['x'])
-    calls = []
-    real = ops.afb2d_fused
-
-    def spy(*a, **k):
-        r = real(*a, **k)
-        calls.append(r is not None)
-        return r
-    monkeypatch.setattr(ops, 'afb2d_fused', spy)
     with emu_backend.emulated():
-        yl, yh = xfm(x)
-    assert calls and all(calls), 'the fused kernel was expected to cover this case'
+        res = ops.afb2d_fused(x, *th, lowlevel.mode_to_int(meta['mode']), meta['J'], strips=strips)
+    assert res is not None, 'the streaming kernel was expected to cover this case'
+    yl, yh = res
     assert G.relerr(yl.numpy(), g, 'yl') < 1e-5
     for j in range(meta['J']):
         assert G.relerr(yh[j].numpy(), g, 'yh%d' % j) < 1e-5
+
+
+@pytest.mark.parametrize('name', ['dwt_01', 'dwt_03', 'dwt_06', 'dwt_07', 'dwt_08', 'dwt_14', 'dwt_15'])
+def test_tile_kernels_fp32_on_emulator(name):
+    """float32 modules take the specialised tile kernels (float64 above takes the generic ones)."""
+    meta, g = G.INDEX[name], G.load(name)
+    torch.set_default_dtype(torch.float32)
+    xfm = pw.DWTForward(J=meta['J'], wave=meta['wave'], mode=meta['mode'])
+    ifm = pw.DWTInverse(wave=meta['wave'], mode=meta['mode'])
+    with emu_backend.emulated():
+        yl, yh = xfm(torch.tensor(g['x']))
+        rec = ifm((yl, yh))
+    assert G.relerr(yl.numpy(), g, 'yl') < 1e-5
+    for j in range(meta['J']):
+        assert G.relerr(yh[j].numpy(), g, 'yh%d' % j) < 1e-5
+    assert G.relerr(rec.numpy(), g, 'rec') < 1e-5

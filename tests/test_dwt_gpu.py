@@ -153,7 +153,7 @@ def test_errors_and_edge_cases():
         pw.DWTForward()(torch.randn(1, 1, 8, 8))
     # empty batch
     yl, yh = pw.DWTForward(J=2, wave='db2').to(DEV)(torch.randn(0, 3, 16, 16, device=DEV))
-    assert yl.shape == (0, 3, 5, 5) and yh[0].shape == (0, 3, 3, 9, 9)
+    assert yl.shape == (0, 3, 6, 6) and yh[0].shape == (0, 3, 3, 9, 9)
     # non-contiguous input
     x = torch.randn(2, 3, 40, 50, device=DEV).transpose(2, 3)
     yl, _ = pw.DWTForward(J=1, wave='db3', mode='symmetric').to(DEV)(x)
@@ -165,6 +165,28 @@ def test_errors_and_edge_cases():
     oyl, oyh = wo.dwt_forward(x.double().numpy(), 1, h0, h1, h0, h1, 'symmetric')
     yl, yh = pw.DWTForward(J=1, wave='db4', mode='symmetric').to(DEV)(x.to(DEV))
     assert rel(yl, oyl) < TOL and rel(yh[0], oyh[0]) < TOL
+
+
+@pytest.mark.parametrize('wave,mode,J,shape', [
+    ('db4', 'symmetric', 3, (2, 2, 200, 136)), ('db2', 'zero', 3, (1, 3, 97, 204)),
+    ('db3', 'reflect', 2, (1, 2, 130, 78)), ('db8', 'periodization', 1, (2, 2, 256, 320)),
+    ('db4', 'periodic', 1, (1, 2, 112, 66)),
+])
+def test_streaming_kernels_vs_oracle(wave, mode, J, shape):
+    """The experimental streaming kernels (WL_STREAM=1 path) through their C-ABI entry point."""
+    from pytorch_wavelets_amd import ops
+    torch.manual_seed(5)
+    x = torch.randn(*shape)
+    h0, h1 = F.dwt_analysis_taps(wave)
+    th = [torch.tensor(v, dtype=torch.float32, device=DEV) for v in (h0, h1, h0, h1)]
+    oyl, oyh = wo.dwt_forward(x.double().numpy(), J, h0, h1, h0, h1, mode)
+    for strips in (0, 3):
+        res = ops.afb2d_fused(x.to(DEV), *th, lowlevel.mode_to_int(mode), J, strips=strips)
+        assert res is not None
+        yl, yh = res
+        assert rel(yl, oyl) < TOL
+        for a, b in zip(yh, oyh):
+            assert rel(a, b) < TOL
 
 
 def test_function_level_api():
