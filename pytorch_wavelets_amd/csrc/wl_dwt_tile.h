@@ -7,10 +7,10 @@
 //           k=2q,2q+1 from v_pk_fma_f32 with the sample broadcast, one ds_write_b128;
 //   column: item = (out row, q): L ds_read_b128 = (lo,hi) of columns 2q,2q+1, 4 packed FMAs per tap; every
 //           band row leaves as 8 contiguous bytes per lane (512 B per wave) straight into yl / yh[j].
-// A workgroup walks a vertical run of tiles; the 8-byte loads of tile t+1 are issued into registers before
+// A workgroup walks a horizontal run of tiles; the 8-byte loads of tile t+1 are issued into registers before
 // tile t's row bank starts, so ~20 KB per workgroup (four workgroups per CU, ~40 KB LDS each) are in flight
-// during all arithmetic.  Out-of-range cells are never loaded: the lane that holds a border sample also
-// writes its mirrored / wrapped images, out-of-range ROWS are just other source rows (or zeros).
+// during all arithmetic.  Boundary extension costs nothing on the hot path: each lane resolves the source
+// columns of its two cells once per workgroup, out-of-range ROWS are just other source rows (or zeros).
 //
 // Restates AFB2D.forward (reference dwt/lowlevel.py:336-347 = afb1d along W, afb1d along H, reshape, two
 // .contiguous() copies) for even tap counts; other tap counts use wl_dwt_kernels.h.
@@ -32,16 +32,17 @@ struct WlAfbTileArgs {
     int base, ext;
     int tiles_x, tiles_y;
     int vec_ok;       // rows can be read as aligned 8-byte pairs (W even, base pointer 8-byte aligned)
-    int run_len;      // tiles (vertically adjacent) per workgroup
-    int runs_y;       // ceil(tiles_y / run_len)
+    int run_len;      // tiles (horizontally adjacent) per workgroup
+    int runs_x;       // ceil(tiles_x / run_len)
+    int ablate;       // profiling only (WL_ABLATE): 1 no stores, 2 no loads, 4 no row bank, 8 no column bank
 };
 
-template <typename T, int LT>
+template <typename T, int LT, int TH_ = 16, int TW_ = 64>
 struct WlAfbTile {
     typedef WlAfbTileArgs<T> Args;
     static const int kThreads = 256;
     static const int kMinWaves = 3;
-    static const int TH = 16, TW = 64;
+    static const int TH = TH_, TW = TW_;
     static const int NROWS = 2 * TH + LT - 2;            // staged input rows
     static const int NCOLS = 2 * TW + LT - 2;            // staged input cols actually needed
     static const int NV = (LT + 2 + 3) / 4;              // float4 reads per row item
@@ -53,26 +54,17 @@ struct WlAfbTile {
     typedef T Pair2 __attribute__((ext_vector_type(2)));
     struct __attribute__((packed, aligned(sizeof(T)), may_alias)) Pair { T a, b; };   // element-aligned pair
 
-    // images of source column s (value v) inside the staged row whose first column is ec0
-    static WL_DEV void mirror_cols(float* srow, int s, float v, int W, int ec0, int ext) {
-        int e1, e2;
-        if (ext == WL_EXT_SYM) { e1 = -1 - s; e2 = 2 * W - 1 - s; }
-        else if (ext == WL_EXT_REFL) { e1 = s >= 1 ? -s : -0x40000000; e2 = s <= W - 2 ? 2 * W - 2 - s : -0x40000000; }
-        else { e1 = s - W; e2 = s + W; }   // periodic / periodization (even W)
-        const int j1 = e1 - ec0, j2 = e2 - ec0;
-        if ((unsigned)j1 < (unsigned)SP) srow[j1] = v;
-        if ((unsigned)j2 < (unsigned)SP) srow[j2] = v;
-    }
-
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
         const int tid = ctx.tid;
-        const int per_plane = a.tiles_x * a.runs_y;
+        // a workgroup walks a HORIZONTAL run of tiles (same tile row, consecutive tile columns): whole output
+        // rows are then written by one workgroup, so cache lines are not split between L2s of different XCDs
+        const int per_plane = a.tiles_y * a.runs_x;
         const int64_t plane = ctx.bid / per_plane;
         const int rem = (int)(ctx.bid - plane * per_plane);
-        const int ry = rem / a.tiles_x, tx = rem - ry * a.tiles_x;
-        const int ty_begin = ry * a.run_len;
-        const int ty_end = ty_begin + a.run_len < a.tiles_y ? ty_begin + a.run_len : a.tiles_y;
-        const int kw0 = tx * TW;
+        const int ty = rem / a.runs_x, rx = rem - ty * a.runs_x;
+        const int tx_begin = rx * a.run_len;
+        const int tx_end = tx_begin + a.run_len < a.tiles_x ? tx_begin + a.run_len : a.tiles_x;
+        const int kh0 = ty * TH;
         float* lds = reinterpret_cast<float*>(ctx.smem);
         float* tl = lds;
         float* S = lds + kTapFloats;
@@ -82,95 +74,82 @@ struct WlAfbTile {
             tl[2 * LT + 2 * tid] = a.h_h_lo[tid]; tl[2 * LT + 2 * tid + 1] = a.h_h_hi[tid];
         }
         const T* xp = a.x + (size_t)plane * a.H * a.W;
-        const int ec0 = 2 * kw0 + a.base;
-        const bool fast = a.vec_ok && (ec0 & 1) == 0;     // aligned pair loads + mirrored borders
-        const bool edge_x = ec0 < 0 || ec0 + SP > a.W;    // this tile column touches the left / right border
         constexpr int NP = SP / 2;                        // 8-byte pairs per staged row
-        constexpr int NIT = (NROWS * NP + kThreads - 1) / kThreads;
+        constexpr int RPI = kThreads / NP;                // staged rows per iteration (lanes: RPI x NP)
+        constexpr int NIT = (NROWS + RPI - 1) / RPI;
         Pair2 pf[NIT];
+        // Rows: this tile row needs input rows er0 .. er0+nr_need-1; the lane owns staged rows s_row, s_row+RPI, ..
+        // whose SOURCE rows under the boundary extension are resolved once per workgroup.
+        const int s_row = tid / NP, p_own = tid - s_row * NP;
+        const int er0 = 2 * kh0 + a.base;
+        const int nrows_out = (a.Kh - kh0) < TH ? (a.Kh - kh0) : TH;
+        const int nr_need = 2 * nrows_out + LT - 2;
+        int rsrc[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * RPI + s_row;
+            rsrc[it] = (s_row < RPI && i < nr_need) ? wl_ext(er0 + i, a.H, a.ext) : -1;
+        }
+        // per-tile state (set by issue): which cells this lane stages for the tile being prefetched
+        int nq_need = 0;
 
-        // issue the loads of tile row `ty` (registers only)
-        auto issue = [&](int ty) {
-            const int er0 = 2 * ty * TH + a.base;
+        // issue the loads of tile column `tx` (registers only).  A border cell is simply loaded from its source
+        // column (an L1/L2 hit), so every mode, odd widths and multiple reflections need no special path.
+        auto issue = [&](int tx) {
+            const int kw0 = tx * TW;
+            const int ec0 = 2 * kw0 + a.base;
+            const int ncols_out = (a.Kw - kw0) < TW ? (a.Kw - kw0) : TW;
+            const int nq = (ncols_out + 1) / 2;
+            const int np_need = nq * 2 + NV * 2 - 2 < NP ? nq * 2 + NV * 2 - 2 : NP;   // staged pairs per row
+            const bool lane_on = s_row < RPI && p_own < np_need;
+            const int cs0 = lane_on ? wl_ext(ec0 + 2 * p_own, a.W, a.ext) : -1;
+            const int cs1 = lane_on ? wl_ext(ec0 + 2 * p_own + 1, a.W, a.ext) : -1;
+            const bool pair_ld = a.vec_ok && cs0 >= 0 && cs1 == cs0 + 1 && (cs0 & 1) == 0;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int f = tid + it * kThreads;
                 pf[it] = Pair2{(T)0, (T)0};
-                if (f < NROWS * NP) {
-                    const int i = f / NP, p = f - i * NP;
-                    const int r = wl_ext(er0 + i, a.H, a.ext);
-                    const int c = ec0 + 2 * p;
-                    if (r >= 0 && c >= 0 && c < a.W)
-                        pf[it] = *reinterpret_cast<const Pair2*>(xp + (unsigned)(r * a.W + c));
+                const int r = rsrc[it];
+                if (lane_on && r >= 0 && !(a.ablate & 2)) {
+                    const T* src = xp + r * a.W;
+                    if (pair_ld) pf[it] = *reinterpret_cast<const Pair2*>(src + cs0);
+                    else {
+                        if (cs0 >= 0) pf[it].x = src[cs0];
+                        if (cs1 >= 0) pf[it].y = src[cs1];
+                    }
                 }
             }
         };
-        // registers -> LDS, plus the border images of the samples this lane holds
+        // registers -> LDS (cells outside the needed part of a partial tile are written too: zeros)
         auto commit = [&]() {
+            if (s_row >= RPI) return;
+            float* d = S + s_row * SP + 2 * p_own;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int f = tid + it * kThreads;
-                if (f < NROWS * NP) {
-                    const int i = f / NP, p = f - i * NP;
-                    const int c = ec0 + 2 * p;
-                    if ((c >= 0 && c < a.W) || a.ext == WL_EXT_ZERO) {   // (out-of-range cells hold zeros)
-                        wl_f2 w; w.x = (float)pf[it].x; w.y = (float)pf[it].y;
-                        *reinterpret_cast<wl_f2*>(S + i * SP + 2 * p) = w;
-                    }
-                }
-            }
-            if (edge_x && a.ext != WL_EXT_ZERO) {
-                // border images of the samples this lane just wrote (own LDS writes: program order suffices)
-                _Pragma("nounroll") for (int f = tid; f < NROWS * NP; f += kThreads) {
-                    const int i = f / NP, p = f - i * NP;
-                    const int c = ec0 + 2 * p;
-                    if (c >= 0 && c < a.W && (c < SP || c + SP >= a.W)) {
-                        float* srow = S + i * SP;
-                        mirror_cols(srow, c, srow[2 * p], a.W, ec0, a.ext);
-                        mirror_cols(srow, c + 1, srow[2 * p + 1], a.W, ec0, a.ext);
-                    }
-                }
-            }
-        };
-        // generic staging (odd widths, unaligned bases, odd periodization offsets): per-element extension
-        auto stage_slow = [&](int ty) {
-            const int er0 = 2 * ty * TH + a.base;
-            constexpr int NITS = (NROWS * SP + kThreads - 1) / kThreads;
-            constexpr int G = 8;
-            _Pragma("nounroll") for (int g0 = 0; g0 < NITS; g0 += G) {
-                float v[G];
-#pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    const int f = tid + (g0 + u) * kThreads;
-                    v[u] = 0.f;
-                    if (f < NROWS * SP) {
-                        const int i = f / SP, j = f - i * SP;
-                        const int r = wl_ext(er0 + i, a.H, a.ext);
-                        const int c = wl_ext(ec0 + j, a.W, a.ext);
-                        if (r >= 0 && c >= 0) v[u] = (float)xp[(unsigned)(r * a.W + c)];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    const int f = tid + (g0 + u) * kThreads;
-                    if (f < NROWS * SP) S[f] = v[u];
+                if (it * RPI + s_row < NROWS) {
+                    wl_f2 w; w.x = (float)pf[it].x; w.y = (float)pf[it].y;
+                    *reinterpret_cast<wl_f2*>(d + it * RPI * SP) = w;
                 }
             }
         };
 
-        if (fast) issue(ty_begin);
-        for (int ty = ty_begin; ty < ty_end; ++ty) {
-            const int kh0 = ty * TH;
-            if (fast) commit(); else stage_slow(ty);
+        issue(tx_begin);
+        for (int tx = tx_begin; tx < tx_end; ++tx) {
+            const int kw0 = tx * TW;
+            {
+                const int ncols_out = (a.Kw - kw0) < TW ? (a.Kw - kw0) : TW;
+                nq_need = (ncols_out + 1) / 2;
+            }
+            commit();
             ctx.sync();
-            if (fast && ty + 1 < ty_end) issue(ty + 1);
+            if (tx + 1 < tx_end) issue(tx + 1);
         // ---- row bank -----------------------------------------------------------------------------------------
         {
             wl_v2 tw[LT];
 #pragma unroll
             for (int j = 0; j < LT; ++j) { tw[j].x = tl[2 * j]; tw[j].y = tl[2 * j + 1]; }
-            _Pragma("nounroll") for (int f = tid; f < NROWS * NQ; f += kThreads) {
+            _Pragma("nounroll") for (int f = tid; f < ((a.ablate & 4) ? 0 : nr_need * NQ); f += kThreads) {
                 const int i = f / NQ, q = f - i * NQ;
+                if (q >= nq_need) continue;
                 float v[NV * 4];
                 const wl_f4* s4 = reinterpret_cast<const wl_f4*>(S + i * SP) + q;
 #pragma unroll
@@ -198,7 +177,7 @@ struct WlAfbTile {
             const unsigned bplane = (unsigned)a.Kh * (unsigned)a.Kw;
             T* llp = a.ll + (size_t)plane * bplane;
             T* hp = a.highs + (size_t)plane * 3 * bplane;
-            _Pragma("nounroll") for (int f = tid; f < TH * NQ; f += kThreads) {
+            _Pragma("nounroll") for (int f = tid; f < ((a.ablate & 8) ? 0 : TH * NQ); f += kThreads) {
                 const int kh = f / NQ, q = f - kh * NQ;
                 const int k = kh0 + kh, kw = kw0 + 2 * q;
                 if (k >= a.Kh || kw >= a.Kw) continue;
@@ -211,6 +190,7 @@ struct WlAfbTile {
                     cl1 += th[j] * p.z; ch1 += th[j] * p.w;
                 }
                 const unsigned o = (unsigned)k * (unsigned)a.Kw + (unsigned)kw;
+                if ((a.ablate & 1) && cl0.x != 12345.f) continue;
                 if (kw + 1 < a.Kw) {
                     Pair p0, p1, p2, p3;
                     p0.a = (T)cl0.x; p0.b = (T)cl1.x;   // LL

@@ -1,0 +1,171 @@
+// Compile-time specialised single-level 2-D DWT synthesis tile kernel.
+//
+//   y[n] = sum_{k'} B(k') g[n + s - 2k'],  s = L-2 (zero/symmetric/reflect/periodic) or L/2-1 (periodization,
+//   circular band index).  Polyphase form used here (L even): outputs come in pairs (n0, n0+1) with n0+s even,
+//   c = (n0+s)/2:   (y[n0], y[n0+1]) = sum_{j<L/2} B(c-j) * (g[2j], g[2j+1])
+//   i.e. one packed FMA per tap and band with the band sample broadcast - no zero stuffing, no transposed
+//   convolution, half the MACs of the reference's conv_transpose2d formulation.
+//
+// One 256-thread workgroup produces a 32 x 64 tile of y:
+//   stage : the four band tiles (ll through explicit strides, lh/hl/hh from `highs`) are loaded with coalesced
+//           dword loads (all loads of a thread issued before the first LDS write) and stored interleaved as one
+//           float4 (ll,lh,hl,hh) per cell; cells outside the bands are zero (or wrap, periodization);
+//   column: item = (row pair, band column): L/2 ds_read_b128, 4 packed FMAs per tap -> (lo,hi) for both rows;
+//   row   : item = (row, column pair): L/2 ds_read_b64 (lo,hi), 2 packed FMAs per tap -> 8 contiguous bytes of
+//           y per lane (512 B per wave).
+//
+// Restates SFB2D.forward (reference dwt/lowlevel.py:671-680 = 3 x sfb1d = 6 x conv_transpose2d + 3 adds,
+// :226-271) and, with a cropped OH/OW, AFB2D.backward (:350-365).
+#pragma once
+#include "wl_common.h"
+#include "wl_dwt_stream.h"   // wl_f4 / wl_f2 / wl_v2
+
+template <typename T>
+struct WlSfbTileArgs {
+    const T* ll;      // (NC, Kh, Kw) through strides
+    const T* highs;   // (NC, 3, Kh, Kw) dense or nullptr
+    T* y;             // (NC, OH, OW)
+    const float* g_w_lo;
+    const float* g_w_hi;
+    const float* g_h_lo;
+    const float* g_h_hi;
+    int64_t NC;
+    int64_t ll_plane_stride;
+    int ll_row_stride;
+    int Kh, Kw, OH, OW;
+    int s, circ;
+    int tiles_x, tiles_y;
+};
+
+template <typename T, int LT>
+struct WlSfbTile {
+    typedef WlSfbTileArgs<T> Args;
+    static const int kThreads = 256;
+    static const int kMinWaves = 4;
+    static const int TH = 32, TW = 64;
+    static const int HL = LT / 2;                 // taps per phase
+    static const int NPR = TH / 2 + 1;            // row pairs per tile (+1: odd s shifts the pairing by one)
+    static const int NPC = TW / 2 + 1;            // column pairs per tile
+    static const int NKR = NPR + HL - 1;          // staged band rows
+    static const int NKC = NPC + HL - 1;          // staged band cols
+    static const int UR = 2 * NPR;                // intermediate rows
+    static const int kTapFloats = 4 * LT;
+    static const int kLdsFloats = kTapFloats + 4 * NKR * NKC + 2 * UR * NKC;
+    struct __attribute__((packed, aligned(sizeof(T)), may_alias)) Pair { T a, b; };
+
+    static WL_DEV void run(const Args& a, const WlCtx& ctx) {
+        const int tid = ctx.tid;
+        const int tiles = a.tiles_x * a.tiles_y;
+        const int64_t plane = ctx.bid / tiles;
+        const int tile = (int)(ctx.bid - plane * tiles);
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const int sodd = a.s & 1;
+        // first pair of the tile: n0 = 2*m0 - sodd with 2*m0 = tile origin; c = (n0 + s)/2
+        const int nrow0 = ty * TH - sodd, ncol0 = tx * TW - sodd;
+        const int cr0 = (nrow0 + a.s) >> 1, cc0 = (ncol0 + a.s) >> 1;   // exact (even), may be negative
+        const int kr0 = cr0 - (HL - 1), kc0 = cc0 - (HL - 1);           // first staged band row / col
+        float* lds = reinterpret_cast<float*>(ctx.smem);
+        float* tl = lds;                                  // g_w pairs, then g_h pairs
+        wl_f4* B = reinterpret_cast<wl_f4*>(lds + kTapFloats);
+        wl_f2* U = reinterpret_cast<wl_f2*>(lds + kTapFloats + 4 * NKR * NKC);
+        if (tid < LT) {
+            tl[tid] = a.g_w_lo[tid]; tl[LT + tid] = a.g_w_hi[tid];
+            tl[2 * LT + tid] = a.g_h_lo[tid]; tl[3 * LT + tid] = a.g_h_hi[tid];
+        }
+        // ---- stage the four band tiles -------------------------------------------------------------------------
+        {
+            const unsigned bplane = (unsigned)a.Kh * (unsigned)a.Kw;
+            const T* llp = a.ll + (size_t)plane * a.ll_plane_stride;
+            const T* hp = a.highs ? a.highs + (size_t)plane * 3 * bplane : nullptr;
+            constexpr int NIT = (NKR * NKC + kThreads - 1) / kThreads;
+            float v[NIT][4];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int f = tid + it * kThreads;
+                v[it][0] = v[it][1] = v[it][2] = v[it][3] = 0.f;
+                if (f < NKR * NKC) {
+                    const int i = f / NKC, j = f - i * NKC;
+                    int r = kr0 + i, c = kc0 + j;
+                    if (a.circ) { r = wl_pmod(r, a.Kh); c = wl_pmod(c, a.Kw); }
+                    if ((unsigned)r < (unsigned)a.Kh && (unsigned)c < (unsigned)a.Kw) {
+                        v[it][0] = (float)llp[(unsigned)(r * a.ll_row_stride + c)];
+                        if (hp) {
+                            const unsigned o = (unsigned)r * (unsigned)a.Kw + (unsigned)c;
+                            v[it][1] = (float)hp[o];
+                            v[it][2] = (float)hp[bplane + o];
+                            v[it][3] = (float)hp[2 * bplane + o];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int f = tid + it * kThreads;
+                if (f < NKR * NKC) {
+                    wl_f4 w; w.x = v[it][0]; w.y = v[it][1]; w.z = v[it][2]; w.w = v[it][3];
+                    B[f] = w;
+                }
+            }
+        }
+        ctx.sync();
+        // ---- column synthesis (along H): row pair p -> U rows 2p, 2p+1 of (lo,hi) ------------------------------
+        {
+            wl_v2 g0[HL], g1[HL];
+#pragma unroll
+            for (int j = 0; j < HL; ++j) {
+                g0[j].x = tl[2 * LT + 2 * j]; g0[j].y = tl[2 * LT + 2 * j + 1];
+                g1[j].x = tl[3 * LT + 2 * j]; g1[j].y = tl[3 * LT + 2 * j + 1];
+            }
+            _Pragma("nounroll") for (int f = tid; f < NPR * NKC; f += kThreads) {
+                const int p = f / NKC, kc = f - p * NKC;
+                wl_v2 lo = {0.f, 0.f}, hi = {0.f, 0.f};   // (row n0, row n0+1)
+                // c = cr0 + p;  band row c - j  ->  staged row (c - j) - kr0 = p + HL-1 - j
+#pragma unroll
+                for (int j = 0; j < HL; ++j) {
+                    const wl_f4 b = B[(p + HL - 1 - j) * NKC + kc];
+                    lo += g0[j] * b.x; lo += g1[j] * b.y;
+                    hi += g0[j] * b.z; hi += g1[j] * b.w;
+                }
+                wl_f2 u0, u1;
+                u0.x = lo.x; u0.y = hi.x; u1.x = lo.y; u1.y = hi.y;
+                U[(2 * p) * NKC + kc] = u0;
+                U[(2 * p + 1) * NKC + kc] = u1;
+            }
+        }
+        ctx.sync();
+        // ---- row synthesis (along W) + store ---------------------------------------------------------------------
+        {
+            wl_v2 g0[HL], g1[HL];
+#pragma unroll
+            for (int j = 0; j < HL; ++j) {
+                g0[j].x = tl[2 * j]; g0[j].y = tl[2 * j + 1];
+                g1[j].x = tl[LT + 2 * j]; g1[j].y = tl[LT + 2 * j + 1];
+            }
+            T* yp = a.y + (size_t)plane * a.OH * a.OW;
+            const int row_lo = ty * TH, row_hi = (ty * TH + TH) < a.OH ? (ty * TH + TH) : a.OH;
+            const int col_lo = tx * TW, col_hi = (tx * TW + TW) < a.OW ? (tx * TW + TW) : a.OW;
+            _Pragma("nounroll") for (int f = tid; f < UR * NPC; f += kThreads) {
+                const int ur = f / NPC, q = f - ur * NPC;
+                const int n = nrow0 + ur;
+                if (n < row_lo || n >= row_hi) continue;
+                wl_v2 acc = {0.f, 0.f};   // (col w0, col w0+1)
+#pragma unroll
+                for (int j = 0; j < HL; ++j) {
+                    const wl_f2 u = U[ur * NKC + (q + HL - 1 - j)];
+                    acc += g0[j] * u.x;
+                    acc += g1[j] * u.y;
+                }
+                const int w0 = ncol0 + 2 * q;
+                T* dst = yp + (n * a.OW + w0);   // (w0 may be -1: signed offset)
+                const bool ok0 = w0 >= col_lo && w0 < col_hi, ok1 = w0 + 1 >= col_lo && w0 + 1 < col_hi;
+                if (ok0 && ok1) {
+                    Pair pr; pr.a = (T)acc.x; pr.b = (T)acc.y;
+                    *reinterpret_cast<Pair*>(dst) = pr;
+                } else {
+                    if (ok0) dst[0] = (T)acc.x;
+                    if (ok1) dst[1] = (T)acc.y;
+                }
+            }
+        }
+    }
+};
