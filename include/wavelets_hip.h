@@ -77,6 +77,45 @@ int wl_dwt2d_analysis_fused(const void* x, void* yl, void* const* yh, int dtype,
                             int W, int nlev, const void* h_w_lo, const void* h_w_hi, const void* h_h_lo,
                             const void* h_h_hi, int L, int mode, int strips, void* stream);
 
+/* ---- DTCWT (filters = the reference's stored buffers: reversed columns, dtcwt/lowlevel.py:58-67) ------------ */
+
+/* Level-1 forward = FWD_J1.forward -> fwd_j1 (dtcwt/transform_funcs.py:98-121, :346-358): 2 rowfilter +
+ * 4 colfilter + 3 q2c + stacks.  x (planes,H,W); odd H/W are edge-replicated to He=H+(H&1), We likewise
+ * (dtcwt/transform2d.py:116-120) inside the kernel.  ll (planes,He,We) or NULL; highs
+ * (planes,6,He/2,We/2,2) in the reference's default o_dim=2/ri_dim=-1 layout, or NULL (skip_hps).
+ * h0 (L0 taps) / h1 (L1 taps): odd lengths.  mode 1 = symmetric extension, any other valid code = zero padding
+ * (dtcwt/lowlevel.py:75-79). */
+int wl_dtcwt_fwd_level1(const void* x, void* ll, void* highs, int dtype, int64_t planes, int H, int W,
+                        const void* h0, int L0, const void* h1, int L1, int mode, void* stream);
+
+/* Level>=2 forward = FWD_J2PLUS.forward -> fwd_j2plus (transform_funcs.py:226-249, :380-392): 2 rowdfilt +
+ * 4 coldfilt + q2c, always symmetric.  x (planes,H,W) with H,W even; if not multiples of 4 one row/col is
+ * replicated on both sides (transform2d.py:131-135) inside the kernel: He=H+2*(H%4!=0).  ll (planes,He/2,We/2),
+ * highs (planes,6,He/4,We/4,2) or NULL.  Four filters of even length L. */
+int wl_dtcwt_fwd_level2(const void* x, void* ll, void* highs, int dtype, int64_t planes, int H, int W,
+                        const void* h0a, const void* h0b, const void* h1a, const void* h1b, int L, void* stream);
+
+/* Level-1 inverse = INV_J1.forward -> inv_j1 (transform_funcs.py:152-184, :419-431): c2q x 3, 4 colfilter,
+ * 2 rowfilter, 3 adds.  ll (planes,H,W) through strides (so the 1-px crop of transform_funcs.py:171-176 is a
+ * view) or NULL; highs (planes,6,H/2,W/2,2) or NULL; y (planes,H,W). */
+int wl_dtcwt_inv_level1(const void* ll, int64_t ll_plane_stride, int ll_row_stride, const void* highs, void* y,
+                        int dtype, int64_t planes, int H, int W, const void* g0, int L0, const void* g1, int L1,
+                        int mode, void* stream);
+
+/* Level>=2 inverse = INV_J2PLUS.forward -> inv_j2plus (transform_funcs.py:279-307, :455-468): c2q x 3,
+ * 4 colifilt, 2 rowifilt, 3 adds.  ll (planes,h,w) through strides or NULL; highs (planes,6,h/2,w/2,2) or NULL;
+ * y (planes,2h,2w). */
+int wl_dtcwt_inv_level2(const void* ll, int64_t ll_plane_stride, int ll_row_stride, const void* highs, void* y,
+                        int dtype, int64_t planes, int h, int w, const void* g0a, const void* g0b, const void* g1a,
+                        const void* g1b, int L, void* stream);
+
+/* ScatLayer forward = ScatLayerj1_f.forward (scatternet/lowlevel.py:76-111): level-1 DTCWT + 2x2 average of LL +
+ * smoothed magnitude sqrt(re^2+im^2+b^2)-b, written as z (N,7,C,He/2,We/2) [(N,3+6,..) with combine_colour].
+ * drdx/drdy (N,6,C,He/2,We/2) receive re/r, im/r for the backward pass, or NULL. */
+int wl_scat_fwd_level1(const void* x, void* z, void* drdx, void* drdy, int dtype, int64_t N, int C, int H, int W,
+                       const void* h0, int L0, const void* h1, int L1, int mode, double magbias,
+                       int combine_colour, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,8 @@ Drop-in for the DWT / DTCWT hot path of fbcotter/pytorch_wavelets: the same nn.M
 __version__ = '0.1.0'
 
 from .dwt.transform2d import DWTForward, DWTInverse   # noqa: E402,F401
+from .dtcwt.transform2d import DTCWTForward, DTCWTInverse   # noqa: E402,F401
+from .scatternet import ScatLayer   # noqa: E402,F401
 
 from . import parallel                                  # noqa: E402,F401
 
@@ -17,9 +19,12 @@ def engine_info(module, x=None):
     return transform2d.describe_path(module, x)
 
 
+DTCWT = DTCWTForward
+IDTCWT = DTCWTInverse
 DWT = DWTForward
 IDWT = DWTInverse
 DWT2D = DWT
 IDWT2D = IDWT
 
-__all__ = ['__version__', 'DWTForward', 'DWTInverse', 'DWT', 'IDWT', 'DWT2D', 'IDWT2D']
+__all__ = ['__version__', 'DTCWTForward', 'DTCWTInverse', 'DWTForward', 'DWTInverse', 'DTCWT', 'IDTCWT',
+           'DWT', 'IDWT', 'DWT2D', 'IDWT2D', 'ScatLayer']

@@ -108,3 +108,113 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=0):
         return None
     _lib.check(rc, 'wl_dwt2d_analysis_fused')
     return yl, yh
+
+
+# ---------------------------------------------------------------------------------------------- DTCWT
+def _ll_view(ll, ref_shape):
+    """(ptr, plane_stride, row_stride) of a (N,C,h,w) view whose rows are unit-stride."""
+    N, C = ref_shape
+    if ll.stride(3) != 1 or ll.stride(0) != C * ll.stride(1):
+        ll = ll.contiguous()
+    return ll, ll.stride(1), ll.stride(2)
+
+
+def dtcwt_fwd1(x, h0, h1, mode, skip_hps=False):
+    """Level-1 forward: x (N,C,H,W) -> ll (N,C,He,We), highs (N,C,6,He/2,We/2,2) or None."""
+    _check_tensor(x, 'x')
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    t0, t1 = _taps(h0, x), _taps(h1, x)
+    He, We = H + (H & 1), W + (W & 1)
+    ll = torch.empty((N, C, He, We), dtype=x.dtype, device=x.device)
+    highs = None if skip_hps else torch.empty((N, C, 6, He // 2, We // 2, 2), dtype=x.dtype, device=x.device)
+    rc = _backend().wl_dtcwt_fwd_level1(x.data_ptr(), ll.data_ptr(), None if skip_hps else highs.data_ptr(),
+                                        _DTYPES[x.dtype], N * C, H, W, t0.data_ptr(), t0.numel(), t1.data_ptr(),
+                                        t1.numel(), mode, _stream(x))
+    _lib.check(rc, 'wl_dtcwt_fwd_level1')
+    return ll, highs
+
+
+def dtcwt_fwd2(x, h0a, h0b, h1a, h1b, skip_hps=False):
+    """Level>=2 forward: x (N,C,H,W), H,W even -> ll (N,C,He/2,We/2), highs (N,C,6,He/4,We/4,2) or None."""
+    _check_tensor(x, 'x')
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    ta, tb, tc, td = (_taps(h, x) for h in (h0a, h0b, h1a, h1b))
+    He, We = H + (2 if H % 4 else 0), W + (2 if W % 4 else 0)
+    ll = torch.empty((N, C, He // 2, We // 2), dtype=x.dtype, device=x.device)
+    highs = None if skip_hps else torch.empty((N, C, 6, He // 4, We // 4, 2), dtype=x.dtype, device=x.device)
+    rc = _backend().wl_dtcwt_fwd_level2(x.data_ptr(), ll.data_ptr(), None if skip_hps else highs.data_ptr(),
+                                        _DTYPES[x.dtype], N * C, H, W, ta.data_ptr(), tb.data_ptr(), tc.data_ptr(),
+                                        td.data_ptr(), ta.numel(), _stream(x))
+    _lib.check(rc, 'wl_dtcwt_fwd_level2')
+    return ll, highs
+
+
+def dtcwt_inv1(ll, highs, g0, g1, mode):
+    """Level-1 inverse: ll (N,C,H,W) or None, highs (N,C,6,H/2,W/2,2) or None -> y (N,C,H,W)."""
+    ref = ll if ll is not None else highs
+    _check_tensor(ref, 'coeffs')
+    if highs is not None:
+        highs = highs.contiguous()
+        N, C = highs.shape[:2]
+        H, W = 2 * highs.shape[3], 2 * highs.shape[4]
+    else:
+        N, C, H, W = ll.shape
+    ps = rs = 0
+    if ll is not None:
+        assert tuple(ll.shape) == (N, C, H, W), (ll.shape, (N, C, H, W))
+        ll, ps, rs = _ll_view(ll, (N, C))
+    t0, t1 = _taps(g0, ref), _taps(g1, ref)
+    y = torch.empty((N, C, H, W), dtype=ref.dtype, device=ref.device)
+    rc = _backend().wl_dtcwt_inv_level1(None if ll is None else ll.data_ptr(), ps, rs,
+                                        None if highs is None else highs.data_ptr(), y.data_ptr(),
+                                        _DTYPES[ref.dtype], N * C, H, W, t0.data_ptr(), t0.numel(), t1.data_ptr(),
+                                        t1.numel(), mode, _stream(ref))
+    _lib.check(rc, 'wl_dtcwt_inv_level1')
+    return y
+
+
+def dtcwt_inv2(ll, highs, g0a, g0b, g1a, g1b):
+    """Level>=2 inverse: ll (N,C,h,w) or None, highs (N,C,6,h/2,w/2,2) or None -> y (N,C,2h,2w)."""
+    ref = ll if ll is not None else highs
+    _check_tensor(ref, 'coeffs')
+    if highs is not None:
+        highs = highs.contiguous()
+        N, C = highs.shape[:2]
+        h, w = 2 * highs.shape[3], 2 * highs.shape[4]
+    else:
+        N, C, h, w = ll.shape
+    ps = rs = 0
+    if ll is not None:
+        assert tuple(ll.shape) == (N, C, h, w), (ll.shape, (N, C, h, w))
+        ll, ps, rs = _ll_view(ll, (N, C))
+    ta, tb, tc, td = (_taps(g, ref) for g in (g0a, g0b, g1a, g1b))
+    y = torch.empty((N, C, 2 * h, 2 * w), dtype=ref.dtype, device=ref.device)
+    rc = _backend().wl_dtcwt_inv_level2(None if ll is None else ll.data_ptr(), ps, rs,
+                                        None if highs is None else highs.data_ptr(), y.data_ptr(),
+                                        _DTYPES[ref.dtype], N * C, h, w, ta.data_ptr(), tb.data_ptr(), tc.data_ptr(),
+                                        td.data_ptr(), ta.numel(), _stream(ref))
+    _lib.check(rc, 'wl_dtcwt_inv_level2')
+    return y
+
+
+def scat_fwd1(x, h0, h1, mode, magbias, combine_colour, save):
+    """ScatLayer forward: x (N,C,H,W) -> Z (N,7,C,He/2,We/2) [(N,9,..) when combining colour] and, if
+    `save`, (re/r, im/r) of shape (N,6,C,He/2,We/2)."""
+    _check_tensor(x, 'x')
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    t0, t1 = _taps(h0, x), _taps(h1, x)
+    h2, w2 = (H + (H & 1)) // 2, (W + (W & 1)) // 2
+    z = torch.empty((N, 9, h2, w2) if combine_colour else (N, 7, C, h2, w2), dtype=x.dtype, device=x.device)
+    dx = dy = None
+    if save:
+        dx = torch.empty((N, 6, C, h2, w2), dtype=x.dtype, device=x.device)
+        dy = torch.empty_like(dx)
+    rc = _backend().wl_scat_fwd_level1(x.data_ptr(), z.data_ptr(), None if dx is None else dx.data_ptr(),
+                                       None if dy is None else dy.data_ptr(), _DTYPES[x.dtype], N, C, H, W,
+                                       t0.data_ptr(), t0.numel(), t1.data_ptr(), t1.numel(), mode, float(magbias),
+                                       1 if combine_colour else 0, _stream(x))
+    _lib.check(rc, 'wl_scat_fwd_level1')
+    return z, dx, dy

@@ -1,0 +1,60 @@
+"""CPU tests: DTCWT / ScatLayer modules and autograd Functions on the host emulation of the kernels,
+against the reference's golden vectors (float64 arithmetic)."""
+import pytest
+import torch
+
+import _dtcwt_cases as D
+import _golden as G
+import emu_backend
+import pytorch_wavelets_amd as pw
+
+TOL = 5e-7   # fixtures are rounded to float32
+
+
+@pytest.fixture(autouse=True)
+def _f64_on_emulator():
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    with emu_backend.emulated():
+        yield
+    torch.set_default_dtype(prev)
+
+
+SMALL = [n for n in G.cases('dtcwt') if G.INDEX[n]['shape'][-1] <= 128]
+
+
+@pytest.mark.parametrize('name', SMALL)
+def test_dtcwt_modules(name):
+    D.check_dtcwt_case(name, 'cpu', torch.float64, TOL)
+
+
+def test_dtcwt_inverse_with_missing_inputs():
+    D.check_dtcwt_none('cpu', torch.float64, TOL)
+
+
+@pytest.mark.parametrize('name', [n for n in G.cases('scat') if G.INDEX[n]['shape'][-1] <= 64])
+def test_scatlayer(name):
+    D.check_scat_case(name, 'cpu', torch.float64, TOL)
+
+
+def test_layout_permutations():
+    D.check_layouts('cpu', torch.float64, 1e-9)
+
+
+def test_api_contract():
+    with pytest.raises(ValueError, match='different dimensions'):
+        pw.DTCWTForward(o_dim=2, ri_dim=2)
+    x = torch.randn(1, 2, 16, 16)
+    yl, yh = pw.DTCWTForward(J=0)(x)
+    assert yl is x and yh is None
+    sd = pw.DTCWTForward().state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {
+        'h0o': (1, 1, 5, 1), 'h1o': (1, 1, 7, 1), 'h0a': (1, 1, 10, 1), 'h0b': (1, 1, 10, 1),
+        'h1a': (1, 1, 10, 1), 'h1b': (1, 1, 10, 1)}
+    assert sorted(pw.DTCWTInverse().state_dict()) == ['g0a', 'g0b', 'g0o', 'g1a', 'g1b', 'g1o']
+    sl = pw.ScatLayer()
+    assert [n for n, _ in sl.named_parameters()] == ['h0o', 'h1o'] and not sl.h0o.requires_grad
+    assert sl(torch.randn(2, 3, 17, 20)).shape == (2, 21, 9, 10)
+    yl, yh = pw.DTCWTForward(J=2, skip_hps=[True, False])(x)
+    assert yh[0].shape == torch.Size([]) and yh[1].shape == (1, 2, 6, 4, 4, 2)
+    assert pw.DTCWT is pw.DTCWTForward and pw.IDTCWT is pw.DTCWTInverse
