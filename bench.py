@@ -47,7 +47,7 @@ def cpu_baseline(args):
     try:
         from oracle import dwt_port
         ncores = os.cpu_count() or 1
-        n = max(2, min(16, ncores))
+        n = max(2, min(64, ncores))
         x = rng.randn(n, 3, 512, 512).astype(np.float32)
         dwt_port.fwd_inv(x, 3, h0, h1, g0, g1, 'symmetric', threads=ncores)    # warm-up
         reps, t0 = 0, time.perf_counter()

@@ -98,3 +98,13 @@ WL_HD int wl_ext_padded(int v, int n, int pad_lo, int pad_hi, int ext) {
 
 WL_HD int wl_cdiv(int a, int b) { return (a + b - 1) / b; }
 WL_HD int wl_align_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// XCD-aware block remap (MI355X: workgroup b is dispatched to XCD b % 8, each XCD has its own L2).  Returns the
+// LOGICAL block a hardware block should work on so that every XCD walks one contiguous range of logical blocks:
+// neighbouring tiles (which share halo rows / cache lines) then meet in the same L2.  Placement only affects speed.
+WL_HD int64_t wl_xcd_remap(int64_t bid, int64_t nblocks) {
+    if (nblocks <= 0) return bid;   // remap disabled
+    const int64_t q = nblocks / 8, r = nblocks % 8;
+    const int64_t x = bid % 8, i = bid / 8;
+    return x * q + (x < r ? x : r) + i;
+}

@@ -34,6 +34,7 @@ struct WlAfbTileArgs {
     int vec_ok;       // rows can be read as aligned 8-byte pairs (W even, base pointer 8-byte aligned)
     int run_len;      // tiles (horizontally adjacent) per workgroup
     int runs_x;       // ceil(tiles_x / run_len)
+    int64_t nblocks;  // grid size (for the XCD-aware block remap)
     int ablate;       // profiling only (WL_ABLATE): 1 no stores, 2 no loads, 4 no row bank, 8 no column bank
 };
 
@@ -59,8 +60,9 @@ struct WlAfbTile {
         // a workgroup walks a HORIZONTAL run of tiles (same tile row, consecutive tile columns): whole output
         // rows are then written by one workgroup, so cache lines are not split between L2s of different XCDs
         const int per_plane = a.tiles_y * a.runs_x;
-        const int64_t plane = ctx.bid / per_plane;
-        const int rem = (int)(ctx.bid - plane * per_plane);
+        const int64_t lbid = wl_xcd_remap(ctx.bid, a.nblocks);
+        const int64_t plane = lbid / per_plane;
+        const int rem = (int)(lbid - plane * per_plane);
         const int ty = rem / a.runs_x, rx = rem - ty * a.runs_x;
         const int tx_begin = rx * a.run_len;
         const int tx_end = tx_begin + a.run_len < a.tiles_x ? tx_begin + a.run_len : a.tiles_x;

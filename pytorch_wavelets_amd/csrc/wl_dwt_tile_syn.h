@@ -35,6 +35,7 @@ struct WlSfbTileArgs {
     int Kh, Kw, OH, OW;
     int s, circ;
     int tiles_x, tiles_y;
+    int64_t nblocks;  // grid size (for the XCD-aware block remap)
 };
 
 template <typename T, int LT>
@@ -56,8 +57,9 @@ struct WlSfbTile {
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
         const int tid = ctx.tid;
         const int tiles = a.tiles_x * a.tiles_y;
-        const int64_t plane = ctx.bid / tiles;
-        const int tile = (int)(ctx.bid - plane * tiles);
+        const int64_t lbid = wl_xcd_remap(ctx.bid, a.nblocks);
+        const int64_t plane = lbid / tiles;
+        const int tile = (int)(lbid - plane * tiles);
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const int sodd = a.s & 1;
         // first pair of the tile: n0 = 2*m0 - sodd with 2*m0 = tile origin; c = (n0 + s)/2
