@@ -37,6 +37,14 @@ typedef _Float16 wl_half;
 template <typename T> struct WlAcc { typedef float type; };
 template <> struct WlAcc<double> { typedef double type; };
 
+// value of `v` in the previous lane of the wave (lane 0 gets its own).  The host emulation runs one fibre per
+// lane to the next barrier, so it emulates the shuffle through a per-workgroup exchange array + two barriers.
+#if defined(__HIPCC__)
+WL_DEV float wl_shfl_up1(float v) { return __shfl_up(v, 1); }
+#else
+float wl_shfl_up1(float v);
+#endif
+
 struct WlCtx {
     int tid;        // thread index in the workgroup
     int nthreads;   // workgroup size

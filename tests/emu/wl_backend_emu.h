@@ -1,8 +1,10 @@
 // Host emulation backend (TEST INFRASTRUCTURE, never loaded by the product package).
-// Runs each workgroup as 256 cooperative fibres on one OS thread: a fibre runs until its next
-// barrier (WlCtx::sync) or its end, so barrier semantics are exact.  The visiting order of the
-// fibres alternates forward / backward between barrier rounds so that a MISSING barrier in a
-// kernel shows up as a wrong result instead of passing by luck.  LDS is poisoned with NaNs.
+// Runs each workgroup as cooperative fibres on one OS thread: a fibre runs until its next barrier
+// (WlCtx::sync), its next wave shuffle (wl_shfl_up1) or its end.  Barriers release when every live fibre of the
+// workgroup waits at one; a shuffle resolves when every live lane of that 64-lane wave waits at it, so barrier and
+// wave semantics are exact.  The visiting order of the fibres alternates forward / backward between barrier
+// phases so that a MISSING barrier in a kernel shows up as a wrong result instead of passing by luck.  LDS is
+// poisoned with NaNs.
 #pragma once
 #include <stdlib.h>
 #include <string.h>
@@ -16,15 +18,28 @@ struct WlEmuBlock {
     ucontext_t main;
     std::vector<ucontext_t> fib;
     std::vector<char*> stacks;
-    std::vector<char> done;
+    std::vector<char> state;        // 0 ready, 1 at barrier, 2 at shuffle, 3 done
+    std::vector<float> shfl_in, shfl_out;
     int cur;
     WlEmuBlock() : cur(0) {}
     ~WlEmuBlock() { for (size_t i = 0; i < stacks.size(); ++i) free(stacks[i]); }
 };
 
+static thread_local WlEmuBlock* wl_emu_cur_block = nullptr;
+
 static void wl_emu_sync(void* arg) {
     WlEmuBlock* b = (WlEmuBlock*)arg;
+    b->state[b->cur] = 1;
     swapcontext(&b->fib[b->cur], &b->main);
+}
+
+float wl_shfl_up1(float v) {
+    WlEmuBlock* b = wl_emu_cur_block;
+    const int me = b->cur;
+    b->shfl_in[me] = v;
+    b->state[me] = 2;
+    swapcontext(&b->fib[me], &b->main);
+    return b->shfl_out[me];
 }
 
 template <typename K>
@@ -47,7 +62,7 @@ static void wl_emu_entry(unsigned lo, unsigned hi) {
     ctx.sync_fn = wl_emu_sync;
     ctx.sync_arg = b;
     K::run(*job->args, ctx);
-    b->done[ctx.tid] = 1;
+    b->state[ctx.tid] = 3;
     // returning follows uc_link back to the scheduler
 }
 
@@ -61,20 +76,23 @@ static int wl_launch(const typename K::Args& a, int64_t nblocks, size_t lds, voi
     {
         WlEmuBlock blk;
         blk.fib.resize(nt);
-        blk.done.resize(nt);
+        blk.state.resize(nt);
         blk.stacks.resize(nt);
+        blk.shfl_in.resize(nt);
+        blk.shfl_out.resize(nt);
         for (int i = 0; i < nt; ++i) blk.stacks[i] = (char*)malloc(kStack);
         char* smem = (char*)aligned_alloc(64, ((lds + 63) / 64 + 1) * 64);
         WlEmuJob<K> job;
         job.args = &a;
         job.blk = &blk;
         job.smem = smem;
+        wl_emu_cur_block = &blk;
 #pragma omp for schedule(dynamic, 1)
         for (int64_t bid = 0; bid < nblocks; ++bid) {
             memset(smem, 0xFF, lds);   // NaN poison
             job.bid = bid;
             for (int i = 0; i < nt; ++i) {
-                blk.done[i] = 0;
+                blk.state[i] = 0;
                 getcontext(&blk.fib[i]);
                 blk.fib[i].uc_stack.ss_sp = blk.stacks[i];
                 blk.fib[i].uc_stack.ss_size = kStack;
@@ -83,20 +101,49 @@ static int wl_launch(const typename K::Args& a, int64_t nblocks, size_t lds, voi
                 makecontext(&blk.fib[i], (void (*)())wl_emu_entry<K>, 2, (unsigned)(p & 0xffffffffu),
                             (unsigned)(p >> 32));
             }
-            bool alive = true;
-            int round = 0;
-            while (alive) {
-                alive = false;
+            int phase = 0;
+            for (;;) {
+                // run every ready fibre to its next yield
+                bool ran = false;
                 for (int s = 0; s < nt; ++s) {
-                    const int i = (round & 1) ? nt - 1 - s : s;
-                    if (blk.done[i]) continue;
+                    const int i = (phase & 1) ? nt - 1 - s : s;
+                    if (blk.state[i] != 0) continue;
                     blk.cur = i;
                     swapcontext(&blk.main, &blk.fib[i]);
-                    if (!blk.done[i]) alive = true;
+                    ran = true;
                 }
-                ++round;
+                // resolve wave shuffles: all live lanes of the wave must have arrived
+                bool resolved = false;
+                for (int w0 = 0; w0 < nt; w0 += 64) {
+                    bool any = false, all = true;
+                    for (int i = w0; i < w0 + 64 && i < nt; ++i) {
+                        if (blk.state[i] == 2) any = true;
+                        else if (blk.state[i] != 3) all = false;
+                    }
+                    if (any && all) {
+                        for (int i = w0; i < w0 + 64 && i < nt; ++i)
+                            blk.shfl_out[i] = (i > w0) ? blk.shfl_in[i - 1] : blk.shfl_in[i];
+                        for (int i = w0; i < w0 + 64 && i < nt; ++i)
+                            if (blk.state[i] == 2) blk.state[i] = 0;
+                        resolved = true;
+                    }
+                }
+                if (resolved) continue;
+                bool any_ready = false, any_barrier = false, any_shfl = false;
+                for (int i = 0; i < nt; ++i) {
+                    any_ready |= blk.state[i] == 0;
+                    any_barrier |= blk.state[i] == 1;
+                    any_shfl |= blk.state[i] == 2;
+                }
+                if (any_ready) continue;
+                if (any_shfl) abort();   // a wave is stuck at a shuffle while others sit at a barrier: divergent shuffle
+                if (!any_barrier) break; // everyone done
+                for (int i = 0; i < nt; ++i) if (blk.state[i] == 1) blk.state[i] = 0;
+                ++phase;
+                (void)ran;
             }
         }
+        wl_emu_cur_block = nullptr;
         free(smem);
     }
     return 0;

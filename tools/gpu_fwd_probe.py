@@ -4,7 +4,8 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pytorch_wavelets_amd as pw
 dev = torch.device('cuda:0')
-x = torch.randn(128, 3, 512, 512, device=dev)
+HH = int(os.environ.get('PROBE_H', 512)); WW = int(os.environ.get('PROBE_W', 512))
+x = torch.randn(128, 3, HH, WW, device=dev)
 def t(fn, n=20):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -18,4 +19,5 @@ for J in Js:
     xfm = pw.DWTForward(J=J, wave='db4', mode='symmetric').to(dev)
     with torch.no_grad():
         a = t(lambda: xfm(x))
-    print('%-50s J=%d fwd %.4f ms' % (tag, J, a), flush=True)
+    nb = 128 * 3 * 4 * (HH * WW + 4 * ((HH + 7) // 2) * ((WW + 7) // 2)) if J == 1 else 0
+    print('%-50s %dx%d J=%d fwd %.4f ms  %s' % (tag, HH, WW, J, a, ('%.0f GB/s' % (nb / a / 1e6)) if nb else ''), flush=True)
