@@ -53,6 +53,96 @@ WL_HD size_t wl_dtfwd1_lds(const WlDtFwd1Args<T>& a) {
     return sizeof(A) * (wl_align_up(a.L0 + a.L1, 4) + nr * (nc | 1) + nr * a.TW * 2);
 }
 
+// element-aligned pair (8-byte stores of two adjacent samples / one complex value)
+template <typename T> struct __attribute__((packed, aligned(sizeof(T)), may_alias)) WlPair { T a, b; };
+
+// q2c (transform_funcs.py:61-72): quad samples p = 0:(r,c) 1:(r,c+1) 2:(r+1,c) 3:(r+1,c+1) of the band `v` ->
+// orientations (o1, o2):  z1 = ((a-d) + i(b+c))/sqrt2,  z2 = ((a+d) + i(b-c))/sqrt2
+template <typename A>
+WL_DEV void wl_q2c(const A* v, A& re1, A& im1, A& re2, A& im2) {
+    const A k = (A)WL_SQRT1_2;
+    re1 = (v[0] - v[3]) * k; im1 = (v[1] + v[2]) * k;
+    re2 = (v[0] + v[3]) * k; im2 = (v[1] - v[2]) * k;
+}
+
+// Output of one 2x2 quad (full-res origin R, Cc; both even) of plane `plane`, shared by the generic and the
+// specialised level-1 kernels: lowpass, the six complex orientations and / or the ScatLayer epilogue.
+// `msum` = this quad's six running sums over colour planes (combine_colour), `ch` the colour index.
+template <typename T, typename A>
+WL_DEV void wl_dtfwd1_quad_out(const WlDtFwd1Args<T>& a, int64_t plane, int ch, int R, int Cc, const A* ll,
+                               const A* lh, const A* hl, const A* hh, A* msum) {
+    typedef WlPair<T> Pair;
+    const int w2 = a.We / 2;
+    const size_t qplane = (size_t)(a.He / 2) * w2;
+    if (a.ll) {
+        T* lp = a.ll + (size_t)plane * a.He * a.We + (size_t)R * a.We + Cc;
+        Pair p0, p1;
+        p0.a = (T)ll[0]; p0.b = (T)ll[1]; p1.a = (T)ll[2]; p1.b = (T)ll[3];
+        *reinterpret_cast<Pair*>(lp) = p0;
+        *reinterpret_cast<Pair*>(lp + a.We) = p1;
+    }
+    if (!a.highs && !a.z) return;
+    A re[6], im[6];
+    wl_q2c(lh, re[0], im[0], re[5], im[5]);
+    wl_q2c(hh, re[1], im[1], re[4], im[4]);
+    wl_q2c(hl, re[2], im[2], re[3], im[3]);
+    const size_t q = (size_t)(R / 2) * w2 + (Cc / 2);
+    if (a.highs) {
+        T* hp = a.highs + (size_t)plane * 12 * qplane;
+#pragma unroll
+        for (int o = 0; o < 6; ++o) {
+            Pair p; p.a = (T)re[o]; p.b = (T)im[o];
+            *reinterpret_cast<Pair*>(hp + ((size_t)o * qplane + q) * 2) = p;
+        }
+    }
+    if (!a.z) return;
+    const int64_t n = plane / a.C;
+    const int c = (int)(plane - n * a.C);
+    const A b2 = a.magbias * a.magbias;
+    const A llavg = (ll[0] + ll[1] + ll[2] + ll[3]) * (A)0.25;
+    if (!a.combine) {
+        T* zp = a.z + ((size_t)n * 7 * a.C + c) * qplane + q;
+        zp[0] = (T)llavg;
+#pragma unroll
+        for (int o = 0; o < 6; ++o) {
+            const A r = wl_sqrt(re[o] * re[o] + im[o] * im[o] + b2);
+            zp[(size_t)(o + 1) * a.C * qplane] = (T)(r - a.magbias);
+            if (a.drdx) {
+                const size_t so = (((size_t)n * 6 + o) * a.C + c) * qplane + q;
+                a.drdx[so] = (T)(re[o] / r);
+                a.drdy[so] = (T)(im[o] / r);
+            }
+        }
+    } else {
+        T* zp = a.z + (size_t)n * 9 * qplane + q;
+        zp[(size_t)c * qplane] = (T)llavg;
+#pragma unroll
+        for (int o = 0; o < 6; ++o) {
+            const A e = re[o] * re[o] + im[o] * im[o];
+            msum[o] = ch == 0 ? e : msum[o] + e;
+            if (a.drdx) {   // numerators now, divided by r in the last pass
+                const size_t so = (((size_t)n * 6 + o) * 3 + c) * qplane + q;
+                a.drdx[so] = (T)re[o];
+                a.drdy[so] = (T)im[o];
+            }
+        }
+        if (ch == 2) {
+#pragma unroll
+            for (int o = 0; o < 6; ++o) {
+                const A r = wl_sqrt(msum[o] + b2);
+                zp[(size_t)(3 + o) * qplane] = (T)(r - a.magbias);
+                if (a.drdx) {
+                    for (int c3 = 0; c3 < 3; ++c3) {
+                        const size_t so = (((size_t)n * 6 + o) * 3 + c3) * qplane + q;
+                        a.drdx[so] = (T)((A)a.drdx[so] / r);
+                        a.drdy[so] = (T)((A)a.drdy[so] / r);
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <typename T>
 WL_DEV void wl_dtcwt_fwd1_body(const WlDtFwd1Args<T>& a, const WlCtx& ctx) {
     typedef typename WlAcc<T>::type A;
@@ -69,8 +159,6 @@ WL_DEV void wl_dtcwt_fwd1_body(const WlDtFwd1Args<T>& a, const WlCtx& ctx) {
     for (int i = ctx.tid; i < a.L0; i += ctx.nthreads) t0[i] = a.h0[i];
     for (int i = ctx.tid; i < a.L1; i += ctx.nthreads) t1[i] = a.h1[i];
     const int m0 = a.L0 / 2, m1 = a.L1 / 2;
-    const int h2 = a.He / 2, w2 = a.We / 2;
-    const size_t qplane = (size_t)h2 * w2;
     const int nch = a.combine ? 3 : 1;
     // combine_colour accumulates re^2+im^2 over the 3 colour planes; each thread owns the same quads for all
     A msum[4][6];
@@ -119,69 +207,7 @@ WL_DEV void wl_dtcwt_fwd1_body(const WlDtFwd1Args<T>& a, const WlCtx& ctx) {
                     }
                     ll[p] = vll; lh[p] = vlh; hl[p] = vhl; hh[p] = vhh;
                 }
-                if (a.ll) {
-                    T* lp = a.ll + (size_t)plane * a.He * a.We + (size_t)R * a.We + Cc;
-                    lp[0] = (T)ll[0]; lp[1] = (T)ll[1]; lp[a.We] = (T)ll[2]; lp[a.We + 1] = (T)ll[3];
-                }
-                if (!a.highs && !a.z) continue;
-                // q2c: a=y[0,0] b=y[0,1] c=y[1,0] d=y[1,1];  z1=(a-d)+i(b+c)  z2=(a+d)+i(b-c), all /sqrt2
-                A re[6], im[6];
-                const A k = (A)WL_SQRT1_2;
-                re[0] = (lh[0] - lh[3]) * k; im[0] = (lh[1] + lh[2]) * k; re[5] = (lh[0] + lh[3]) * k; im[5] = (lh[1] - lh[2]) * k;
-                re[1] = (hh[0] - hh[3]) * k; im[1] = (hh[1] + hh[2]) * k; re[4] = (hh[0] + hh[3]) * k; im[4] = (hh[1] - hh[2]) * k;
-                re[2] = (hl[0] - hl[3]) * k; im[2] = (hl[1] + hl[2]) * k; re[3] = (hl[0] + hl[3]) * k; im[3] = (hl[1] - hl[2]) * k;
-                const size_t q = (size_t)(R / 2) * w2 + (Cc / 2);
-                if (a.highs) {
-                    T* hp = a.highs + (size_t)plane * 12 * qplane;
-                    for (int o = 0; o < 6; ++o) {
-                        hp[((size_t)o * qplane + q) * 2] = (T)re[o];
-                        hp[((size_t)o * qplane + q) * 2 + 1] = (T)im[o];
-                    }
-                }
-                if (a.z) {
-                    const int64_t n = plane / a.C;
-                    const int c = (int)(plane - n * a.C);
-                    const A b2 = a.magbias * a.magbias;
-                    const A llavg = (ll[0] + ll[1] + ll[2] + ll[3]) * (A)0.25;
-                    if (!a.combine) {
-                        T* zp = a.z + ((size_t)n * 7 * a.C + c) * qplane + q;
-                        zp[0] = (T)llavg;
-                        for (int o = 0; o < 6; ++o) {
-                            const A r = wl_sqrt(re[o] * re[o] + im[o] * im[o] + b2);
-                            zp[(size_t)(o + 1) * a.C * qplane] = (T)(r - a.magbias);
-                            if (a.drdx) {
-                                const size_t so = (((size_t)n * 6 + o) * a.C + c) * qplane + q;
-                                a.drdx[so] = (T)(re[o] / r);
-                                a.drdy[so] = (T)(im[o] / r);
-                            }
-                        }
-                    } else {
-                        T* zp = a.z + (size_t)n * 9 * qplane + q;
-                        zp[(size_t)c * qplane] = (T)llavg;
-                        for (int o = 0; o < 6; ++o) {
-                            const A e = re[o] * re[o] + im[o] * im[o];
-                            msum[slot & 3][o] = ch == 0 ? e : msum[slot & 3][o] + e;
-                            if (a.drdx) {   // numerators now, divided by r in the last pass
-                                const size_t so = (((size_t)n * 6 + o) * 3 + c) * qplane + q;
-                                a.drdx[so] = (T)re[o];
-                                a.drdy[so] = (T)im[o];
-                            }
-                        }
-                        if (ch == 2) {
-                            for (int o = 0; o < 6; ++o) {
-                                const A r = wl_sqrt(msum[slot & 3][o] + b2);
-                                zp[(size_t)(3 + o) * qplane] = (T)(r - a.magbias);
-                                if (a.drdx) {
-                                    for (int c3 = 0; c3 < 3; ++c3) {
-                                        const size_t so = (((size_t)n * 6 + o) * 3 + c3) * qplane + q;
-                                        a.drdx[so] = (T)((A)a.drdx[so] / r);
-                                        a.drdy[so] = (T)((A)a.drdy[so] / r);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
+                wl_dtfwd1_quad_out<T>(a, plane, ch, R, Cc, ll, lh, hl, hh, msum[slot & 3]);
             }
         }
     }
