@@ -16,6 +16,19 @@ __global__ void __launch_bounds__(K::kThreads, K::kMinWaves) wl_kernel(const typ
     K::run(a, ctx);
 }
 
+// compute units of the current device (persistent kernels size their grid from it)
+static int wl_num_cus() {
+    static thread_local int cached_dev = -1, cached = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached = n; cached_dev = dev;
+    }
+    return cached;
+}
+
 template <typename K>
 static int wl_launch(const typename K::Args& a, int64_t nblocks, size_t lds, void* stream) {
     if (nblocks <= 0) return 0;

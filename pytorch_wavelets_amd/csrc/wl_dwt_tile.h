@@ -134,16 +134,20 @@ struct WlAfbTile {
             }
         };
 
+        // Software pipeline (gfx9 has ONE in-order counter for loads and stores, so a wait for loads also waits
+        // for every store issued before it): tile t+1 is committed to LDS between the two banks of tile t, i.e.
+        // the wait sits a whole row bank after the youngest stores, and the loads of tile t+2 are issued right
+        // after it - they fly during the column bank of t and the row bank of t+1.
         issue(tx_begin);
+        commit();
+        ctx.sync();
+        if (tx_begin + 1 < tx_end) issue(tx_begin + 1);
         for (int tx = tx_begin; tx < tx_end; ++tx) {
             const int kw0 = tx * TW;
             {
                 const int ncols_out = (a.Kw - kw0) < TW ? (a.Kw - kw0) : TW;
                 nq_need = (ncols_out + 1) / 2;
             }
-            commit();
-            ctx.sync();
-            if (tx + 1 < tx_end) issue(tx + 1);
         // ---- row bank -----------------------------------------------------------------------------------------
         {
             wl_v2 tw[LT];
@@ -171,6 +175,10 @@ struct WlAfbTile {
             }
         }
         ctx.sync();
+        if (tx + 1 < tx_end) {
+            commit();                                  // tile tx+1 -> S (the row bank above was its last reader)
+            if (tx + 2 < tx_end) issue(tx + 2);
+        }
         // ---- column bank + band stores ---------------------------------------------------------------------------
         {
             wl_v2 th[LT];
@@ -211,6 +219,7 @@ struct WlAfbTile {
                 }
             }
         }
-        }   // tile loop (the barrier after the next commit orders this column bank before the next row bank)
+        ctx.sync();   // S(tx+1) visible; Tm free for the next row bank
+        }   // tile loop
     }
 };

@@ -14,6 +14,9 @@
 
 #define WL_BACKEND_NAME "emu"
 
+// a deliberately tiny "chip" so that persistent kernels walk several tiles per workgroup in the tests
+static int wl_num_cus() { return 2; }
+
 struct WlEmuBlock {
     ucontext_t main;
     std::vector<ucontext_t> fib;

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pytorch_wavelets_amd as pw
 dev = torch.device('cuda:0')
 HH = int(os.environ.get('PROBE_H', 512)); WW = int(os.environ.get('PROBE_W', 512))
-x = torch.randn(128, 3, HH, WW, device=dev)
+NN = int(os.environ.get("PROBE_N", 128))
+x = torch.randn(NN, 3, HH, WW, device=dev)
 def t(fn, n=20):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -19,5 +20,5 @@ for J in Js:
     xfm = pw.DWTForward(J=J, wave='db4', mode='symmetric').to(dev)
     with torch.no_grad():
         a = t(lambda: xfm(x))
-    nb = 128 * 3 * 4 * (HH * WW + 4 * ((HH + 7) // 2) * ((WW + 7) // 2)) if J == 1 else 0
-    print('%-50s %dx%d J=%d fwd %.4f ms  %s' % (tag, HH, WW, J, a, ('%.0f GB/s' % (nb / a / 1e6)) if nb else ''), flush=True)
+    nb = NN * 3 * 4 * (HH * WW + 4 * ((HH + 7) // 2) * ((WW + 7) // 2)) if J == 1 else 0
+    print('%-30s N=%d %dx%d J=%d fwd %.4f ms (%.3f us/plane) %s' % (tag, NN, HH, WW, J, a, a * 1e3 / (3 * NN), ('%.0f GB/s' % (nb / a / 1e6)) if nb else ''), flush=True)
