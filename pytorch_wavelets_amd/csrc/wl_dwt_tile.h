@@ -38,7 +38,7 @@ struct WlAfbTileArgs {
     int ablate;       // profiling only (WL_ABLATE): 1 no stores, 2 no loads, 4 no row bank, 8 no column bank
 };
 
-template <typename T, int LT, int TH_ = 16, int TW_ = 64>
+template <typename T, int LT, int TH_ = 16, int TW_ = 64, int SH_ = 0>
 struct WlAfbTile {
     typedef WlAfbTileArgs<T> Args;
     static const int kThreads = 256;
@@ -46,7 +46,9 @@ struct WlAfbTile {
     static const int TH = TH_, TW = TW_;
     static const int NROWS = 2 * TH + LT - 2;            // staged input rows
     static const int NCOLS = 2 * TW + LT - 2;            // staged input cols actually needed
-    static const int NV = (LT + 2 + 3) / 4;              // float4 reads per row item
+    static const int SH = SH_;                           // 1: odd `base` (periodization) - the staged origin is moved one
+                                                         //    column left so that lanes still read aligned pairs
+    static const int NV = (LT + 2 + SH + 3) / 4;         // float4 reads per row item
     static const int NQ = TW / 2;                        // k-pairs per tile row
     static const int SP = 4 * (NQ - 1) + 4 * NV;         // staged row pitch (floats, multiple of 4, >= NCOLS)
     static const int TP = 2 * TW;                        // (lo,hi) row pitch in floats
@@ -99,7 +101,7 @@ struct WlAfbTile {
         // column (an L1/L2 hit), so every mode, odd widths and multiple reflections need no special path.
         auto issue = [&](int tx) {
             const int kw0 = tx * TW;
-            const int ec0 = 2 * kw0 + a.base;
+            const int ec0 = 2 * kw0 + a.base - SH;
             const int ncols_out = (a.Kw - kw0) < TW ? (a.Kw - kw0) : TW;
             const int nq = (ncols_out + 1) / 2;
             const int np_need = nq * 2 + NV * 2 - 2 < NP ? nq * 2 + NV * 2 - 2 : NP;   // staged pairs per row
@@ -166,8 +168,8 @@ struct WlAfbTile {
                 wl_v2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < LT; ++j) {
-                    a0 += tw[j] * v[j];
-                    a1 += tw[j] * v[j + 2];
+                    a0 += tw[j] * v[j + SH];
+                    a1 += tw[j] * v[j + 2 + SH];
                 }
                 wl_f4 o;
                 o.x = a0.x; o.y = a0.y; o.z = a1.x; o.w = a1.y;
