@@ -11,14 +11,17 @@
 //           dword loads (all loads of a thread issued before the first LDS write) and stored interleaved as one
 //           float4 (ll,lh,hl,hh) per cell; cells outside the bands are zero (or wrap, periodization);
 //   column: item = (row pair, band column): L/2 ds_read_b128, 4 packed FMAs per tap -> (lo,hi) for both rows;
-//   row   : item = (row, column pair): L/2 ds_read_b64 (lo,hi), 2 packed FMAs per tap -> 8 contiguous bytes of
-//           y per lane (512 B per wave).
+//   row   : item = (row, TWO column pairs): (L/2+2)/2 ds_read_b128 (a sliding window of (lo,hi) samples), 4 packed
+//           FMAs per tap -> 16 contiguous bytes of y per lane.
+// The parity of the shift s is a template parameter: for even s (every non-periodization mode with L = 2 mod 4
+// excluded - e.g. db4 symmetric) a 32 x 64 tile needs exactly 16 x 32 output pairs, no spare pair row / column.
 //
 // Restates SFB2D.forward (reference dwt/lowlevel.py:671-680 = 3 x sfb1d = 6 x conv_transpose2d + 3 adds,
 // :226-271) and, with a cropped OH/OW, AFB2D.backward (:350-365).
 #pragma once
 #include "wl_common.h"
 #include "wl_dwt_stream.h"   // wl_f4 / wl_f2 / wl_v2
+#include "wl_dtcwt_tile.h"   // WlPair / WlQuad
 
 template <typename T>
 struct WlSfbTileArgs {
@@ -38,21 +41,21 @@ struct WlSfbTileArgs {
     int64_t nblocks;  // grid size (for the XCD-aware block remap)
 };
 
-template <typename T, int LT>
+template <typename T, int LT, int SODD>   // SODD = s & 1 (parity of the synthesis shift)
 struct WlSfbTile {
     typedef WlSfbTileArgs<T> Args;
     static const int kThreads = 256;
     static const int kMinWaves = 4;
     static const int TH = 32, TW = 64;
     static const int HL = LT / 2;                 // taps per phase
-    static const int NPR = TH / 2 + 1;            // row pairs per tile (+1: odd s shifts the pairing by one)
-    static const int NPC = TW / 2 + 1;            // column pairs per tile
+    static const int NPR = TH / 2 + SODD;         // row pairs per tile (odd s shifts the pairing by one)
+    static const int NPC = TW / 2 + 2 * SODD;     // column pairs per tile (even: the row pass takes two at a time)
     static const int NKR = NPR + HL - 1;          // staged band rows
-    static const int NKC = NPC + HL - 1;          // staged band cols
+    static const int NKC = (NPC + HL - 1 + 1) & ~1;   // staged band cols = LDS pitch in cells (even: b128 reads of U)
     static const int UR = 2 * NPR;                // intermediate rows
     static const int kTapFloats = 4 * LT;
     static const int kLdsFloats = kTapFloats + 4 * NKR * NKC + 2 * UR * NKC;
-    struct __attribute__((packed, aligned(sizeof(T)), may_alias)) Pair { T a, b; };
+    typedef WlPair<T> Pair;
 
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
         const int tid = ctx.tid;
@@ -61,7 +64,7 @@ struct WlSfbTile {
         const int64_t plane = lbid / tiles;
         const int tile = (int)(lbid - plane * tiles);
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-        const int sodd = a.s & 1;
+        constexpr int sodd = SODD;
         // first pair of the tile: n0 = 2*m0 - sodd with 2*m0 = tile origin; c = (n0 + s)/2
         const int nrow0 = ty * TH - sodd, ncol0 = tx * TW - sodd;
         const int cr0 = (nrow0 + a.s) >> 1, cc0 = (ncol0 + a.s) >> 1;   // exact (even), may be negative
@@ -146,26 +149,43 @@ struct WlSfbTile {
             T* yp = a.y + (size_t)plane * a.OH * a.OW;
             const int row_lo = ty * TH, row_hi = (ty * TH + TH) < a.OH ? (ty * TH + TH) : a.OH;
             const int col_lo = tx * TW, col_hi = (tx * TW + TW) < a.OW ? (tx * TW + TW) : a.OW;
-            _Pragma("nounroll") for (int f = tid; f < UR * NPC; f += kThreads) {
-                const int ur = f / NPC, q = f - ur * NPC;
+            // item = (intermediate row, two column pairs): window of HL+1 (lo,hi) samples -> 4 contiguous outputs
+            constexpr int NQ2 = NPC / 2;
+            constexpr int NW = (HL + 1 + 1) / 2;      // ds_read_b128 per item (two (lo,hi) samples each)
+            _Pragma("nounroll") for (int f = tid; f < UR * NQ2; f += kThreads) {
+                const int ur = f / NQ2, q2 = f - ur * NQ2;
                 const int n = nrow0 + ur;
                 if (n < row_lo || n >= row_hi) continue;
-                wl_v2 acc = {0.f, 0.f};   // (col w0, col w0+1)
+                // pairs q = 2*q2 and q+1 read U[q + HL-1 - j] and U[q + HL - j], j < HL: cells 2*q2 .. 2*q2 + HL
+                float ul[2 * NW], uh[2 * NW];
+                const wl_f4* u4 = reinterpret_cast<const wl_f4*>(U + ur * NKC + 2 * q2);
+#pragma unroll
+                for (int u = 0; u < NW; ++u) {
+                    const wl_f4 t = u4[u];
+                    ul[2 * u] = t.x; uh[2 * u] = t.y; ul[2 * u + 1] = t.z; uh[2 * u + 1] = t.w;
+                }
+                wl_v2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};   // (col w0, w0+1), (w0+2, w0+3)
 #pragma unroll
                 for (int j = 0; j < HL; ++j) {
-                    const wl_f2 u = U[ur * NKC + (q + HL - 1 - j)];
-                    acc += g0[j] * u.x;
-                    acc += g1[j] * u.y;
+                    acc0 += g0[j] * ul[HL - 1 - j]; acc0 += g1[j] * uh[HL - 1 - j];
+                    acc1 += g0[j] * ul[HL - j];     acc1 += g1[j] * uh[HL - j];
                 }
-                const int w0 = ncol0 + 2 * q;
+                const int w0 = ncol0 + 4 * q2;
                 T* dst = yp + (n * a.OW + w0);   // (w0 may be -1: signed offset)
-                const bool ok0 = w0 >= col_lo && w0 < col_hi, ok1 = w0 + 1 >= col_lo && w0 + 1 < col_hi;
-                if (ok0 && ok1) {
-                    Pair pr; pr.a = (T)acc.x; pr.b = (T)acc.y;
-                    *reinterpret_cast<Pair*>(dst) = pr;
+                if (w0 >= col_lo && w0 + 3 < col_hi) {
+                    if (SODD == 0) {
+                        WlQuad<T> o; o.a = (T)acc0.x; o.b = (T)acc0.y; o.c = (T)acc1.x; o.d = (T)acc1.y;
+                        *reinterpret_cast<WlQuad<T>*>(dst) = o;
+                    } else {
+                        Pair p0, p1; p0.a = (T)acc0.x; p0.b = (T)acc0.y; p1.a = (T)acc1.x; p1.b = (T)acc1.y;
+                        *reinterpret_cast<Pair*>(dst) = p0;
+                        *reinterpret_cast<Pair*>(dst + 2) = p1;
+                    }
                 } else {
-                    if (ok0) dst[0] = (T)acc.x;
-                    if (ok1) dst[1] = (T)acc.y;
+                    const float v[4] = {acc0.x, acc0.y, acc1.x, acc1.y};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (w0 + u >= col_lo && w0 + u < col_hi) dst[u] = (T)v[u];
                 }
             }
         }
