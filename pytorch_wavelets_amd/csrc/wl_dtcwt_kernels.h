@@ -68,9 +68,11 @@ WL_DEV void wl_q2c(const A* v, A& re1, A& im1, A& re2, A& im2) {
 // Output of one 2x2 quad (full-res origin R, Cc; both even) of plane `plane`, shared by the generic and the
 // specialised level-1 kernels: lowpass, the six complex orientations and / or the ScatLayer epilogue.
 // `msum` = this quad's six running sums over colour planes (combine_colour), `ch` the colour index.
-template <typename T, typename A>
+// COMB: compile-time combine_colour (0 / 1), or -1 = decided at run time by a.combine.
+template <typename T, int COMB = -1, typename A>
 WL_DEV void wl_dtfwd1_quad_out(const WlDtFwd1Args<T>& a, int64_t plane, int ch, int R, int Cc, const A* ll,
                                const A* lh, const A* hl, const A* hh, A* msum) {
+    const bool combine = COMB < 0 ? (a.combine != 0) : (COMB != 0);
     typedef WlPair<T> Pair;
     const int w2 = a.We / 2;
     const size_t qplane = (size_t)(a.He / 2) * w2;
@@ -100,7 +102,7 @@ WL_DEV void wl_dtfwd1_quad_out(const WlDtFwd1Args<T>& a, int64_t plane, int ch, 
     const int c = (int)(plane - n * a.C);
     const A b2 = a.magbias * a.magbias;
     const A llavg = (ll[0] + ll[1] + ll[2] + ll[3]) * (A)0.25;
-    if (!a.combine) {
+    if (!combine) {
         T* zp = a.z + ((size_t)n * 7 * a.C + c) * qplane + q;
         zp[0] = (T)llavg;
 #pragma unroll

@@ -19,14 +19,14 @@
 //   stage : (TH+2M) x SP input cells, origin (r0-M, c0-MA) with MA = M rounded up to even so that interior
 //           lanes read aligned pairs;
 //   row   : item = (staged row, 4 output columns): NV ds_read_b128 -> 4 x (lo, hi) -> 2 ds_write_b128;
-//   column: item = (column pair, 4 output rows) = two 2x2 quads: 4+2M ds_read_b128 of (lo,hi,lo,hi), all four
-//           bands of both quads in registers, q2c + stores through wl_dtfwd1_quad_out.
+//   column: item = one 2x2 quad: 2+2M ds_read_b128 of (lo,hi,lo,hi), packed FMAs ((ll,hl) and (lh,hh) pairs), all
+//           four bands in registers, q2c + stores through wl_dtfwd1_quad_out.
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, int L0, int L1, int TH_ = 32, int TW_ = 64>
+template <typename T, int L0, int L1, int COMB = 0, int TH_ = 32, int TW_ = 64>
 struct WlDtFwd1Tile {
     typedef WlDtFwd1Args<T> Args;
     static const int kThreads = 256;
-    static const int kMinWaves = 2;
+    static const int kMinWaves = (L0 + L1 <= 16) ? 4 : 2;
     static const int TH = TH_, TW = TW_;
     static const int M0 = L0 / 2, M1 = L1 / 2, M = M0 > M1 ? M0 : M1, MA = (M + 1) & ~1;
     static const int NR = TH + 2 * M;                    // staged rows
@@ -38,7 +38,7 @@ struct WlDtFwd1Tile {
     static const int NP = SP / 2;                        // staged pairs per row
     static const int RPI = kThreads / NP;                // staged rows per staging iteration
     static const int NIT = (NR + RPI - 1) / RPI;
-    static const int NQT = (TH / 4) * (TW / 2);          // column items per tile
+    static const int NQT = (TH / 2) * (TW / 2);          // column items (2x2 quads) per tile
     static const int NQI = (NQT + kThreads - 1) / kThreads;
     typedef T Pair2 __attribute__((ext_vector_type(2)));
 
@@ -69,10 +69,10 @@ struct WlDtFwd1Tile {
             const int i = it * RPI + s_row;
             rsrc[it] = (lane_on && i < NR) ? wl_ext_padded(r0 - M + i, a.H, 0, padr, a.ext) : -1;
         }
-        const int nch = a.combine ? 3 : 1;
-        float msum[NQI][2][6];
+        const int nch = COMB ? 3 : 1;
+        float msum[COMB ? NQI : 1][6];
         for (int ch = 0; ch < nch; ++ch) {
-            const int64_t plane = a.combine ? unit * 3 + ch : unit;
+            const int64_t plane = COMB ? unit * 3 + ch : unit;
             const T* xp = a.x + (size_t)plane * a.H * a.W;
             // ---- stage: all loads first, then the LDS writes ------------------------------------------------------
             {
@@ -145,42 +145,34 @@ struct WlDtFwd1Tile {
                 for (int qi = 0; qi < NQI; ++qi) {
                     const int f = tid + qi * kThreads;
                     if (f >= NQT) break;
-                    const int rg = f / (TW / 2), cp = f - rg * (TW / 2);
-                    // acc[row][col][band]: band 0 ll, 1 lh, 2 hl, 3 hh
-                    float acc[4][2][4];
+                    const int qr = f / (TW / 2), cp = f - qr * (TW / 2);
+                    // [row][col] of the quad: aL = (ll, hl) (lowpass along H), aH = (lh, hh) (highpass along H)
+                    wl_v2 aL[2][2], aH[2][2];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 2; ++r)
 #pragma unroll
-                        for (int c = 0; c < 2; ++c) acc[r][c][0] = acc[r][c][1] = acc[r][c][2] = acc[r][c][3] = 0.f;
-                    const float* col = Tm + (4 * rg) * TP + 4 * cp;
+                        for (int c = 0; c < 2; ++c) { aL[r][c] = wl_v2{0.f, 0.f}; aH[r][c] = wl_v2{0.f, 0.f}; }
+                    const float* col = Tm + (2 * qr) * TP + 4 * cp;
 #pragma unroll
-                    for (int w = 0; w < 4 + 2 * M; ++w) {
+                    for (int w = 0; w < 2 + 2 * M; ++w) {
                         const wl_f4 p = *reinterpret_cast<const wl_f4*>(col + w * TP);   // lo_c0, hi_c0, lo_c1, hi_c1
+                        const wl_v2 s0 = {p.x, p.y}, s1 = {p.z, p.w};
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
+                        for (int r = 0; r < 2; ++r) {
                             const int ta = w - r - (M - M0), tb = w - r - (M - M1);
-                            if (ta >= 0 && ta < L0) {
-                                acc[r][0][0] += t0[ta] * p.x; acc[r][0][2] += t0[ta] * p.y;
-                                acc[r][1][0] += t0[ta] * p.z; acc[r][1][2] += t0[ta] * p.w;
-                            }
-                            if (tb >= 0 && tb < L1) {
-                                acc[r][0][1] += t1[tb] * p.x; acc[r][0][3] += t1[tb] * p.y;
-                                acc[r][1][1] += t1[tb] * p.z; acc[r][1][3] += t1[tb] * p.w;
-                            }
+                            if (ta >= 0 && ta < L0) { aL[r][0] += s0 * t0[ta]; aL[r][1] += s1 * t0[ta]; }
+                            if (tb >= 0 && tb < L1) { aH[r][0] += s0 * t1[tb]; aH[r][1] += s1 * t1[tb]; }
                         }
                     }
+                    const int R = r0 + 2 * qr, Cc = c0 + 2 * cp;
+                    if (R >= a.He || Cc >= a.We) continue;
+                    float ll[4], lh[4], hl[4], hh[4];
 #pragma unroll
-                    for (int qd = 0; qd < 2; ++qd) {
-                        const int R = r0 + 4 * rg + 2 * qd, Cc = c0 + 2 * cp;
-                        if (R >= a.He || Cc >= a.We) continue;
-                        float ll[4], lh[4], hl[4], hh[4];
-#pragma unroll
-                        for (int p = 0; p < 4; ++p) {
-                            const int r = 2 * qd + (p >> 1), c = p & 1;
-                            ll[p] = acc[r][c][0]; lh[p] = acc[r][c][1]; hl[p] = acc[r][c][2]; hh[p] = acc[r][c][3];
-                        }
-                        wl_dtfwd1_quad_out<T>(a, plane, ch, R, Cc, ll, lh, hl, hh, msum[qi][qd]);
+                    for (int p = 0; p < 4; ++p) {
+                        const int r = p >> 1, c = p & 1;
+                        ll[p] = aL[r][c].x; hl[p] = aL[r][c].y; lh[p] = aH[r][c].x; hh[p] = aH[r][c].y;
                     }
+                    wl_dtfwd1_quad_out<T, COMB>(a, plane, ch, R, Cc, ll, lh, hl, hh, msum[COMB ? qi : 0]);
                 }
             }
             // (the barrier after the next colour plane's staging orders this column bank before its row bank)
