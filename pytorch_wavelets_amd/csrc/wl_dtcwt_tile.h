@@ -322,8 +322,8 @@ struct WlDtFwd2Tile {
 };
 
 // ---------------------------------------------------------------------------------------------------------
-// shared by the inverse kernels: stage an (2*NRQ) x (2*NCQ) block of the four real bands (ll, lh, hl, hh) as one
-// float4 per cell.  The unit of work is a 2x2 QUAD: c2q (dtcwt/lowlevel.py:263-295) turns the two complex
+// shared by the inverse kernels: stage an (2*NRQ) x (2*NCQ) block of the four real bands as one float4
+// (ll, hl, lh, hh) per cell - the two bands that meet the lowpass column filter first, then the two highpass ones.  The unit of work is a 2x2 QUAD: c2q (dtcwt/lowlevel.py:263-295) turns the two complex
 // orientations of a band into the four samples of a quad, and the symmetric extension of an even-sized band
 // maps quads onto quads (mirrored ones with their rows / columns swapped).  Per quad: 2 + 6 eight-byte loads,
 // all issued before the first LDS write.   origin (pr_org, pc_org) must be even.
@@ -382,7 +382,7 @@ WL_DEV void wl_dt_stage_quads(wl_f4* B, int tid, int pr_org, int pc_org, int h, 
             n[0].FIELD = (w1r + w2r) * k; n[1].FIELD = (w1i + w2i) * k;                               \
             n[2].FIELD = (w1i - w2i) * k; n[3].FIELD = (w2r - w1r) * k;                               \
         }
-        WL_C2Q(y, 0, 5) WL_C2Q(z, 2, 3) WL_C2Q(w, 1, 4)
+        WL_C2Q(z, 0, 5) WL_C2Q(y, 2, 3) WL_C2Q(w, 1, 4)
 #undef WL_C2Q
         if (flip[it] & 1) { wl_f4 t = n[0]; n[0] = n[1]; n[1] = t; t = n[2]; n[2] = n[3]; n[3] = t; }
         if (flip[it] & 2) { wl_f4 t = n[0]; n[0] = n[2]; n[2] = t; t = n[1]; n[1] = n[3]; n[3] = t; }
@@ -437,21 +437,22 @@ struct WlDtInv1Tile {
         // ---- column bank ------------------------------------------------------------------------------------------
         _Pragma("nounroll") for (int f = tid; f < (TH / 4) * NCS; f += kThreads) {
             const int rg = f / NCS, j = f - rg * NCS;
-            float lo[4] = {0.f, 0.f, 0.f, 0.f}, hi[4] = {0.f, 0.f, 0.f, 0.f};
+            wl_v2 lh[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // (lo, hi) of the four output rows
             const wl_f4* col = B + (4 * rg) * NCS + j;
 #pragma unroll
             for (int w = ME - M; w < ME + M + 4; ++w) {
-                const wl_f4 p = col[w * NCS];   // ll, lh, hl, hh
+                const wl_f4 p = col[w * NCS];   // ll, hl, lh, hh
+                const wl_v2 pl = {p.x, p.y}, ph = {p.z, p.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ta = w - r - (ME - M0), tb = w - r - (ME - M1);
-                    if (ta >= 0 && ta < L0) { lo[r] += t0[ta] * p.x; hi[r] += t0[ta] * p.z; }
-                    if (tb >= 0 && tb < L1) { lo[r] += t1[tb] * p.y; hi[r] += t1[tb] * p.w; }
+                    if (ta >= 0 && ta < L0) lh[r] += pl * t0[ta];
+                    if (tb >= 0 && tb < L1) lh[r] += ph * t1[tb];
                 }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                wl_f2 u; u.x = lo[r]; u.y = hi[r];
+                wl_f2 u; u.x = lh[r].x; u.y = lh[r].y;
                 U[(4 * rg + r) * NCS + j] = u;
             }
         }
@@ -551,27 +552,22 @@ struct WlDtInv2Tile {
         // ---- column interpolation: item = (staged column, q) -> output rows 4q .. 4q+3 ---------------------------
         _Pragma("nounroll") for (int f = tid; f < (TH / 4) * NCS; f += kThreads) {
             const int ql = f / NCS, j = f - ql * NCS;
-            float lo[4] = {0.f, 0.f, 0.f, 0.f}, hi[4] = {0.f, 0.f, 0.f, 0.f};
+            wl_v2 lh[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // (lo, hi) of output rows 4q+s
             const wl_f4* col = B + (2 * ql + D) * NCS + j;
 #pragma unroll
             for (int w = 0; w < WR; ++w) {
-                const wl_f4 p = col[w * NCS];   // ll, lh, hl, hh
+                const wl_f4 p = col[w * NCS];   // ll, hl, lh, hh
+                const wl_v2 pl = {p.x, p.y}, ph = {p.z, p.w};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int tl_ = w - LP::o(s), th_ = w - HPm::o(s);
-                    if (tl_ >= 0 && (tl_ & 1) == 0 && tl_ / 2 < m2) {
-                        const float c = tp[s & 1][LP::e(s) + tl_];
-                        lo[s] += c * p.x; hi[s] += c * p.z;
-                    }
-                    if (th_ >= 0 && (th_ & 1) == 0 && th_ / 2 < m2) {
-                        const float c = tp[2 + (s & 1)][HPm::e(s) + th_];
-                        lo[s] += c * p.y; hi[s] += c * p.w;
-                    }
+                    if (tl_ >= 0 && (tl_ & 1) == 0 && tl_ / 2 < m2) lh[s] += pl * tp[s & 1][LP::e(s) + tl_];
+                    if (th_ >= 0 && (th_ & 1) == 0 && th_ / 2 < m2) lh[s] += ph * tp[2 + (s & 1)][HPm::e(s) + th_];
                 }
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                wl_f2 u; u.x = lo[s]; u.y = hi[s];
+                wl_f2 u; u.x = lh[s].x; u.y = lh[s].y;
                 U[(4 * ql + s) * NCS + j] = u;
             }
         }
