@@ -167,6 +167,18 @@ def main():
         l1_ms = e0.elapsed_time(e1) / args.steps
     l1_bytes = algorithmic_bytes_fwd(N, C, H, W, 1, 8, 4)
     l1_gbs = l1_bytes / (l1_ms * 1e-3) / 1e9
+    # what a plain device copy of the same footprint achieves on this box (read + write bytes / time)
+    with torch.no_grad():
+        cdst = torch.empty_like(x)
+        cdst.copy_(x)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.steps):
+            cdst.copy_(x)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2 * x.numel() * 4 / (e0.elapsed_time(e1) / args.steps * 1e-3) / 1e9
+        del cdst
     info = pw.engine_info(xfm, x)
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
@@ -194,6 +206,7 @@ def main():
                          'achieved': round(l1_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(l1_gbs / HBM_PEAK_GBS, 4), 'traffic': traffic,
                          'algorithmic_bytes_per_launch': l1_bytes, 'avg_launch_ms': round(l1_ms, 4),
+                         'device_copy_gbs': round(copy_gbs, 1), 'frac_of_device_copy': round(l1_gbs / copy_gbs, 4),
                          'forward_all_levels': {'achieved': round(fwd_gbs, 1), 'frac': round(fwd_gbs / HBM_PEAK_GBS, 4),
                                                 'algorithmic_bytes': fwd_bytes, 'avg_ms': round(fwd_ms, 4),
                                                 'launches': info['fwd_launches']},

@@ -40,6 +40,19 @@ __global__ void k_write(V* __restrict__ out, size_t n) {
     for (; i < n; i += stride) out[i] = v;
 }
 
+__global__ void k_read1(const float* __restrict__ in, float* sink, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float acc = 0.f;
+    for (; i < n; i += stride) acc += in[i];
+    if (acc == 12345.678f) sink[0] = acc;
+}
+__global__ void k_copy1(const float* __restrict__ in, float* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = in[i];
+}
+
 template <typename F>
 static float timeit(F f, int n = 20) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -57,8 +70,12 @@ int main() {
     CK(hipMalloc(&in, nin * 4)); CK(hipMalloc(&out, nout * 4)); CK(hipMalloc(&sink, 4));
     CK(hipMemset(in, 0, nin * 4)); CK(hipMemset(out, 0, nout * 4));
     const size_t n2 = nin / 2, n4 = nin / 4;
-    for (int grid : {768, 2048, 8192, 65536}) {
+    for (int grid : {8192}) {
         float t;
+        t = timeit([&] { hipLaunchKernelGGL(k_read1, dim3(grid), dim3(256), 0, 0, (const float*)in, sink, nin); });
+        printf("read float1 grid %6d: %.4f ms  %.0f GB/s\n", grid, t, 1.0 * nin * 4 / t / 1e6);
+        t = timeit([&] { hipLaunchKernelGGL(k_copy1, dim3(grid), dim3(256), 0, 0, (const float*)in, out, nin); });
+        printf("copy float1 grid %6d: %.4f ms  %.0f GB/s (r+w)\n", grid, t, 2.0 * nin * 4 / t / 1e6);
         t = timeit([&] { hipLaunchKernelGGL(k_copy<float2>, dim3(grid), dim3(256), 0, 0, (const float2*)in, (float2*)out, n2); });
         printf("copy float2 grid %6d: %.4f ms  %.0f GB/s (r+w)\n", grid, t, 2.0 * nin * 4 / t / 1e6);
         t = timeit([&] { hipLaunchKernelGGL(k_copy<float4>, dim3(grid), dim3(256), 0, 0, (const float4*)in, (float4*)out, n4); });
