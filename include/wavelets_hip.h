@@ -116,6 +116,16 @@ int wl_scat_fwd_level1(const void* x, void* z, void* drdx, void* drdy, int dtype
                        const void* h0, int L0, const void* h1, int L1, int mode, double magbias,
                        int combine_colour, void* stream);
 
+/* ScatLayer backward = ScatLayerj1_f.backward (scatternet/lowlevel.py:114-137) in ONE launch: the prologue
+ * (1/4 nearest-upsample of the lowpass gradient, dr*re/r, dr*im/r) is fused into the staging of the level-1 inverse.
+ * dz: gradient of z, same layout as z; drdx/drdy: as written by wl_scat_fwd_level1; dx (N,C,H,W) with H, W the
+ * padded-to-even input size (callers fold the replicated edge for odd inputs, scatternet/layers.py:55-59).
+ * h0/h1: the FORWARD level-1 taps.  Returns WL_ERR_UNSUPPORTED for tap counts / dtypes without a specialised
+ * kernel; callers then compose the prologue themselves and call wl_dtcwt_inv_level1. */
+int wl_scat_bwd_level1(const void* dz, const void* drdx, const void* drdy, void* dx, int dtype, int64_t N, int C,
+                       int H, int W, const void* h0, int L0, const void* h1, int L1, int mode, int combine_colour,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -359,6 +359,9 @@ struct WlDtInv1Args {
     int ll_row_stride;
     int H, W, L0, L1, M, ext;
     int TH, TW, tiles_x, tiles_y;
+    // fused ScatLayer backward (specialised kernel only): dZ, re/r, im/r instead of ll / highs
+    const T* sz; const T* sdx; const T* sdy;
+    int C, combine;
 };
 
 template <typename T>

@@ -330,13 +330,52 @@ struct WlDtFwd2Tile {
 // ---------------------------------------------------------------------------------------------------------
 template <typename T> struct __attribute__((packed, aligned(sizeof(T)), may_alias)) WlQuad { T a, b, c, d; };
 
-template <typename T, int NRQ, int NCQ, int kThreads>
-WL_DEV void wl_dt_stage_quads(wl_f4* B, int tid, int pr_org, int pc_org, int h, int w, int ext, const T* llp,
-                              int ll_rs, const T* hp) {
+// Where a quad's values come from.  A loader fills  l0,l1 = the two lowpass row pairs of source quad (qr,qc)  and
+// z[o] = (re, im) of orientation o.
+template <typename T>
+struct WlDtQuadLoaderPlain {      // (ll plane through strides, highs (6, h/2, w/2, 2)); either may be nullptr
+    const T* llp; int ll_rs; const T* hp; size_t qplane; int w2;
+    WL_DEV void load(int qr, int qc, WlPair<T>& l0, WlPair<T>& l1, WlPair<T>* z) const {
+        typedef WlPair<T> Pair;
+        if (llp) {
+            const T* p = llp + (size_t)(2 * qr) * ll_rs + 2 * qc;
+            l0 = *reinterpret_cast<const Pair*>(p);
+            l1 = *reinterpret_cast<const Pair*>(p + ll_rs);
+        }
+        if (hp) {
+            const size_t q = (size_t)qr * w2 + qc;
+#pragma unroll
+            for (int o = 0; o < 6; ++o) z[o] = *reinterpret_cast<const Pair*>(hp + ((size_t)o * qplane + q) * 2);
+        }
+    }
+};
+// ScatLayer backward prologue (scatternet/lowlevel.py:114-137) fused into the staging:
+//   ll = 1/4 nearest-upsample(dZ_ll),  w_o = dZ_o * (re/r, im/r)
+template <typename T>
+struct WlDtQuadLoaderScat {
+    const T* zl;     // dZ lowpass plane of this (n,c): (h/2, w/2)
+    const T* zr;     // dZ magnitude planes of this (n,c): orientation stride zr_os
+    const T* dx;     // re/r, im/r planes of this (n,c): orientation stride d_os
+    const T* dy;
+    size_t zr_os, d_os;
+    int w2;
+    WL_DEV void load(int qr, int qc, WlPair<T>& l0, WlPair<T>& l1, WlPair<T>* z) const {
+        const size_t q = (size_t)qr * w2 + qc;
+        const T v = (T)((float)zl[q] * 0.25f);
+        l0.a = l0.b = l1.a = l1.b = v;
+#pragma unroll
+        for (int o = 0; o < 6; ++o) {
+            const float dr = (float)zr[o * zr_os + q];
+            z[o].a = (T)(dr * (float)dx[o * d_os + q]);
+            z[o].b = (T)(dr * (float)dy[o * d_os + q]);
+        }
+    }
+};
+
+template <typename T, int NRQ, int NCQ, int kThreads, typename Loader>
+WL_DEV void wl_dt_stage_quads(wl_f4* B, int tid, int pr_org, int pc_org, int h, int w, int ext, const Loader& ld) {
     typedef WlPair<T> Pair;
     constexpr int NQ = NRQ * NCQ, NQI = (NQ + kThreads - 1) / kThreads, BP = 2 * NCQ;
-    const int w2 = w / 2;
-    const size_t qplane = (size_t)(h / 2) * w2;
     Pair l0[NQI], l1[NQI], z[NQI][6];
     int flip[NQI];
 #pragma unroll
@@ -351,18 +390,8 @@ WL_DEV void wl_dt_stage_quads(wl_f4* B, int tid, int pr_org, int pc_org, int h, 
             const int sr = wl_ext(pr_org + 2 * Qr, h, ext), sc = wl_ext(pc_org + 2 * Qc, w, ext);
             flip[it] = 0;
             if (sr >= 0 && sc >= 0) {
-                const int qr = sr >> 1, qc = sc >> 1;
                 flip[it] = ((sr & 1) << 1) | (sc & 1);
-                if (llp) {
-                    const T* p = llp + (size_t)(2 * qr) * ll_rs + 2 * qc;
-                    l0[it] = *reinterpret_cast<const Pair*>(p);
-                    l1[it] = *reinterpret_cast<const Pair*>(p + ll_rs);
-                }
-                if (hp) {
-                    const size_t q = (size_t)qr * w2 + qc;
-#pragma unroll
-                    for (int o = 0; o < 6; ++o) z[it][o] = *reinterpret_cast<const Pair*>(hp + ((size_t)o * qplane + q) * 2);
-                }
+                ld.load(sr >> 1, sc >> 1, l0[it], l1[it], z[it]);
             }
         }
     }
@@ -398,7 +427,7 @@ WL_DEV void wl_dt_stage_quads(wl_f4* B, int tid, int pr_org, int pc_org, int h, 
 //   column: item = (staged column, 4 output rows): 4+2M ds_read_b128 -> 4 x (lo,hi) -> ds_write_b64;
 //   row   : item = (row, 4 output columns): ds_read_b128 of (lo,hi) pairs -> 16 contiguous bytes of y per lane.
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, int L0, int L1, int TH_ = 16, int TW_ = 64>
+template <typename T, int L0, int L1, int SCAT = 0, int TH_ = 16, int TW_ = 64>   // SCAT: fused ScatLayer backward
 struct WlDtInv1Tile {
     typedef WlDtInv1Args<T> Args;
     static const int kThreads = 256;
@@ -425,9 +454,32 @@ struct WlDtInv1Tile {
         if (tid < L0) tl[tid] = a.g0[tid];
         if (tid < L1) tl[L0 + tid] = a.g1[tid];
         const size_t qplane = (size_t)(a.H / 2) * (a.W / 2);
-        wl_dt_stage_quads<T, NRS / 2, NCS / 2, kThreads>(
-            B, tid, r0 - ME, c0 - ME, a.H, a.W, a.ext, a.ll ? a.ll + (size_t)plane * a.ll_plane_stride : nullptr,
-            a.ll_row_stride, a.highs ? a.highs + (size_t)plane * 12 * qplane : nullptr);
+        if (SCAT) {
+            const int64_t n = plane / a.C;
+            const int c = (int)(plane - n * a.C);
+            WlDtQuadLoaderScat<T> ld;
+            ld.w2 = a.W / 2;
+            if (!a.combine) {   // dZ (N,7,C,h,w)
+                ld.zl = a.sz + ((size_t)n * 7 * a.C + c) * qplane;
+                ld.zr = ld.zl + (size_t)a.C * qplane;
+                ld.zr_os = (size_t)a.C * qplane;
+            } else {            // dZ (N,3+6,h,w): the six magnitudes are shared by the three colours
+                ld.zl = a.sz + ((size_t)n * 9 + c) * qplane;
+                ld.zr = a.sz + ((size_t)n * 9 + 3) * qplane;
+                ld.zr_os = qplane;
+            }
+            ld.dx = a.sdx + ((size_t)n * 6 * a.C + c) * qplane;
+            ld.dy = a.sdy + ((size_t)n * 6 * a.C + c) * qplane;
+            ld.d_os = (size_t)a.C * qplane;
+            wl_dt_stage_quads<T, NRS / 2, NCS / 2, kThreads>(B, tid, r0 - ME, c0 - ME, a.H, a.W, a.ext, ld);
+        } else {
+            WlDtQuadLoaderPlain<T> ld;
+            ld.llp = a.ll ? a.ll + (size_t)plane * a.ll_plane_stride : nullptr;
+            ld.ll_rs = a.ll_row_stride;
+            ld.hp = a.highs ? a.highs + (size_t)plane * 12 * qplane : nullptr;
+            ld.qplane = qplane; ld.w2 = a.W / 2;
+            wl_dt_stage_quads<T, NRS / 2, NCS / 2, kThreads>(B, tid, r0 - ME, c0 - ME, a.H, a.W, a.ext, ld);
+        }
         ctx.sync();
         float t0[L0], t1[L1];
 #pragma unroll
@@ -537,10 +589,14 @@ struct WlDtInv2Tile {
             tl[tid] = a.g0b[tid]; tl[L + tid] = a.g0a[tid]; tl[2 * L + tid] = a.g1b[tid]; tl[3 * L + tid] = a.g1a[tid];
         }
         const size_t qplane = (size_t)(a.h / 2) * (a.w / 2);
-        wl_dt_stage_quads<T, NRS / 2, NCS / 2, kThreads>(
-            B, tid, R0 / 2 - m2e, C0 / 2 - m2e, a.h, a.w, WL_EXT_SYM,
-            a.ll ? a.ll + (size_t)plane * a.ll_plane_stride : nullptr, a.ll_row_stride,
-            a.highs ? a.highs + (size_t)plane * 12 * qplane : nullptr);
+        {
+            WlDtQuadLoaderPlain<T> ld;
+            ld.llp = a.ll ? a.ll + (size_t)plane * a.ll_plane_stride : nullptr;
+            ld.ll_rs = a.ll_row_stride;
+            ld.hp = a.highs ? a.highs + (size_t)plane * 12 * qplane : nullptr;
+            ld.qplane = qplane; ld.w2 = a.w / 2;
+            wl_dt_stage_quads<T, NRS / 2, NCS / 2, kThreads>(B, tid, R0 / 2 - m2e, C0 / 2 - m2e, a.h, a.w, WL_EXT_SYM, ld);
+        }
         ctx.sync();
         float tp[4][L];   // [0] ha_lp [1] hb_lp [2] ha_hp [3] hb_hp
 #pragma unroll

@@ -218,3 +218,21 @@ def scat_fwd1(x, h0, h1, mode, magbias, combine_colour, save):
                                        1 if combine_colour else 0, _stream(x))
     _lib.check(rc, 'wl_scat_fwd_level1')
     return z, dx, dy
+
+
+def scat_bwd1(dz, drdx, drdy, h0, h1, mode, combine_colour):
+    """ScatLayer backward in one launch: dz (gradient of Z), the saved re/r, im/r -> dx (N,C,He,We) (padded size).
+    Returns None when the engine has no specialised kernel for these taps / dtype (callers compose the prologue
+    and call dtcwt_inv1 instead)."""
+    _check_tensor(dz, 'dz')
+    dz = dz.contiguous()
+    N, _, C, h2, w2 = drdx.shape
+    t0, t1 = _taps(h0, dz), _taps(h1, dz)
+    dx = torch.empty((N, C, 2 * h2, 2 * w2), dtype=dz.dtype, device=dz.device)
+    rc = _backend().wl_scat_bwd_level1(dz.data_ptr(), drdx.data_ptr(), drdy.data_ptr(), dx.data_ptr(), _DTYPES[dz.dtype],
+                                       N, C, 2 * h2, 2 * w2, t0.data_ptr(), t0.numel(), t1.data_ptr(), t1.numel(), mode,
+                                       1 if combine_colour else 0, _stream(dz))
+    if rc == -3:   # WL_ERR_UNSUPPORTED
+        return None
+    _lib.check(rc, 'wl_scat_bwd_level1')
+    return dx

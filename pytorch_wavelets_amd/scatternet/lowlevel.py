@@ -29,15 +29,17 @@ class ScatLayerj1_f(Function):
         dX = None
         if ctx.needs_input_grad[0]:
             h0o, h1o, drdx, drdy = ctx.saved_tensors
-            if ctx.combine_colour:
-                dYl, dr = dZ[:, :3], dZ[:, 3:]
-                dr = dr[:, :, None]
-            else:
-                dYl, dr = dZ[:, 0], dZ[:, 1:]
-            ll = 0.25 * F.interpolate(dYl, scale_factor=2, mode="nearest")
-            # (N,6,C,h,w) real / imag -> default coefficient layout (N,C,6,h,w,2)
-            highs = torch.stack((dr * drdx, dr * drdy), dim=-1).permute(0, 2, 1, 3, 4, 5).contiguous()
-            dX = ops.dtcwt_inv1(ll, highs, h0o, h1o, ctx.mode)
+            dX = ops.scat_bwd1(dZ, drdx, drdy, h0o, h1o, ctx.mode, ctx.combine_colour)   # one fused launch
+            if dX is None:   # no specialised kernel for these taps / dtype: prologue in torch + level-1 inverse
+                if ctx.combine_colour:
+                    dYl, dr = dZ[:, :3], dZ[:, 3:]
+                    dr = dr[:, :, None]
+                else:
+                    dYl, dr = dZ[:, 0], dZ[:, 1:]
+                ll = 0.25 * F.interpolate(dYl, scale_factor=2, mode="nearest")
+                # (N,6,C,h,w) real / imag -> default coefficient layout (N,C,6,h,w,2)
+                highs = torch.stack((dr * drdx, dr * drdy), dim=-1).permute(0, 2, 1, 3, 4, 5).contiguous()
+                dX = ops.dtcwt_inv1(ll, highs, h0o, h1o, ctx.mode)
             H, W = ctx.in_hw
             if dX.shape[2] > H:   # gradient of the edge replication for odd sizes (layers.py:55-59 upstream)
                 dX = torch.cat((dX[:, :, :H - 1], dX[:, :, H - 1:H] + dX[:, :, H:H + 1]), dim=2)

@@ -37,6 +37,33 @@ def test_scatlayer(name):
     D.check_scat_case(name, 'cpu', torch.float64, TOL)
 
 
+@pytest.mark.parametrize('name', SMALL)
+def test_dtcwt_tile_kernels_fp32(name):
+    """float32 data takes the specialised tile kernels (float64 above takes the generic ones)."""
+    D.check_dtcwt_case(name, 'cpu', torch.float32, 1e-5)
+
+
+@pytest.mark.parametrize('name', [n for n in G.cases('scat') if G.INDEX[n]['shape'][-1] <= 64])
+def test_scatlayer_tile_kernels_fp32(name):
+    """... including the fused ScatLayer backward launch (wl_scat_bwd_level1)."""
+    D.check_scat_case(name, 'cpu', torch.float32, 1e-5)
+
+
+def test_scat_backward_fused_equals_composed(monkeypatch):
+    """The one-launch backward against prologue-in-torch + level-1 inverse (the fallback for other taps)."""
+    grads = {}
+    for generic in ('0', '1'):
+        monkeypatch.setenv('WL_GENERIC_ONLY', generic)
+        for comb in (False, True):
+            torch.manual_seed(3)
+            x = torch.randn(2, 3, 33, 30, dtype=torch.float32, requires_grad=True)
+            z = pw.ScatLayer(biort='near_sym_b', combine_colour=comb)(x)
+            dx, = torch.autograd.grad((z * torch.randn_like(z)).sum(), x)
+            grads[generic, comb] = dx
+    for comb in (False, True):
+        assert float((grads['0', comb] - grads['1', comb]).abs().max()) < 1e-5 * float(grads['1', comb].abs().max())
+
+
 def test_layout_permutations():
     D.check_layouts('cpu', torch.float64, 1e-9)
 
