@@ -15,14 +15,14 @@
 
 // ---------------------------------------------------------------------------------------------------------
 // level 1 forward (+ ScatLayer epilogue): fwd_j1, reference dtcwt/transform_funcs.py:98-121 and
-// scatternet/lowlevel.py:86-109.  One workgroup = one TH x TW tile of the (padded-to-even) full-res plane.
+// scatternet/lowlevel.py:86-109.  One workgroup = one TH x TW (32 x 32: best of the measured shapes) tile of the (padded-to-even) full-res plane.
 //   stage : (TH+2M) x SP input cells, origin (r0-M, c0-MA) with MA = M rounded up to even so that interior
 //           lanes read aligned pairs;
 //   row   : item = (staged row, 4 output columns): NV ds_read_b128 -> 4 x (lo, hi) -> 2 ds_write_b128;
 //   column: item = one 2x2 quad: 2+2M ds_read_b128 of (lo,hi,lo,hi), packed FMAs ((ll,hl) and (lh,hh) pairs), all
 //           four bands in registers, q2c + stores through wl_dtfwd1_quad_out.
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, int L0, int L1, int COMB = 0, int TH_ = 32, int TW_ = 64>
+template <typename T, int L0, int L1, int COMB = 0, int TH_ = 32, int TW_ = 32>
 struct WlDtFwd1Tile {
     typedef WlDtFwd1Args<T> Args;
     static const int kThreads = 256;
@@ -427,7 +427,7 @@ WL_DEV void wl_dt_stage_quads(wl_f4* B, int tid, int pr_org, int pc_org, int h, 
 //   column: item = (staged column, 4 output rows): 4+2M ds_read_b128 -> 4 x (lo,hi) -> ds_write_b64;
 //   row   : item = (row, 4 output columns): ds_read_b128 of (lo,hi) pairs -> 16 contiguous bytes of y per lane.
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, int L0, int L1, int SCAT = 0, int TH_ = 16, int TW_ = 64>   // SCAT: fused ScatLayer backward
+template <typename T, int L0, int L1, int SCAT = 0, int TH_ = 16, int TW_ = 32>   // SCAT: fused ScatLayer backward
 struct WlDtInv1Tile {
     typedef WlDtInv1Args<T> Args;
     static const int kThreads = 256;
