@@ -85,3 +85,42 @@ def test_api_contract():
     yl, yh = pw.DTCWTForward(J=2, skip_hps=[True, False])(x)
     assert yh[0].shape == torch.Size([]) and yh[1].shape == (1, 2, 6, 4, 4, 2)
     assert pw.DTCWT is pw.DTCWTForward and pw.IDTCWT is pw.DTCWTInverse
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_specialised_equals_generic_on_random_shapes(seed, monkeypatch):
+    """Property test: the compile-time specialised kernels (float32) and the generic runtime-L kernels must agree on
+    shapes around the tile / halo / padding boundaries, for every filter table of the reference."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    biort = ['near_sym_a', 'near_sym_b', 'antonini', 'legall'][seed % 4]
+    qshift = ['qshift_a', 'qshift_b', 'qshift_c', 'qshift_d', 'qshift_06'][seed % 5]
+    for _ in range(4):
+        H, W = int(rng.randint(2, 80)), int(rng.randint(2, 150))
+        J = int(rng.randint(1, 4))
+        x = torch.tensor(rng.randn(1, 2, H, W), dtype=torch.float32)
+        out = {}
+        for generic in ('0', '1'):
+            monkeypatch.setenv('WL_GENERIC_ONLY', generic)
+            xfm = pw.DTCWTForward(biort=biort, qshift=qshift, J=J)
+            ifm = pw.DTCWTInverse(biort=biort, qshift=qshift)
+            yl, yh = xfm(x)
+            out[generic] = [yl] + list(yh) + [ifm((yl, yh))]
+        for a, b in zip(out['0'], out['1']):
+            assert a.shape == b.shape
+            scale = float(b.abs().max()) + 1e-30
+            assert float((a - b).abs().max()) <= 2e-5 * scale, (biort, qshift, H, W, J)
+
+
+def test_dtcwt_half_precision_tile_kernels():
+    torch.manual_seed(5)
+    x = torch.randn(1, 2, 40, 56, dtype=torch.float32)
+    ref_yl, ref_yh = pw.DTCWTForward(J=2)(x)
+    xh = x.half()
+    yl, yh = pw.DTCWTForward(J=2).half()(xh)
+    assert yl.dtype == torch.float16
+    assert float((yl.float() - ref_yl).abs().max()) < 4e-3 * float(ref_yl.abs().max())
+    for a, b in zip(yh, ref_yh):
+        assert float((a.float() - b).abs().max()) < 4e-3 * float(b.abs().max())
+    rec = pw.DTCWTInverse().half()((yl, yh))
+    assert float((rec.float() - x).abs().max()) < 1e-2 * float(x.abs().max())
