@@ -42,6 +42,7 @@ struct WlDtFwd1Args {
     int C, H, W, He, We;
     int L0, L1, M, ext;   // M = max(L0,L1)/2
     int TH, TW, tiles_x, tiles_y;
+    int run_len, runs_x;   // specialised kernel: tiles per workgroup along x, ceil(tiles_x / run_len)
     int combine;     // ScatLayer combine_colour (C == 3)
     A magbias;
 };

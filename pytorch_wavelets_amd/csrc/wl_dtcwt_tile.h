@@ -15,14 +15,14 @@
 
 // ---------------------------------------------------------------------------------------------------------
 // level 1 forward (+ ScatLayer epilogue): fwd_j1, reference dtcwt/transform_funcs.py:98-121 and
-// scatternet/lowlevel.py:86-109.  One workgroup = one TH x TW (32 x 32: best of the measured shapes) tile of the (padded-to-even) full-res plane.
+// scatternet/lowlevel.py:86-109.  One workgroup walks a horizontal run of TH x TW (32 x 64) tiles of the (padded-to-even) full-res plane.
 //   stage : (TH+2M) x SP input cells, origin (r0-M, c0-MA) with MA = M rounded up to even so that interior
 //           lanes read aligned pairs;
 //   row   : item = (staged row, 4 output columns): NV ds_read_b128 -> 4 x (lo, hi) -> 2 ds_write_b128;
 //   column: item = one 2x2 quad: 2+2M ds_read_b128 of (lo,hi,lo,hi), packed FMAs ((ll,hl) and (lh,hh) pairs), all
 //           four bands in registers, q2c + stores through wl_dtfwd1_quad_out.
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, int L0, int L1, int COMB = 0, int TH_ = 32, int TW_ = 32>
+template <typename T, int L0, int L1, int COMB = 0, int TH_ = 32, int TW_ = 64>
 struct WlDtFwd1Tile {
     typedef WlDtFwd1Args<T> Args;
     static const int kThreads = 256;
@@ -44,64 +44,80 @@ struct WlDtFwd1Tile {
 
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
         const int tid = ctx.tid;
-        const int tiles = a.tiles_x * a.tiles_y;
-        const int64_t unit = ctx.bid / tiles;            // plane, or image when combining colour
-        const int tile = (int)(ctx.bid - unit * tiles);
-        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-        const int r0 = ty * TH, c0 = tx * TW;
+        // A workgroup walks a horizontal run of tiles (x colour planes when combining colour); the loads of step
+        // s+1 are in registers while step s is computed and are committed to LDS between its two passes, the loads
+        // of step s+2 are issued right after (same software pipeline as the DWT analysis kernel, wl_dwt_tile.h).
+        const int per_unit = a.tiles_y * a.runs_x;
+        const int64_t unit = ctx.bid / per_unit;         // plane, or image when combining colour
+        const int rem = (int)(ctx.bid - unit * per_unit);
+        const int ty = rem / a.runs_x, rx = rem - ty * a.runs_x;
+        const int tx_begin = rx * a.run_len;
+        const int tx_end = tx_begin + a.run_len < a.tiles_x ? tx_begin + a.run_len : a.tiles_x;
+        const int r0 = ty * TH;
         float* lds = reinterpret_cast<float*>(ctx.smem);
         float* tl = lds;
         float* S = lds + kTapFloats;
         float* Tm = S + NR * SP;
         if (tid < L0) tl[tid] = a.h0[tid];
         if (tid < L1) tl[L0 + tid] = a.h1[tid];
-        // ---- staging geometry: resolved once per workgroup ---------------------------------------------------
+        // ---- staging geometry: rows resolved once per workgroup, columns once per tile ------------------------
         const int s_row = tid / NP, p_own = tid - s_row * NP;
         const bool lane_on = s_row < RPI;
         const int padr = a.He - a.H, padc = a.We - a.W;
-        const int cs0 = lane_on ? wl_ext_padded(c0 - MA + 2 * p_own, a.W, 0, padc, a.ext) : -1;
-        const int cs1 = lane_on ? wl_ext_padded(c0 - MA + 2 * p_own + 1, a.W, 0, padc, a.ext) : -1;
         const bool vec_ok = (a.W % 2 == 0) && ((uintptr_t)a.x % (2 * sizeof(T)) == 0);
-        const bool pair_ld = vec_ok && cs0 >= 0 && cs1 == cs0 + 1 && (cs0 & 1) == 0;
-        int rsrc[NIT];
+        int roff[NIT];   // element offset of the source row inside a plane, or -1
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = it * RPI + s_row;
-            rsrc[it] = (lane_on && i < NR) ? wl_ext_padded(r0 - M + i, a.H, 0, padr, a.ext) : -1;
+            const int r = (lane_on && i < NR) ? wl_ext_padded(r0 - M + i, a.H, 0, padr, a.ext) : -1;
+            roff[it] = r < 0 ? -1 : r * a.W;
         }
-        const int nch = COMB ? 3 : 1;
-        float msum[COMB ? NQI : 1][6];
-        for (int ch = 0; ch < nch; ++ch) {
-            const int64_t plane = COMB ? unit * 3 + ch : unit;
-            const T* xp = a.x + (size_t)plane * a.H * a.W;
-            // ---- stage: all loads first, then the LDS writes ------------------------------------------------------
-            {
-                Pair2 pf[NIT];
+        constexpr int nch = COMB ? 3 : 1;
+        const int nsteps = (tx_end - tx_begin) * nch;    // step = (tile column, colour plane)
+        Pair2 pf[NIT];
+        auto issue = [&](int step) {
+            const int tx = tx_begin + step / nch, ch = step - (step / nch) * nch;
+            const T* xp = a.x + (size_t)(COMB ? unit * 3 + ch : unit) * a.H * a.W;
+            const int c0 = tx * TW;
+            const int cs0 = lane_on ? wl_ext_padded(c0 - MA + 2 * p_own, a.W, 0, padc, a.ext) : -1;
+            const int cs1 = lane_on ? wl_ext_padded(c0 - MA + 2 * p_own + 1, a.W, 0, padc, a.ext) : -1;
+            const bool pair_ld = vec_ok && cs0 >= 0 && cs1 == cs0 + 1 && (cs0 & 1) == 0;
+            const int cpair = pair_ld ? cs0 : -1;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                pf[it] = Pair2{(T)0, (T)0};
+                if ((cpair | roff[it]) >= 0) pf[it] = *reinterpret_cast<const Pair2*>(xp + (unsigned)(roff[it] + cpair));
+            }
+            if (lane_on && !pair_ld) {   // border lanes (mirrored / replicated / odd widths): element loads
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
-                    pf[it] = Pair2{(T)0, (T)0};
-                    const int r = rsrc[it];
-                    if (r >= 0) {
-                        const T* src = xp + r * a.W;
-                        if (pair_ld) pf[it] = *reinterpret_cast<const Pair2*>(src + cs0);
-                        else {
-                            if (cs0 >= 0) pf[it].x = src[cs0];
-                            if (cs1 >= 0) pf[it].y = src[cs1];
-                        }
-                    }
-                }
-                if (lane_on) {
-                    float* d = S + s_row * SP + 2 * p_own;
-#pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
-                        if (it * RPI + s_row < NR) {
-                            wl_f2 w; w.x = (float)pf[it].x; w.y = (float)pf[it].y;
-                            *reinterpret_cast<wl_f2*>(d + it * RPI * SP) = w;
-                        }
+                    if (roff[it] >= 0) {
+                        if (cs0 >= 0) pf[it].x = xp[(unsigned)(roff[it] + cs0)];
+                        if (cs1 >= 0) pf[it].y = xp[(unsigned)(roff[it] + cs1)];
                     }
                 }
             }
-            ctx.sync();
+        };
+        auto commit = [&]() {
+            if (!lane_on) return;
+            float* d = S + s_row * SP + 2 * p_own;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (it * RPI + s_row < NR) {
+                    wl_f2 w; w.x = (float)pf[it].x; w.y = (float)pf[it].y;
+                    *reinterpret_cast<wl_f2*>(d + it * RPI * SP) = w;
+                }
+            }
+        };
+        float msum[COMB ? NQI : 1][6];
+        issue(0);
+        commit();
+        ctx.sync();
+        if (1 < nsteps) issue(1);
+        for (int step = 0; step < nsteps; ++step) {
+            const int tx = tx_begin + step / nch, ch = step - (step / nch) * nch;
+            const int64_t plane = COMB ? unit * 3 + ch : unit;
+            const int c0 = tx * TW;
             // ---- row bank: lo[j] = sum h0[t] s[j+MA-M0+t], hi[j] = sum h1[t] s[j+MA-M1+t] -----------------------
             {
                 float t0[L0], t1[L1];
@@ -134,6 +150,10 @@ struct WlDtFwd1Tile {
                 }
             }
             ctx.sync();
+            if (step + 1 < nsteps) {
+                commit();                                  // step+1 -> S (the row bank above was its last reader)
+                if (step + 2 < nsteps) issue(step + 2);
+            }
             // ---- column bank + q2c + stores -----------------------------------------------------------------------
             {
                 float t0[L0], t1[L1];
@@ -175,7 +195,7 @@ struct WlDtFwd1Tile {
                     wl_dtfwd1_quad_out<T, COMB>(a, plane, ch, R, Cc, ll, lh, hl, hh, msum[COMB ? qi : 0]);
                 }
             }
-            // (the barrier after the next colour plane's staging orders this column bank before its row bank)
+            ctx.sync();   // S(step+1) visible; Tm free for the next row bank
         }
     }
 };
