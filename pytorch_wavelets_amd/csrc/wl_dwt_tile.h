@@ -7,7 +7,8 @@
 //           k=2q,2q+1 from v_pk_fma_f32 with the sample broadcast, one ds_write_b128;
 //   column: item = (out row, q): L ds_read_b128 = (lo,hi) of columns 2q,2q+1, 4 packed FMAs per tap; every
 //           band row leaves as 8 contiguous bytes per lane (512 B per wave) straight into yl / yh[j].
-// A workgroup walks a horizontal run of tiles; the 8-byte loads of tile t+1 are issued into registers before
+// A workgroup walks a horizontal run of tiles (the last tile of a row absorbs a remainder of up to XT columns: a
+// band is (W+L-2)/2 wide, e.g. 259 = 4 x 64 + 3, and a 3-column tile would cost a whole pipeline step); the 8-byte loads of tile t+1 are issued into registers before
 // tile t's row bank starts, so ~20 KB per workgroup (four workgroups per CU, ~40 KB LDS each) are in flight
 // during all arithmetic.  Boundary extension costs nothing on the hot path: each lane resolves the source
 // columns of its two cells once per workgroup, out-of-range ROWS are just other source rows (or zeros).
@@ -49,9 +50,11 @@ struct WlAfbTile {
     static const int SH = SH_;                           // 1: odd `base` (periodization) - the staged origin is moved one
                                                          //    column left so that lanes still read aligned pairs
     static const int NV = (LT + 2 + SH + 3) / 4;         // float4 reads per row item
-    static const int NQ = TW / 2;                        // k-pairs per tile row
-    static const int SP = 4 * (NQ - 1) + 4 * NV;         // staged row pitch (floats, multiple of 4, >= NCOLS)
-    static const int TP = 2 * TW;                        // (lo,hi) row pitch in floats
+    static const int NQ = TW / 2;                        // k-pairs per regular tile row
+    static const int XT = 8;                             // the LAST tile of a row may be up to XT columns wider, so
+    static const int NQX = XT / 2;                       //   the L/2-1 excess columns of a band do not cost a tile
+    static const int SP = 4 * (NQ + NQX - 1) + 4 * NV;   // staged row pitch (floats, multiple of 4)
+    static const int TP = 2 * (TW + XT);                 // (lo,hi) row pitch in floats
     static const int kTapFloats = 4 * LT;
     static const int kLdsFloats = kTapFloats + NROWS * SP + NROWS * TP;
     typedef T Pair2 __attribute__((ext_vector_type(2)));
@@ -102,7 +105,7 @@ struct WlAfbTile {
         auto issue = [&](int tx) {
             const int kw0 = tx * TW;
             const int ec0 = 2 * kw0 + a.base - SH;
-            const int ncols_out = (a.Kw - kw0) < TW ? (a.Kw - kw0) : TW;
+            const int ncols_out = tx == a.tiles_x - 1 ? a.Kw - kw0 : TW;
             const int nq = (ncols_out + 1) / 2;
             const int np_need = nq * 2 + NV * 2 - 2 < NP ? nq * 2 + NV * 2 - 2 : NP;   // staged pairs per row
             const bool lane_on = s_row < RPI && p_own < np_need;
@@ -147,7 +150,7 @@ struct WlAfbTile {
         for (int tx = tx_begin; tx < tx_end; ++tx) {
             const int kw0 = tx * TW;
             {
-                const int ncols_out = (a.Kw - kw0) < TW ? (a.Kw - kw0) : TW;
+                const int ncols_out = tx == a.tiles_x - 1 ? a.Kw - kw0 : TW;
                 nq_need = (ncols_out + 1) / 2;
             }
         // ---- row bank -----------------------------------------------------------------------------------------
@@ -155,9 +158,7 @@ struct WlAfbTile {
             wl_v2 tw[LT];
 #pragma unroll
             for (int j = 0; j < LT; ++j) { tw[j].x = tl[2 * j]; tw[j].y = tl[2 * j + 1]; }
-            _Pragma("nounroll") for (int f = tid; f < ((a.ablate & 4) ? 0 : nr_need * NQ); f += kThreads) {
-                const int i = f / NQ, q = f - i * NQ;
-                if (q >= nq_need) continue;
+            auto row_item = [&](int i, int q) {
                 float v[NV * 4];
                 const wl_f4* s4 = reinterpret_cast<const wl_f4*>(S + i * SP) + q;
 #pragma unroll
@@ -174,6 +175,16 @@ struct WlAfbTile {
                 wl_f4 o;
                 o.x = a0.x; o.y = a0.y; o.z = a1.x; o.w = a1.y;
                 reinterpret_cast<wl_f4*>(Tm + i * TP)[q] = o;
+            };
+            _Pragma("nounroll") for (int f = tid; f < ((a.ablate & 4) ? 0 : nr_need * NQ); f += kThreads) {
+                const int i = f / NQ, q = f - i * NQ;
+                if (q < nq_need) row_item(i, q);
+            }
+            if (nq_need > NQ) {   // the wider last tile: pairs NQ .. nq_need-1
+                _Pragma("nounroll") for (int f = tid; f < nr_need * NQX; f += kThreads) {
+                    const int i = f / NQX, q = NQ + (f - i * NQX);
+                    if (q < nq_need) row_item(i, q);
+                }
             }
         }
         ctx.sync();
@@ -189,10 +200,9 @@ struct WlAfbTile {
             const unsigned bplane = (unsigned)a.Kh * (unsigned)a.Kw;
             T* llp = a.ll + (size_t)plane * bplane;
             T* hp = a.highs + (size_t)plane * 3 * bplane;
-            _Pragma("nounroll") for (int f = tid; f < ((a.ablate & 8) ? 0 : TH * NQ); f += kThreads) {
-                const int kh = f / NQ, q = f - kh * NQ;
+            auto col_item = [&](int kh, int q) {
                 const int k = kh0 + kh, kw = kw0 + 2 * q;
-                if (k >= a.Kh || kw >= a.Kw) continue;
+                if (k >= a.Kh || kw >= a.Kw) return;
                 wl_v2 cl0 = {0.f, 0.f}, ch0 = {0.f, 0.f}, cl1 = {0.f, 0.f}, ch1 = {0.f, 0.f};
                 const float* col = Tm + (2 * kh) * TP + 4 * q;
 #pragma unroll
@@ -202,7 +212,7 @@ struct WlAfbTile {
                     cl1 += th[j] * p.z; ch1 += th[j] * p.w;
                 }
                 const unsigned o = (unsigned)k * (unsigned)a.Kw + (unsigned)kw;
-                if ((a.ablate & 1) && cl0.x != 12345.f) continue;
+                if ((a.ablate & 1) && cl0.x != 12345.f) return;
                 if (kw + 1 < a.Kw) {
                     Pair p0, p1, p2, p3;
                     p0.a = (T)cl0.x; p0.b = (T)cl1.x;   // LL
@@ -218,6 +228,16 @@ struct WlAfbTile {
                     hp[o] = (T)cl0.y;
                     hp[bplane + o] = (T)ch0.x;
                     hp[2 * bplane + o] = (T)ch0.y;
+                }
+            };
+            _Pragma("nounroll") for (int f = tid; f < ((a.ablate & 8) ? 0 : TH * NQ); f += kThreads) {
+                const int kh = f / NQ;
+                col_item(kh, f - kh * NQ);
+            }
+            if (nq_need > NQ) {
+                _Pragma("nounroll") for (int f = tid; f < TH * NQX; f += kThreads) {
+                    const int kh = f / NQX;
+                    col_item(kh, NQ + (f - kh * NQX));
                 }
             }
         }
