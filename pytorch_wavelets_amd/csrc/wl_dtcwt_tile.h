@@ -580,7 +580,7 @@ struct WlIfiltMap {   // compile-time (e, o) of output phase s
     }
 };
 
-template <typename T, int L, int TH_ = 32, int TW_ = 64>
+template <typename T, int L, int TH_ = 16, int TW_ = 64>
 struct WlDtInv2Tile {
     typedef WlDtInv2Args<T> Args;
     static const int kThreads = 256;
