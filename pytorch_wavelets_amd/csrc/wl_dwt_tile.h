@@ -51,8 +51,14 @@ struct WlAfbTile {
                                                          //    column left so that lanes still read aligned pairs
     static const int NV = (LT + 2 + SH + 3) / 4;         // float4 reads per row item
     static const int NQ = TW / 2;                        // k-pairs per regular tile row
-    static const int XT = 8;                             // the LAST tile of a row may be up to XT columns wider, so
-    static const int NQX = XT / 2;                       //   the L/2-1 excess columns of a band do not cost a tile
+    // the LAST tile of a row may be up to XT columns wider, so the L/2-1 excess columns of a band do not cost a
+    // tile - unless the wider LDS rows would push the kernel from three to two workgroups per CU (long filters)
+    static constexpr int lds_bytes(int xt) {
+        return 4 * (4 * LT + NROWS * (4 * (TW / 2 + xt / 2 - 1) + 4 * NV) + NROWS * 2 * (TW + xt));
+    }
+    static const int XT = lds_bytes(8) <= 160 * 1024 / 3 ? 8 : 0;
+    static const int NQX = XT / 2;
+    static const int NQXD = NQX > 0 ? NQX : 1;           // divisor for the extra-pair loops (dead when XT == 0)
     static const int SP = 4 * (NQ + NQX - 1) + 4 * NV;   // staged row pitch (floats, multiple of 4)
     static const int TP = 2 * (TW + XT);                 // (lo,hi) row pitch in floats
     static const int kTapFloats = 4 * LT;
@@ -180,9 +186,9 @@ struct WlAfbTile {
                 const int i = f / NQ, q = f - i * NQ;
                 if (q < nq_need) row_item(i, q);
             }
-            if (nq_need > NQ) {   // the wider last tile: pairs NQ .. nq_need-1
+            if (NQX > 0 && nq_need > NQ) {   // the wider last tile: pairs NQ .. nq_need-1
                 _Pragma("nounroll") for (int f = tid; f < nr_need * NQX; f += kThreads) {
-                    const int i = f / NQX, q = NQ + (f - i * NQX);
+                    const int i = f / NQXD, q = NQ + (f - i * NQXD);
                     if (q < nq_need) row_item(i, q);
                 }
             }
@@ -234,10 +240,10 @@ struct WlAfbTile {
                 const int kh = f / NQ;
                 col_item(kh, f - kh * NQ);
             }
-            if (nq_need > NQ) {
+            if (NQX > 0 && nq_need > NQ) {
                 _Pragma("nounroll") for (int f = tid; f < TH * NQX; f += kThreads) {
-                    const int kh = f / NQX;
-                    col_item(kh, NQ + (f - kh * NQX));
+                    const int kh = f / NQXD;
+                    col_item(kh, NQ + (f - kh * NQXD));
                 }
             }
         }
