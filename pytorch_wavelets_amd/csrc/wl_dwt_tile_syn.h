@@ -91,7 +91,10 @@ struct WlSfbTile {
                 if (f < NKR * NKC) {
                     const int i = f / NKC, j = f - i * NKC;
                     int r = kr0 + i, c = kc0 + j;
-                    if (a.circ) { r = wl_pmod(r, a.Kh); c = wl_pmod(c, a.Kw); }
+                    if (a.circ) {   // wrap only the out-of-range (border) cells: the modulo is slow
+                        if ((unsigned)r >= (unsigned)a.Kh) r = wl_pmod(r, a.Kh);
+                        if ((unsigned)c >= (unsigned)a.Kw) c = wl_pmod(c, a.Kw);
+                    }
                     if ((unsigned)r < (unsigned)a.Kh && (unsigned)c < (unsigned)a.Kw) {
                         v[it][0] = (float)llp[(unsigned)(r * a.ll_row_stride + c)];
                         if (hp) {
