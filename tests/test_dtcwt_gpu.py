@@ -72,3 +72,32 @@ def test_full_size_properties_config2_and_3():
     assert Z.shape == (32, 21, 128, 128)
     oZ = wo.scat_layer_forward(xs[5:6].cpu().double().numpy(), hb[0], hb[1])
     assert np.abs(Z[5:6].cpu().numpy() - oZ).max() / np.abs(oZ).max() < TOL
+
+
+@pytest.mark.parametrize('seed', range(5))
+def test_specialised_equals_generic_random_shapes_gpu(seed, monkeypatch):
+    """Specialised DTCWT / ScatLayer kernels against the generic ones on the real hardware, random shapes."""
+    import numpy as np
+    rng = np.random.RandomState(500 + seed)
+    biort = ['near_sym_a', 'near_sym_b', 'antonini', 'legall', 'near_sym_a'][seed]
+    qshift = ['qshift_a', 'qshift_b', 'qshift_c', 'qshift_d', 'qshift_06'][seed]
+    for _ in range(3):
+        H, W = int(rng.randint(8, 300)), int(rng.randint(8, 500))
+        J = int(rng.randint(1, 4))
+        x = torch.tensor(rng.randn(2, 3, H, W), dtype=torch.float32, device=DEV)
+        out = {}
+        for generic in ('0', '1'):
+            monkeypatch.setenv('WL_GENERIC_ONLY', generic)
+            xfm = pw.DTCWTForward(biort=biort, qshift=qshift, J=J).to(DEV)
+            ifm = pw.DTCWTInverse(biort=biort, qshift=qshift).to(DEV)
+            yl, yh = xfm(x)
+            res = [yl] + list(yh) + [ifm((yl, yh))]
+            if biort in ('near_sym_a', 'near_sym_b'):
+                xs = x.clone().requires_grad_(True)
+                z = pw.ScatLayer(biort=biort).to(DEV)(xs)
+                g, = torch.autograd.grad((z * z).sum(), xs)
+                res += [z.detach(), g]
+            out[generic] = res
+        for a, b in zip(out['0'], out['1']):
+            assert a.shape == b.shape
+            assert float((a - b).abs().max()) <= 3e-5 * (float(b.abs().max()) + 1e-30), (biort, qshift, H, W, J)

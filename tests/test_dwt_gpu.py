@@ -199,3 +199,30 @@ def test_function_level_api():
     ll, lh, hl, hh = y.reshape(1, 2, 4, 17, 21).unbind(2)
     xr = lowlevel.sfb2d(ll, lh, hl, hh, (w.rec_lo, w.rec_hi), mode='symmetric')
     assert float((xr - x).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_tile_equals_generic_random_shapes_gpu(seed, monkeypatch):
+    """On the real hardware (barriers, vmcnt ordering, unaligned accesses are only real here): the specialised
+    kernels against the generic ones on random shapes, every mode, several tiles/runs per plane, fp32 and fp16."""
+    import numpy as np
+    rng = np.random.RandomState(300 + seed)
+    wave = ['db4', 'haar', 'db3', 'db8', 'sym4', 'db5'][seed]
+    for mode in ('zero', 'symmetric', 'reflect', 'periodic', 'periodization'):
+        H, W = int(rng.randint(20, 400)), int(rng.randint(20, 700))
+        J = int(rng.randint(1, 4))
+        x = torch.tensor(rng.randn(3, 5, H, W), dtype=torch.float32, device=DEV)
+        out = {}
+        for generic in ('0', '1'):
+            monkeypatch.setenv('WL_GENERIC_ONLY', generic)
+            xfm = pw.DWTForward(J=J, wave=wave, mode=mode).to(DEV)
+            ifm = pw.DWTInverse(wave=wave, mode=mode).to(DEV)
+            yl, yh = xfm(x)
+            out[generic] = [yl] + list(yh) + [ifm((yl, yh))]
+        for a, b in zip(out['0'], out['1']):
+            assert a.shape == b.shape
+            assert float((a - b).abs().max()) <= 2e-5 * (float(b.abs().max()) + 1e-30), (wave, mode, H, W, J)
+        monkeypatch.setenv('WL_GENERIC_ONLY', '0')
+        xh = x.half()
+        yl, yh = pw.DWTForward(J=J, wave=wave, mode=mode).to(DEV).half()(xh)
+        assert float((yl.float() - out['1'][0]).abs().max()) <= 1e-2 * float(out['1'][0].abs().max())
