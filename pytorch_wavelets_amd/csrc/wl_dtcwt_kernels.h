@@ -42,6 +42,7 @@ struct WlDtFwd1Args {
     int C, H, W, He, We;
     int L0, L1, M, ext;   // M = max(L0,L1)/2
     int TH, TW, tiles_x, tiles_y;
+    int64_t nblocks;       // specialised kernels: grid size for the XCD-aware block remap (0 = off)
     int run_len, runs_x;   // specialised kernel: tiles per workgroup along x, ceil(tiles_x / run_len)
     int combine;     // ScatLayer combine_colour (C == 3)
     A magbias;
@@ -232,6 +233,7 @@ struct WlDtFwd2Args {
     int H, W, He, We, padr, padc;   // virtual size (multiple of 4) and replicate pad (0/1) on both sides
     int L;
     int TH, TW, tiles_x, tiles_y;   // output (half-res) tile, multiples of 4
+    int64_t nblocks;                // specialised kernel: grid size for the XCD-aware block remap (0 = off)
 };
 
 template <typename T>
@@ -360,6 +362,7 @@ struct WlDtInv1Args {
     int ll_row_stride;
     int H, W, L0, L1, M, ext;
     int TH, TW, tiles_x, tiles_y;
+    int64_t nblocks;       // specialised kernel: grid size for the XCD-aware block remap (0 = off)
     // fused ScatLayer backward (specialised kernel only): dZ, re/r, im/r instead of ll / highs
     const T* sz; const T* sdx; const T* sdy;
     int C, combine;
@@ -463,6 +466,7 @@ struct WlDtInv2Args {
     int ll_row_stride;
     int h, w, L;
     int TH, TW, tiles_x, tiles_y;   // output tile, multiples of 4
+    int64_t nblocks;                // specialised kernel: grid size for the XCD-aware block remap (0 = off)
 };
 
 template <typename T>

@@ -48,8 +48,9 @@ struct WlDtFwd1Tile {
         // s+1 are in registers while step s is computed and are committed to LDS between its two passes, the loads
         // of step s+2 are issued right after (same software pipeline as the DWT analysis kernel, wl_dwt_tile.h).
         const int per_unit = a.tiles_y * a.runs_x;
-        const int64_t unit = ctx.bid / per_unit;         // plane, or image when combining colour
-        const int rem = (int)(ctx.bid - unit * per_unit);
+        const int64_t lbid = wl_xcd_remap(ctx.bid, a.nblocks);
+        const int64_t unit = lbid / per_unit;            // plane, or image when combining colour
+        const int rem = (int)(lbid - unit * per_unit);
         const int ty = rem / a.runs_x, rx = rem - ty * a.runs_x;
         const int tx_begin = rx * a.run_len;
         const int tx_end = tx_begin + a.run_len < a.tiles_x ? tx_begin + a.run_len : a.tiles_x;
@@ -231,8 +232,9 @@ struct WlDtFwd2Tile {
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
         const int tid = ctx.tid;
         const int tiles = a.tiles_x * a.tiles_y;
-        const int64_t plane = ctx.bid / tiles;
-        const int tile = (int)(ctx.bid - plane * tiles);
+        const int64_t lbid = wl_xcd_remap(ctx.bid, a.nblocks);   // neighbouring tiles share their halo in one L2
+        const int64_t plane = lbid / tiles;
+        const int tile = (int)(lbid - plane * tiles);
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const int r0 = ty * THO, c0 = tx * TWO;          // half-res output origin
         float* lds = reinterpret_cast<float*>(ctx.smem);
@@ -463,8 +465,9 @@ struct WlDtInv1Tile {
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
         const int tid = ctx.tid;
         const int tiles = a.tiles_x * a.tiles_y;
-        const int64_t plane = ctx.bid / tiles;
-        const int tile = (int)(ctx.bid - plane * tiles);
+        const int64_t lbid = wl_xcd_remap(ctx.bid, a.nblocks);   // neighbouring tiles share their halo in one L2
+        const int64_t plane = lbid / tiles;
+        const int tile = (int)(lbid - plane * tiles);
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const int r0 = ty * TH, c0 = tx * TW;
         float* lds = reinterpret_cast<float*>(ctx.smem);
@@ -597,8 +600,9 @@ struct WlDtInv2Tile {
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
         const int tid = ctx.tid;
         const int tiles = a.tiles_x * a.tiles_y;
-        const int64_t plane = ctx.bid / tiles;
-        const int tile = (int)(ctx.bid - plane * tiles);
+        const int64_t lbid = wl_xcd_remap(ctx.bid, a.nblocks);   // neighbouring tiles share their halo in one L2
+        const int64_t plane = lbid / tiles;
+        const int tile = (int)(lbid - plane * tiles);
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const int R0 = ty * TH, C0 = tx * TW;
         float* lds = reinterpret_cast<float*>(ctx.smem);
