@@ -80,6 +80,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=128, help='images per GPU (BASELINE configs[1]: 128)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the DTCWT / ScatLayer / fp16 context timings')
     args = ap.parse_args()
 
     import __graft_entry__ as ge
@@ -179,6 +180,44 @@ def main():
         torch.cuda.synchronize()
         copy_gbs = 2 * x.numel() * 4 / (e0.elapsed_time(e1) / args.steps * 1e-3) / 1e9
         del cdst
+    # the other BASELINE configs (parity-test cases, not the metric): timed once on rank 0 at N=1 as context
+    other = None
+    if world == 1 and not args.no_other_configs:
+        other = {}
+
+        def timed(fn, n=10):
+            fn()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n
+        with torch.no_grad():
+            xd = torch.randn(64, 3, 512, 512, device=dev)
+            dx, di = pw.DTCWTForward(J=3).to(dev), pw.DTCWTInverse().to(dev)
+            dyl, dyh = dx(xd)
+            tf, ti = timed(lambda: dx(xd)), timed(lambda: di((dyl, dyh)))
+            other['dtcwt_j3_near_sym_a_qshift_a_64x3x512x512_fp32'] = {
+                'fwd_ms': round(tf, 4), 'inv_ms': round(ti, 4), 'fwd_inv_mpix_s': round(xd.numel() / (tf + ti) / 1e3, 1),
+                'fwd_frac_of_hbm_peak_at_20B_per_px': round(20 * xd.numel() / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            del xd, dyl, dyh
+            xs = torch.randn(256, 3, 256, 256, device=dev)
+            sl = pw.ScatLayer().to(dev)
+            ts = timed(lambda: sl(xs))
+            other['scatlayer_256x3x256x256_fp32_one_gpu'] = {
+                'fwd_ms': round(ts, 4), 'mpix_s': round(xs.numel() / ts / 1e3, 1),
+                'frac_of_hbm_peak_at_11B_per_px': round(11 * xs.numel() / (ts * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            del xs
+            xh = torch.randn(8, 16, 2048, 2048, device=dev).half()
+            hx = pw.DWTForward(J=4, wave='db8', mode='periodization').to(dev).half()
+            th = timed(lambda: hx(xh), 5)
+            other['dwt_j4_db8_periodization_8x16x2048x2048_fp16'] = {
+                'fwd_ms': round(th, 4), 'mpix_s': round(xh.numel() / th / 1e3, 1),
+                'frac_of_hbm_peak_at_4B_per_px': round(4 * xh.numel() / (th * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                'note': 'batch reduced from 32 to 8 images of 16 channels'}
+            del xh
     info = pw.engine_info(xfm, x)
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
@@ -217,6 +256,8 @@ def main():
             'inv_mpix_s': round(N * C * H * W / (inv_ms * 1e-3) / 1e6, 1),
             'roundtrip_rel_err': err,
         }
+        if other is not None:
+            out['other_configs'] = other
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args)
         elif world > 1:

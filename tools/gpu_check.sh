@@ -19,6 +19,6 @@ timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/b
 cat "$OUT/bench.json"; tail -5 "$OUT/bench.err"
 echo "== rocprofv3 kernel stats"
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o bench -- python "$REPO/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/prof_bench.json" 2> "$OUT/prof.err"; echo "rocprof rc=$?"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o bench -- python "$REPO/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs > "$OUT/prof_bench.json" 2> "$OUT/prof.err"; echo "rocprof rc=$?"
 find "$OUT/prof" -name "*kernel_stats*" | head -3
 for f in $(find "$OUT/prof" -name "*kernel_stats*.csv" | head -1); do head -12 "$f"; done

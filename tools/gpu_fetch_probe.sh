@@ -4,7 +4,7 @@ TAG=$1; shift
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/fetch_$TAG; mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  env "$@" timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/$c" -o p -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/$c.log" 2>&1
+  env "$@" timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/$c" -o p -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs > "$OUT/$c.log" 2>&1
 done
 python - "$OUT" "$TAG" <<'PY'
 import csv, glob, collections, sys

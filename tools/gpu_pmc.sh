@@ -7,7 +7,7 @@ cd /tmp; export TMPDIR=/tmp
 pass() { # name counters...
   local name=$1; shift
   env "${ENVV[@]}" timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -o p -- \
-      python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/$name.log" 2>&1
+      python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > "$OUT/$name.log" 2>&1
   echo "pass $name rc=$?"
 }
 ENVV=("$@")
