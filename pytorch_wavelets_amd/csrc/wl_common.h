@@ -41,8 +41,10 @@ template <> struct WlAcc<double> { typedef double type; };
 // lane to the next barrier, so it emulates the shuffle through a per-workgroup exchange array + two barriers.
 #if defined(__HIPCC__)
 WL_DEV float wl_shfl_up1(float v) { return __shfl_up(v, 1); }
+WL_DEV float wl_shfl(float v, int src_lane) { return __shfl(v, src_lane, 64); }   // value of `v` in lane src_lane & 63
 #else
 float wl_shfl_up1(float v);
+float wl_shfl(float v, int src_lane);
 #endif
 
 struct WlCtx {

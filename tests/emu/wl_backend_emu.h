@@ -23,6 +23,7 @@ struct WlEmuBlock {
     std::vector<char*> stacks;
     std::vector<char> state;        // 0 ready, 1 at barrier, 2 at shuffle, 3 done
     std::vector<float> shfl_in, shfl_out;
+    std::vector<int> shfl_src;      // source lane (0..63) of a pending shuffle, -1 = the lane below (wl_shfl_up1)
     int cur;
     WlEmuBlock() : cur(0) {}
     ~WlEmuBlock() { for (size_t i = 0; i < stacks.size(); ++i) free(stacks[i]); }
@@ -36,14 +37,17 @@ static void wl_emu_sync(void* arg) {
     swapcontext(&b->fib[b->cur], &b->main);
 }
 
-float wl_shfl_up1(float v) {
+static float wl_emu_shuffle(float v, int src) {
     WlEmuBlock* b = wl_emu_cur_block;
     const int me = b->cur;
     b->shfl_in[me] = v;
+    b->shfl_src[me] = src;
     b->state[me] = 2;
     swapcontext(&b->fib[me], &b->main);
     return b->shfl_out[me];
 }
+float wl_shfl_up1(float v) { return wl_emu_shuffle(v, -1); }
+float wl_shfl(float v, int src_lane) { return wl_emu_shuffle(v, src_lane & 63); }
 
 template <typename K>
 struct WlEmuJob {
@@ -83,6 +87,7 @@ static int wl_launch(const typename K::Args& a, int64_t nblocks, size_t lds, voi
         blk.stacks.resize(nt);
         blk.shfl_in.resize(nt);
         blk.shfl_out.resize(nt);
+        blk.shfl_src.resize(nt);
         for (int i = 0; i < nt; ++i) blk.stacks[i] = (char*)malloc(kStack);
         char* smem = (char*)aligned_alloc(64, ((lds + 63) / 64 + 1) * 64);
         WlEmuJob<K> job;
@@ -125,7 +130,8 @@ static int wl_launch(const typename K::Args& a, int64_t nblocks, size_t lds, voi
                     }
                     if (any && all) {
                         for (int i = w0; i < w0 + 64 && i < nt; ++i)
-                            blk.shfl_out[i] = (i > w0) ? blk.shfl_in[i - 1] : blk.shfl_in[i];
+                            blk.shfl_out[i] = blk.shfl_src[i] < 0 ? ((i > w0) ? blk.shfl_in[i - 1] : blk.shfl_in[i])
+                                                                  : blk.shfl_in[w0 + blk.shfl_src[i]];
                         for (int i = w0; i < w0 + 64 && i < nt; ++i)
                             if (blk.state[i] == 2) blk.state[i] = 0;
                         resolved = true;
