@@ -99,6 +99,7 @@ WL_HD int wl_ext(int i, int n, int ext) {
 // a virtual signal of length n + pad_lo + pad_hi whose first pad_lo / last pad_hi samples
 // replicate the edge.  Returns the source position of virtual position v (after extension).
 WL_HD int wl_ext_padded(int v, int n, int pad_lo, int pad_hi, int ext) {
+    if ((unsigned)(v - pad_lo) < (unsigned)n) return v - pad_lo;   // interior: no extension, no padding
     int nv = n + pad_lo + pad_hi;
     int j = wl_ext(v, nv, ext);
     if (j < 0) return -1;
