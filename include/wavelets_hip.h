@@ -54,6 +54,14 @@ int wl_dwt2d_analysis(const void* x, void* ll, void* highs, int dtype, int64_t p
                       const void* h_w_lo, const void* h_w_hi, int Lw,
                       const void* h_h_lo, const void* h_h_hi, int Lh, int mode, void* stream);
 
+/* The same with explicit layouts: x and ll as (planes, rows, cols) views with unit column stride and the given
+ * plane / row strides (elements).  The level loop of DWTForward keeps the inner LL_j at a cache-line-aligned row
+ * pitch (aligned stores for this level, aligned 8-byte loads for the next); highs and the final yl stay dense. */
+int wl_dwt2d_analysis_strided(const void* x, int64_t x_plane_stride, int x_row_stride, void* ll,
+                              int64_t ll_plane_stride, int ll_row_stride, void* highs, int dtype, int64_t planes,
+                              int H, int W, const void* h_w_lo, const void* h_w_hi, int Lw, const void* h_h_lo,
+                              const void* h_h_hi, int Lh, int mode, void* stream);
+
 /* One 2-D synthesis level = SFB2D.forward (dwt/lowlevel.py:671-680: three sfb1d = six
  * conv_transpose2d + three adds), also AFB2D.backward (dwt/lowlevel.py:350-365, the crop is done
  * by passing a smaller OH/OW).

@@ -10,6 +10,7 @@ PROTOTYPES = {
     'wl_backend': (C.c_char_p, []),
     'wl_dwt_coeff_len': (I, [I, I, I]),
     'wl_dwt2d_analysis': (I, [P, P, P, I, L, I, I, P, P, I, P, P, I, I, P]),
+    'wl_dwt2d_analysis_strided': (I, [P, L, I, P, L, I, P, I, L, I, I, P, P, I, P, P, I, I, P]),
     'wl_dwt2d_synthesis': (I, [P, L, I, P, P, I, L, I, I, I, I, P, P, I, P, P, I, I, P]),
     'wl_dwt2d_analysis_fused': (I, [P, P, C.POINTER(P), I, L, I, I, I, P, P, P, P, I, I, I, P]),
     'wl_dtcwt_fwd_level1': (I, [P, P, P, I, L, I, I, P, I, P, I, I, P]),

@@ -26,6 +26,8 @@ struct WlAfb2dArgs {
     const A* h_h_lo; // taps along H, Lh each
     const A* h_h_hi;
     int64_t NC;
+    int64_t x_ps, ll_ps;   // plane strides of x and ll (elements)
+    int x_rs, ll_rs;       // row strides of x and ll (elements; rows are unit-stride)
     int H, W, Kh, Kw;
     int Lw, Lh, basew, baseh, extw, exth;
     int TH, TW, tiles_x, tiles_y;
@@ -56,11 +58,11 @@ WL_DEV void wl_afb2d_tile_body(const WlAfb2dArgs<T>& a, const WlCtx& ctx) {
     for (int i = ctx.tid; i < a.Lh; i += ctx.nthreads) { hhl[i] = a.h_h_lo[i]; hhh[i] = a.h_h_hi[i]; }
 
     // phase 1: stage the boundary-extended input tile
-    const T* xp = a.x + (size_t)plane * a.H * a.W;
+    const T* xp = a.x + (size_t)plane * a.x_ps;
     const int er0 = 2 * kh0 + a.baseh, ec0 = 2 * kw0 + a.basew;
     for (int i = ty; i < a.nrows; i += ny) {
         const int r = wl_ext(er0 + i, a.H, a.exth);
-        const T* xr = xp + (size_t)(r < 0 ? 0 : r) * a.W;
+        const T* xr = xp + (size_t)(r < 0 ? 0 : r) * a.x_rs;
         for (int j = tx; j < a.ncols; j += 64) {
             const int c = wl_ext(ec0 + j, a.W, a.extw);
             S[i * a.spitch + j] = (r < 0 || c < 0) ? (A)0 : (A)xr[c];
@@ -84,7 +86,7 @@ WL_DEV void wl_afb2d_tile_body(const WlAfb2dArgs<T>& a, const WlCtx& ctx) {
     ctx.sync();
     // phase 3: column bank (along H) and sub-band scatter
     const size_t bplane = (size_t)a.Kh * a.Kw;
-    T* llp = a.ll + (size_t)plane * bplane;
+    T* llp = a.ll + (size_t)plane * a.ll_ps;
     T* hp = a.highs + (size_t)plane * 3 * bplane;
     for (int kh = ty; kh < a.TH; kh += ny) {
         if (kh0 + kh >= a.Kh) break;
@@ -100,7 +102,7 @@ WL_DEV void wl_afb2d_tile_body(const WlAfb2dArgs<T>& a, const WlCtx& ctx) {
                 hh += hhh[j] * hi;
             }
             const size_t o = (size_t)(kh0 + kh) * a.Kw + (kw0 + kw);
-            llp[o] = (T)ll;
+            llp[(size_t)(kh0 + kh) * a.ll_rs + (kw0 + kw)] = (T)ll;
             hp[o] = (T)lh;
             hp[bplane + o] = (T)hl;
             hp[2 * bplane + o] = (T)hh;

@@ -29,6 +29,9 @@ struct WlAfbTileArgs {
     const float* h_h_lo;
     const float* h_h_hi;
     int64_t NC;
+    int64_t x_ps, ll_ps;   // plane strides of x and ll (elements)
+    int x_rs, ll_rs;       // row strides of x and ll (elements; rows are unit-stride): LL_j of the inner levels is
+                           //   kept at a cache-line-aligned pitch, only the last level's yl is dense
     int H, W, Kh, Kw;
     int base, ext;
     int tiles_x, tiles_y;
@@ -86,7 +89,7 @@ struct WlAfbTile {
             tl[2 * tid] = a.h_w_lo[tid]; tl[2 * tid + 1] = a.h_w_hi[tid];
             tl[2 * LT + 2 * tid] = a.h_h_lo[tid]; tl[2 * LT + 2 * tid + 1] = a.h_h_hi[tid];
         }
-        const T* xp = a.x + (size_t)plane * a.H * a.W;
+        const T* xp = a.x + (size_t)plane * a.x_ps;
         constexpr int NP = SP / 2;                        // 8-byte pairs per staged row
         constexpr int RPI = kThreads / NP;                // staged rows per iteration (lanes: RPI x NP)
         constexpr int NIT = (NROWS + RPI - 1) / RPI;
@@ -123,7 +126,7 @@ struct WlAfbTile {
                 pf[it] = Pair2{(T)0, (T)0};
                 const int r = rsrc[it];
                 if (lane_on && r >= 0 && !(a.ablate & 2)) {
-                    const T* src = xp + r * a.W;
+                    const T* src = xp + r * a.x_rs;
                     if (pair_ld) pf[it] = *reinterpret_cast<const Pair2*>(src + cs0);
                     else {
                         if (cs0 >= 0) pf[it].x = src[cs0];
@@ -204,7 +207,7 @@ struct WlAfbTile {
 #pragma unroll
             for (int j = 0; j < LT; ++j) { th[j].x = tl[2 * LT + 2 * j]; th[j].y = tl[2 * LT + 2 * j + 1]; }
             const unsigned bplane = (unsigned)a.Kh * (unsigned)a.Kw;
-            T* llp = a.ll + (size_t)plane * bplane;
+            T* llp = a.ll + (size_t)plane * a.ll_ps;
             T* hp = a.highs + (size_t)plane * 3 * bplane;
             auto col_item = [&](int kh, int q) {
                 const int k = kh0 + kh, kw = kw0 + 2 * q;
@@ -218,6 +221,7 @@ struct WlAfbTile {
                     cl1 += th[j] * p.z; ch1 += th[j] * p.w;
                 }
                 const unsigned o = (unsigned)k * (unsigned)a.Kw + (unsigned)kw;
+                const unsigned ol = (unsigned)k * (unsigned)a.ll_rs + (unsigned)kw;
                 if ((a.ablate & 1) && cl0.x != 12345.f) return;
                 if (kw + 1 < a.Kw) {
                     Pair p0, p1, p2, p3;
@@ -225,12 +229,12 @@ struct WlAfbTile {
                     p1.a = (T)cl0.y; p1.b = (T)cl1.y;   // W-lo / H-hi
                     p2.a = (T)ch0.x; p2.b = (T)ch1.x;   // W-hi / H-lo
                     p3.a = (T)ch0.y; p3.b = (T)ch1.y;   // HH
-                    *reinterpret_cast<Pair*>(llp + o) = p0;
+                    *reinterpret_cast<Pair*>(llp + ol) = p0;
                     *reinterpret_cast<Pair*>(hp + o) = p1;
                     *reinterpret_cast<Pair*>(hp + bplane + o) = p2;
                     *reinterpret_cast<Pair*>(hp + 2 * bplane + o) = p3;
                 } else {
-                    llp[o] = (T)cl0.x;
+                    llp[ol] = (T)cl0.x;
                     hp[o] = (T)cl0.y;
                     hp[bplane + o] = (T)ch0.x;
                     hp[2 * bplane + o] = (T)ch0.y;

@@ -88,6 +88,7 @@ class SFB2D(Function):
 import os as _os
 _STREAM = bool(_os.environ.get('WL_STREAM'))           # experimental streaming kernels instead of tiles
 _FUSE_DEEP = bool(_os.environ.get('WL_STREAM_FUSE'))   # ... with levels 2..4 fused in one launch
+_PAD_LL = _os.environ.get('WL_PAD_LL', '0') != '0'     # inner-level LL_j at a cache-line-aligned row pitch (measured neutral: off)
 
 
 class AFB2DMulti(Function):
@@ -119,7 +120,9 @@ class AFB2DMulti(Function):
             if res is None:
                 n = 1
                 shapes.append(tuple(ll.shape[-2:]))
-                ll, high = ops.afb2d(ll, h0_row, h1_row, h0_col, h1_col, mode)
+                # LL_j of the inner levels is internal: keep it at a cache-line-aligned row pitch (aligned stores
+                # here, aligned 8-byte loads in the next level); the last level's yl is dense like every output
+                ll, high = ops.afb2d(ll, h0_row, h1_row, h0_col, h1_col, mode, pad_ll=_PAD_LL and done + 1 < J)
                 yh.append(high)
             else:
                 shapes.append(tuple(ll.shape[-2:]))

@@ -35,20 +35,33 @@ def coeff_len(n, L, mode):
     return (n + 1) // 2 if mode == 2 else (n + L - 1) // 2
 
 
-def afb2d(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode):
-    """One analysis level: x (N,C,H,W) -> ll (N,C,Kh,Kw), highs (N,C,3,Kh,Kw)."""
+def _ll_pitch(kw, itemsize):
+    """Row pitch (elements) of an inner-level LL buffer: the next multiple of a 128-byte cache line."""
+    q = 128 // itemsize
+    return (kw + q - 1) // q * q
+
+
+def afb2d(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, pad_ll=False):
+    """One analysis level: x (N,C,H,W) -> ll (N,C,Kh,Kw), highs (N,C,3,Kh,Kw).  x may be a row-padded view
+    (unit column stride, uniform plane stride); with `pad_ll` the returned ll is such a view (row pitch = a multiple
+    of a cache line) - the level loop uses it for the LL_j that only feed the next level."""
     _check_tensor(x, 'x')
-    x = x.contiguous()
     N, C, H, W = x.shape
+    if x.numel() == 0 or x.stride(3) != 1 or x.stride(0) != C * x.stride(1) or x.stride(2) < W:
+        x = x.contiguous()
     hwl, hwh, hhl, hhh = (_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi))
     Lw, Lh = hwl.numel(), hhl.numel()
     Kh, Kw = coeff_len(H, Lh, mode), coeff_len(W, Lw, mode)
-    ll = torch.empty((N, C, Kh, Kw), dtype=x.dtype, device=x.device)
+    if pad_ll:
+        ll = torch.empty((N, C, Kh, _ll_pitch(Kw, x.element_size())), dtype=x.dtype, device=x.device)[..., :Kw]
+    else:
+        ll = torch.empty((N, C, Kh, Kw), dtype=x.dtype, device=x.device)
     highs = torch.empty((N, C, 3, Kh, Kw), dtype=x.dtype, device=x.device)
-    rc = _backend().wl_dwt2d_analysis(x.data_ptr(), ll.data_ptr(), highs.data_ptr(), _DTYPES[x.dtype],
-                                      N * C, H, W, hwl.data_ptr(), hwh.data_ptr(), Lw, hhl.data_ptr(),
-                                      hhh.data_ptr(), Lh, mode, _stream(x))
-    _lib.check(rc, 'wl_dwt2d_analysis')
+    rc = _backend().wl_dwt2d_analysis_strided(x.data_ptr(), x.stride(1), x.stride(2), ll.data_ptr(), ll.stride(1),
+                                              ll.stride(2), highs.data_ptr(), _DTYPES[x.dtype], N * C, H, W,
+                                              hwl.data_ptr(), hwh.data_ptr(), Lw, hhl.data_ptr(), hhh.data_ptr(), Lh,
+                                              mode, _stream(x))
+    _lib.check(rc, 'wl_dwt2d_analysis_strided')
     return ll, highs
 
 

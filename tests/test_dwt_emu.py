@@ -155,3 +155,25 @@ def test_tile_equals_generic_on_random_shapes(seed, monkeypatch):
                 assert a.shape == b.shape
                 scale = float(b.abs().max()) + 1e-30
                 assert float((a - b).abs().max()) <= 2e-5 * scale, (wave, mode, H, W, J)
+
+
+def test_strided_input_and_padded_inner_ll(monkeypatch):
+    """wl_dwt2d_analysis_strided: row-padded input views and the (optional) cache-line-aligned pitch of the inner
+    LL_j must give the same coefficients as the dense layout, specialised and generic kernels."""
+    from pytorch_wavelets_amd.dwt import lowlevel
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(11)
+    big = torch.randn(2, 3, 70, 150)
+    x = big[..., :131]                       # unit column stride, row pitch 150, uniform plane stride
+    for generic in ('0', '1'):
+        monkeypatch.setenv('WL_GENERIC_ONLY', generic)
+        for mode in ('symmetric', 'periodization', 'zero'):
+            outs = []
+            for pad, inp in ((False, x.contiguous()), (True, x)):
+                monkeypatch.setattr(lowlevel, '_PAD_LL', pad)
+                with emu_backend.emulated():
+                    yl, yh = pw.DWTForward(J=3, wave='db4', mode=mode)(inp)
+                assert yl.is_contiguous() and all(h.is_contiguous() for h in yh)
+                outs.append([yl] + list(yh))
+            for a, b in zip(*outs):
+                assert torch.equal(a, b)
