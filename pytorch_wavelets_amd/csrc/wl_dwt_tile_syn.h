@@ -82,6 +82,47 @@ struct WlSfbTile {
             const unsigned bplane = (unsigned)a.Kh * (unsigned)a.Kw;
             const T* llp = a.ll + (size_t)plane * a.ll_plane_stride;
             const T* hp = a.highs ? a.highs + (size_t)plane * 3 * bplane : nullptr;
+            // half data with even geometry: 4-byte loads of two cells per lane (half the load instructions)
+            const bool pairs2 = sizeof(T) == 2 && !(a.Kw & 1) && !(a.ll_row_stride & 1) && !(kc0 & 1) &&
+                                !(a.ll_plane_stride & 1) && ((uintptr_t)a.ll % 4 == 0) &&
+                                (!a.highs || (uintptr_t)a.highs % 4 == 0);
+            if (pairs2) {
+                constexpr int NPAIR = NKC / 2, NIT2 = (NKR * NPAIR + kThreads - 1) / kThreads;
+                WlPair<T> pv[NIT2][4];
+#pragma unroll
+                for (int it = 0; it < NIT2; ++it) {
+                    const int f = tid + it * kThreads;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) pv[it][b].a = pv[it][b].b = (T)0;
+                    if (f < NKR * NPAIR) {
+                        const int i = f / NPAIR, j = 2 * (f - i * NPAIR);
+                        int r = kr0 + i, c = kc0 + j;
+                        if (a.circ) {
+                            if ((unsigned)r >= (unsigned)a.Kh) r = wl_pmod(r, a.Kh);
+                            if ((unsigned)c >= (unsigned)a.Kw) c = wl_pmod(c, a.Kw);   // even c, even Kw: the pair stays together
+                        }
+                        if ((unsigned)r < (unsigned)a.Kh && (unsigned)c < (unsigned)a.Kw) {
+                            pv[it][0] = *reinterpret_cast<const WlPair<T>*>(llp + (unsigned)(r * a.ll_row_stride + c));
+                            if (hp) {
+                                const T* q = hp + ((unsigned)r * (unsigned)a.Kw + (unsigned)c);
+                                pv[it][1] = *reinterpret_cast<const WlPair<T>*>(q);
+                                pv[it][2] = *reinterpret_cast<const WlPair<T>*>(q + bplane);
+                                pv[it][3] = *reinterpret_cast<const WlPair<T>*>(q + 2 * bplane);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < NIT2; ++it) {
+                    const int f = tid + it * kThreads;
+                    if (f < NKR * NPAIR) {
+                        wl_f4 w0, w1;
+                        w0.x = (float)pv[it][0].a; w0.y = (float)pv[it][1].a; w0.z = (float)pv[it][2].a; w0.w = (float)pv[it][3].a;
+                        w1.x = (float)pv[it][0].b; w1.y = (float)pv[it][1].b; w1.z = (float)pv[it][2].b; w1.w = (float)pv[it][3].b;
+                        B[2 * f] = w0; B[2 * f + 1] = w1;   // cell (i, j) = i*NKC + j = 2f
+                    }
+                }
+            } else {
             constexpr int NIT = (NKR * NKC + kThreads - 1) / kThreads;
             float v[NIT][4];
 #pragma unroll
@@ -113,6 +154,7 @@ struct WlSfbTile {
                     wl_f4 w; w.x = v[it][0]; w.y = v[it][1]; w.z = v[it][2]; w.w = v[it][3];
                     B[f] = w;
                 }
+            }
             }
         }
         ctx.sync();

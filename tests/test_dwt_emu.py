@@ -177,3 +177,21 @@ def test_strided_input_and_padded_inner_ll(monkeypatch):
                 outs.append([yl] + list(yh))
             for a, b in zip(*outs):
                 assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('wave,mode,shape', [('db8', 'periodization', (1, 2, 96, 160)), ('db4', 'symmetric', (1, 2, 70, 132)),
+                                             ('haar', 'zero', (2, 1, 64, 64)), ('db3', 'periodization', (1, 1, 50, 66))])
+def test_half_precision_tile_kernels(wave, mode, shape):
+    """float16 data (fp32 accumulation; 4-byte pair loads in both directions where the geometry is even)."""
+    torch.set_default_dtype(torch.float32)
+    torch.manual_seed(9)
+    x = torch.randn(*shape)
+    with emu_backend.emulated():
+        ryl, ryh = pw.DWTForward(J=2, wave=wave, mode=mode)(x.half().float())
+        yl, yh = pw.DWTForward(J=2, wave=wave, mode=mode).half()(x.half())
+        rec = pw.DWTInverse(wave=wave, mode=mode).half()((yl, yh))
+    assert yl.dtype == torch.float16 and rec.dtype == torch.float16
+    assert float((yl.float() - ryl).abs().max()) < 4e-3 * float(ryl.abs().max())
+    for a, b in zip(yh, ryh):
+        assert float((a.float() - b).abs().max()) < 4e-3 * float(b.abs().max())
+    assert float((rec.float()[..., :shape[-2], :shape[-1]] - x).abs().max()) < 2e-2 * float(x.abs().max())
