@@ -82,10 +82,11 @@ struct WlSfbTile {
             const unsigned bplane = (unsigned)a.Kh * (unsigned)a.Kw;
             const T* llp = a.ll + (size_t)plane * a.ll_plane_stride;
             const T* hp = a.highs ? a.highs + (size_t)plane * 3 * bplane : nullptr;
-            // half data with even geometry: 4-byte loads of two cells per lane (half the load instructions)
-            const bool pairs2 = sizeof(T) == 2 && !(a.Kw & 1) && !(a.ll_row_stride & 1) && !(kc0 & 1) &&
-                                !(a.ll_plane_stride & 1) && ((uintptr_t)a.ll % 4 == 0) &&
-                                (!a.highs || (uintptr_t)a.highs % 4 == 0);
+            // even geometry (band width, strides, first staged column): ALIGNED two-cell loads per lane - half the load
+            // instructions.  (Odd band widths, e.g. 259, keep element loads: misaligned 8-byte loads measured slower.)
+            const bool pairs2 = !(a.Kw & 1) && !(a.ll_row_stride & 1) && !(kc0 & 1) && !(a.ll_plane_stride & 1) &&
+                                ((uintptr_t)a.ll % (2 * sizeof(T)) == 0) &&
+                                (!a.highs || (uintptr_t)a.highs % (2 * sizeof(T)) == 0) && !(bplane & 1);
             if (pairs2) {
                 constexpr int NPAIR = NKC / 2, NIT2 = (NKR * NPAIR + kThreads - 1) / kThreads;
                 WlPair<T> pv[NIT2][4];
