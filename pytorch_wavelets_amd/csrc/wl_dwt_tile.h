@@ -42,7 +42,9 @@ struct WlAfbTileArgs {
     int ablate;       // profiling only (WL_ABLATE): 1 no stores, 2 no loads, 4 no row bank, 8 no column bank
 };
 
-template <typename T, int LT, int TH_ = 16, int TW_ = 64, int SH_ = 0>
+// V4_ = 1: the input tile is staged with FOUR-element loads (used for float16: 8 instead of 4 bytes per lane); needs
+// W % 4 == 0, an aligned base pointer and the staged origin (2*kw0 + base - SH_) on a multiple of four columns.
+template <typename T, int LT, int TH_ = 16, int TW_ = 64, int SH_ = 0, int V4_ = 0>
 struct WlAfbTile {
     typedef WlAfbTileArgs<T> Args;
     static const int kThreads = 256;
@@ -67,6 +69,8 @@ struct WlAfbTile {
     static const int kTapFloats = 4 * LT;
     static const int kLdsFloats = kTapFloats + NROWS * SP + NROWS * TP;
     typedef T Pair2 __attribute__((ext_vector_type(2)));
+    typedef T Quad4 __attribute__((ext_vector_type(4)));
+    static const int V4 = V4_;
     struct __attribute__((packed, aligned(sizeof(T)), may_alias)) Pair { T a, b; };   // element-aligned pair
 
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
@@ -90,10 +94,11 @@ struct WlAfbTile {
             tl[2 * LT + 2 * tid] = a.h_h_lo[tid]; tl[2 * LT + 2 * tid + 1] = a.h_h_hi[tid];
         }
         const T* xp = a.x + (size_t)plane * a.x_ps;
-        constexpr int NP = SP / 2;                        // 8-byte pairs per staged row
+        constexpr int NP = V4 ? SP / 4 : SP / 2;          // staged cells (pairs, or quads) per row
         constexpr int RPI = kThreads / NP;                // staged rows per iteration (lanes: RPI x NP)
         constexpr int NIT = (NROWS + RPI - 1) / RPI;
-        Pair2 pf[NIT];
+        Pair2 pf[V4 ? 1 : NIT];
+        Quad4 pq[V4 ? NIT : 1];
         // Rows: this tile row needs input rows er0 .. er0+nr_need-1; the lane owns staged rows s_row, s_row+RPI, ..
         // whose SOURCE rows under the boundary extension are resolved once per workgroup.
         const int s_row = tid / NP, p_own = tid - s_row * NP;
@@ -112,6 +117,39 @@ struct WlAfbTile {
         // issue the loads of tile column `tx` (registers only).  A border cell is simply loaded from its source
         // column (an L1/L2 hit), so every mode, odd widths and multiple reflections need no special path.
         auto issue = [&](int tx) {
+            if (V4) {
+                const int kw0 = tx * TW;
+                const int ec0 = 2 * kw0 + a.base - SH;                 // multiple of 4
+                const int ncols_out = tx == a.tiles_x - 1 ? a.Kw - kw0 : TW;
+                const int nq = (ncols_out + 1) / 2;
+                const int nq4 = (nq * 2 + NV * 2 - 2 + 1) / 2;         // staged quads per row actually needed
+                const bool lane_on = s_row < RPI && p_own < (nq4 < NP ? nq4 : NP) && !(a.ablate & 2);
+                int cs[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cs[e] = lane_on ? wl_ext(ec0 + 4 * p_own + e, a.W, a.ext) : -1;
+                const bool quad_ld = cs[0] >= 0 && (cs[0] & 3) == 0 && cs[3] == cs[0] + 3;
+                const int cq = quad_ld ? cs[0] : -1;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    pq[it] = Quad4{(T)0, (T)0, (T)0, (T)0};
+                    const int r = rsrc[it];
+                    if ((cq | r) >= 0) pq[it] = *reinterpret_cast<const Quad4*>(xp + r * a.x_rs + cq);
+                }
+                if (lane_on && !quad_ld) {   // border lanes: element loads from the source columns
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const int r = rsrc[it];
+                        if (r >= 0) {
+                            const T* src = xp + r * a.x_rs;
+                            if (cs[0] >= 0) pq[it].x = src[cs[0]];
+                            if (cs[1] >= 0) pq[it].y = src[cs[1]];
+                            if (cs[2] >= 0) pq[it].z = src[cs[2]];
+                            if (cs[3] >= 0) pq[it].w = src[cs[3]];
+                        }
+                    }
+                }
+                return;
+            }
             const int kw0 = tx * TW;
             const int ec0 = 2 * kw0 + a.base - SH;
             const int ncols_out = tx == a.tiles_x - 1 ? a.Kw - kw0 : TW;
@@ -138,6 +176,17 @@ struct WlAfbTile {
         // registers -> LDS (cells outside the needed part of a partial tile are written too: zeros)
         auto commit = [&]() {
             if (s_row >= RPI) return;
+            if (V4) {
+                float* d4 = S + s_row * SP + 4 * p_own;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    if (it * RPI + s_row < NROWS) {
+                        wl_f4 w; w.x = (float)pq[it].x; w.y = (float)pq[it].y; w.z = (float)pq[it].z; w.w = (float)pq[it].w;
+                        *reinterpret_cast<wl_f4*>(d4 + it * RPI * SP) = w;
+                    }
+                }
+                return;
+            }
             float* d = S + s_row * SP + 2 * p_own;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
