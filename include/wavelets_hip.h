@@ -41,6 +41,13 @@ extern "C" {
 int wl_version(void);
 const char* wl_backend(void);
 
+/* Diagnostics.  wl_set_option("generic_only", 1) routes every operator to the runtime-L generic kernels (the test-suite
+ * compares the two kernel families); the initial value is read once from $WL_GENERIC_ONLY.  Returns 0, or
+ * WL_ERR_UNSUPPORTED for an unknown name.  wl_last_kernel(): name of the kernel functor the calling thread launched
+ * last (static storage), so that a benchmark can label its numbers with the dispatch actually taken. */
+int wl_set_option(const char* name, int value);
+const char* wl_last_kernel(void);
+
 /* Coefficient count of one 1-D analysis level: (n+L-1)/2, or (n+1)/2 for periodization.
  * Replaces pywt.dwt_coeff_len at dwt/lowlevel.py:153. */
 int wl_dwt_coeff_len(int n, int L, int mode);
@@ -74,13 +81,14 @@ int wl_dwt2d_synthesis(const void* ll, int64_t ll_plane_stride, int ll_row_strid
                        const void* g_w_lo, const void* g_w_hi, int Lw,
                        const void* g_h_lo, const void* g_h_hi, int Lh, int mode, void* stream);
 
-/* `nlev` (1..4) analysis levels in ONE launch = the body of DWTForward.forward's level loop
- * (dwt/transform2d.py:63-74): x (planes,H,W) -> yh[j] (planes,3,H_j,W_j) for j < nlev and the last
- * level's low-pass yl; the intermediate LL_j stay in LDS.  `yh` is a HOST array of nlev device
- * pointers.  Same taps (length L) on both axes of every level, F32/F16 data, float taps.
- * zero / symmetric / reflect for nlev > 1, any mode for nlev == 1.  `strips` = workgroups per
- * plane (0 = choose).  Returns WL_ERR_UNSUPPORTED when the configuration is outside this kernel's
- * envelope (the caller then uses wl_dwt2d_analysis level by level). */
+/* `nlev` (1..3) analysis levels in ONE launch = the body of DWTForward.forward's level loop
+ * (dwt/transform2d.py:63-74): x (planes,H,W) dense -> yh[j] (planes,3,H_j,W_j) for j < nlev and the last
+ * level's low-pass yl; one workgroup streams one plane top to bottom, the intermediate LL_j stay in LDS rings and
+ * HBM traffic is the algorithmic minimum.  `yh` is a HOST array of nlev device pointers.  Same taps (even length
+ * L <= 12) on both axes of every level, F32/F16 data, float taps; rows of 16-byte multiples up to ~630 outputs wide;
+ * zero / symmetric / reflect for nlev > 1, any mode for nlev == 1.  `strips`: 0 = let the engine decide (it declines
+ * when there are fewer planes than compute units), 1 = force this kernel.  Returns WL_ERR_UNSUPPORTED outside the
+ * kernel's envelope: the caller then uses wl_dwt2d_analysis level by level. */
 int wl_dwt2d_analysis_fused(const void* x, void* yl, void* const* yh, int dtype, int64_t planes, int H,
                             int W, int nlev, const void* h_w_lo, const void* h_w_hi, const void* h_h_lo,
                             const void* h_h_hi, int L, int mode, int strips, void* stream);

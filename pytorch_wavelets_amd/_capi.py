@@ -8,6 +8,8 @@ L = C.c_int64
 PROTOTYPES = {
     'wl_version': (I, []),
     'wl_backend': (C.c_char_p, []),
+    'wl_set_option': (I, [C.c_char_p, I]),
+    'wl_last_kernel': (C.c_char_p, []),
     'wl_dwt_coeff_len': (I, [I, I, I]),
     'wl_dwt2d_analysis': (I, [P, P, P, I, L, I, I, P, P, I, P, P, I, I, P]),
     'wl_dwt2d_analysis_strided': (I, [P, L, I, P, L, I, P, I, L, I, I, P, P, I, P, P, I, I, P]),

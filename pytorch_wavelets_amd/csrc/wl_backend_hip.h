@@ -13,8 +13,14 @@ __global__ void __launch_bounds__(K::kThreads, K::kMinWaves) wl_kernel(const typ
     ctx.nthreads = K::kThreads;
     ctx.bid = blockIdx.x;
     ctx.smem = wl_smem;
+    ctx.lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)wl_smem;
     K::run(a, ctx);
 }
+
+// name of the kernel functor the calling thread launched last (wl_last_kernel() of the C ABI: bench.py labels its
+// roofline with the dispatch that was actually taken)
+inline thread_local const char* wl_last_kernel_ptr = "";
+static const char* wl_last_kernel_name() { return wl_last_kernel_ptr; }
 
 // compute units of the current device (persistent kernels size their grid from it)
 static int wl_num_cus() {
@@ -33,14 +39,17 @@ template <typename K>
 static int wl_launch(const typename K::Args& a, int64_t nblocks, size_t lds, void* stream) {
     if (nblocks <= 0) return 0;
     if (nblocks > 2147483647LL || lds > 160 * 1024) return -2;
+    wl_last_kernel_ptr = __PRETTY_FUNCTION__;
     if (lds > 48 * 1024) {
         // opt in to large dynamic LDS once per kernel (idempotent, cheap)
-        static thread_local size_t granted = 0;
-        if (lds > granted) {
+        static thread_local unsigned granted = 0;   // bit d: done for device d (the attribute is per device)
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        if (dev >= 32 || !(granted >> dev & 1u)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wl_kernel<K>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
-            granted = 160 * 1024;
+            if (dev < 32) granted |= 1u << dev;
         }
     }
     hipLaunchKernelGGL(wl_kernel<K>, dim3((unsigned)nblocks), dim3(K::kThreads), lds,

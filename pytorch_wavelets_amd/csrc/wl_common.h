@@ -47,11 +47,16 @@ float wl_shfl_up1(float v);
 float wl_shfl(float v, int src_lane);
 #endif
 
+struct __attribute__((may_alias)) alignas(16) wl_f4 { float x, y, z, w; };
+struct __attribute__((may_alias)) alignas(8) wl_f2 { float x, y; };
+typedef float wl_v2 __attribute__((ext_vector_type(2)));   // (low-band, high-band) pair: one v_pk_fma_f32 per tap
+
 struct WlCtx {
     int tid;        // thread index in the workgroup
     int nthreads;   // workgroup size
     int64_t bid;    // linear workgroup index
     char* smem;     // dynamic LDS base (16-byte aligned)
+    unsigned lds_base;   // LDS byte address of smem (M0 base of the LDS-DMA loads; unused by the emulator)
 #if defined(__HIPCC__)
     WL_DEV void sync() const { __syncthreads(); }
 #else
@@ -60,6 +65,40 @@ struct WlCtx {
     inline void sync() const { sync_fn(sync_arg); }
 #endif
 };
+
+// ---------------------------------------------------------------------------------------------
+// Wave-level helpers of the streaming kernels (wl_dwt_rows.h).
+//   wl_uniform : a value the caller knows to be wave-uniform, pinned to a scalar register;
+//   wl_dma16   : asynchronous global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): the wave writes the
+//                64 x 16 B of its lanes with lane_on to LDS bytes [lds_off + 16*lane, +16), lds_off wave-uniform; at
+//                least one lane of the wave must be on (the wait counts are per wave-instruction).  The data
+//                is visible to the issuing wave after wl_wait_vm<N>() (at most N younger DMA / vector-memory
+//                operations of that wave still outstanding) and to other waves after a barrier behind that wait;
+//   The instruction is emitted through inline assembly on purpose: the compiler would otherwise order every later
+//   LDS read behind ALL outstanding DMA loads (s_waitcnt vmcnt(0)), i.e. no prefetch distance.
+// The host emulation defers each copy until the lane's wl_wait_vm releases it, so a missing or too permissive wait
+// reads NaN-poisoned LDS in the CPU tests.
+// ---------------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+WL_DEV int wl_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+WL_DEV float wl_uniform_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+WL_DEV void wl_dma16(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on) {
+    const unsigned m0 = __builtin_amdgcn_readfirstlane(ctx.lds_base + lds_off);
+    // lanes that are off copy nothing; the instruction still counts once per wave as long as one lane is on
+    if (lane_on)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0), "v"(gsrc) : "memory", "m0");
+}
+template <int N> WL_DEV void wl_wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));   // vmcnt(N), others untouched
+}
+#else
+inline int wl_uniform(int v) { return v; }
+inline float wl_uniform_f(float v) { return v; }
+void wl_dma16(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on);
+void wl_emu_wait_vm(int n);
+template <int N> inline void wl_wait_vm() { wl_emu_wait_vm(N); }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Boundary extension: extended position i of a length-n signal -> source position, or -1 for a
@@ -93,6 +132,15 @@ WL_HD int wl_ext(int i, int n, int ext) {
             return j == n ? n - 1 : j;
         }
     }
+}
+
+// Single-fold form of wl_ext for zero / symmetric / reflect (no division: used once per row by every wave of the
+// streaming kernels); valid while -n <= i < 2n (the launcher checks that).
+WL_HD int wl_ext1(int i, int n, int ext) {
+    const int s = ext == WL_EXT_SYM ? 1 : 0;                        // branch-free on purpose (scalar selects)
+    const int fold = (i < 0 ? -s : 2 * n - 2 + s) - i;
+    const int out = ext == WL_EXT_ZERO ? -1 : fold;
+    return (unsigned)i < (unsigned)n ? i : out;
 }
 
 // Replicate-padded view used by the DTCWT modules (dtcwt/transform2d.py:116-120, :131-135):

@@ -10,7 +10,6 @@
 //   * sub-band stores are 8 contiguous bytes per lane (one complex value / two lowpass samples).
 #pragma once
 #include "wl_common.h"
-#include "wl_dwt_stream.h"      // wl_f4 / wl_f2 / wl_v2
 #include "wl_dtcwt_kernels.h"   // argument structs, wl_dtfwd1_quad_out, WlPair
 
 // ---------------------------------------------------------------------------------------------------------

@@ -17,7 +17,6 @@
 // .contiguous() copies) for even tap counts; other tap counts use wl_dwt_kernels.h.
 #pragma once
 #include "wl_common.h"
-#include "wl_dwt_stream.h"   // wl_f4 / wl_f2 / wl_v2
 
 template <typename T>
 struct WlAfbTileArgs {
@@ -39,7 +38,6 @@ struct WlAfbTileArgs {
     int run_len;      // tiles (horizontally adjacent) per workgroup
     int runs_x;       // ceil(tiles_x / run_len)
     int64_t nblocks;  // grid size (for the XCD-aware block remap)
-    int ablate;       // profiling only (WL_ABLATE): 1 no stores, 2 no loads, 4 no row bank, 8 no column bank
 };
 
 // V4_ = 1: the input tile is staged with FOUR-element loads (used for float16: 8 instead of 4 bytes per lane); needs
@@ -123,7 +121,7 @@ struct WlAfbTile {
                 const int ncols_out = tx == a.tiles_x - 1 ? a.Kw - kw0 : TW;
                 const int nq = (ncols_out + 1) / 2;
                 const int nq4 = (nq * 2 + NV * 2 - 2 + 1) / 2;         // staged quads per row actually needed
-                const bool lane_on = s_row < RPI && p_own < (nq4 < NP ? nq4 : NP) && !(a.ablate & 2);
+                const bool lane_on = s_row < RPI && p_own < (nq4 < NP ? nq4 : NP);
                 int cs[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) cs[e] = lane_on ? wl_ext(ec0 + 4 * p_own + e, a.W, a.ext) : -1;
@@ -163,7 +161,7 @@ struct WlAfbTile {
             for (int it = 0; it < NIT; ++it) {
                 pf[it] = Pair2{(T)0, (T)0};
                 const int r = rsrc[it];
-                if (lane_on && r >= 0 && !(a.ablate & 2)) {
+                if (lane_on && r >= 0) {
                     const T* src = xp + r * a.x_rs;
                     if (pair_ld) pf[it] = *reinterpret_cast<const Pair2*>(src + cs0);
                     else {
@@ -234,7 +232,7 @@ struct WlAfbTile {
                 o.x = a0.x; o.y = a0.y; o.z = a1.x; o.w = a1.y;
                 reinterpret_cast<wl_f4*>(Tm + i * TP)[q] = o;
             };
-            _Pragma("nounroll") for (int f = tid; f < ((a.ablate & 4) ? 0 : nr_need * NQ); f += kThreads) {
+            _Pragma("nounroll") for (int f = tid; f < nr_need * NQ; f += kThreads) {
                 const int i = f / NQ, q = f - i * NQ;
                 if (q < nq_need) row_item(i, q);
             }
@@ -271,7 +269,6 @@ struct WlAfbTile {
                 }
                 const unsigned o = (unsigned)k * (unsigned)a.Kw + (unsigned)kw;
                 const unsigned ol = (unsigned)k * (unsigned)a.ll_rs + (unsigned)kw;
-                if ((a.ablate & 1) && cl0.x != 12345.f) return;
                 if (kw + 1 < a.Kw) {
                     Pair p0, p1, p2, p3;
                     p0.a = (T)cl0.x; p0.b = (T)cl1.x;   // LL
@@ -289,7 +286,7 @@ struct WlAfbTile {
                     hp[2 * bplane + o] = (T)ch0.y;
                 }
             };
-            _Pragma("nounroll") for (int f = tid; f < ((a.ablate & 8) ? 0 : TH * NQ); f += kThreads) {
+            _Pragma("nounroll") for (int f = tid; f < TH * NQ; f += kThreads) {
                 const int kh = f / NQ;
                 col_item(kh, f - kh * NQ);
             }

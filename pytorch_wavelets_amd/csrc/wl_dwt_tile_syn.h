@@ -20,7 +20,6 @@
 // :226-271) and, with a cropped OH/OW, AFB2D.backward (:350-365).
 #pragma once
 #include "wl_common.h"
-#include "wl_dwt_stream.h"   // wl_f4 / wl_f2 / wl_v2
 #include "wl_dtcwt_tile.h"   // WlPair / WlQuad
 
 template <typename T>

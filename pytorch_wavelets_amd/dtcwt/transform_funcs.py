@@ -7,6 +7,7 @@ The kernels read / write the reference's DEFAULT coefficient layout (N, C, 6, H,
 """
 import torch
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 from .. import ops
 from ..dwt.lowlevel import int_to_mode
@@ -114,6 +115,7 @@ class FWD_J1(Function):
         return ll, highs
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dl, dh):
         dx = None
         if ctx.needs_input_grad[0]:
@@ -140,6 +142,7 @@ class FWD_J2PLUS(Function):
         return ll, highs
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dl, dh):
         dx = None
         if ctx.needs_input_grad[0]:
@@ -167,6 +170,7 @@ class INV_J1(Function):
         return ops.dtcwt_inv1(lows, highs, g0, g1, mode)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         g0, g1 = ctx.saved_tensors
         dl = dh = None
@@ -192,6 +196,7 @@ class INV_J2PLUS(Function):
         return ops.dtcwt_inv2(lows, highs, g0a, g0b, g1a, g1b)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         g0a, g1a, g0b, g1b = ctx.saved_tensors
         dl = dh = None

@@ -6,6 +6,7 @@ a chain of ATen gathers / grouped convs / copies.
 import numpy as np
 import torch
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 from .. import ops
 
@@ -13,6 +14,7 @@ _MODE_TO_INT = {'zero': 0, 'symmetric': 1, 'per': 2, 'periodization': 2, 'consta
                 'replicate': 5, 'periodic': 6}
 _INT_TO_MODE = {0: 'zero', 1: 'symmetric', 2: 'periodization', 3: 'constant', 4: 'reflect',
                 5: 'replicate', 6: 'periodic'}
+FUSED_LEVELS = True   # set False to force one launch per level (A/B measurements)
 _FILTERBANK_MODES = (0, 1, 2, 4, 6)   # the ones afb1d/sfb1d accept upstream (dwt/lowlevel.py:134-170)
 
 
@@ -52,6 +54,7 @@ class AFB2D(Function):
         return ops.afb2d(x, h0_row, h1_row, h0_col, h1_col, mode)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, low, highs):
         dx = None
         if ctx.needs_input_grad[0]:
@@ -75,6 +78,7 @@ class SFB2D(Function):
         return ops.sfb2d(low, highs, g0_row, g1_row, g0_col, g1_col, mode)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         dlow, dhigh = None, None
         if ctx.needs_input_grad[0] or (ctx.has_highs and ctx.needs_input_grad[1]):
@@ -85,20 +89,18 @@ class SFB2D(Function):
         return dlow, dhigh, None, None, None, None, None
 
 
-import os as _os
-_STREAM = bool(_os.environ.get('WL_STREAM'))           # experimental streaming kernels instead of tiles
-_FUSE_DEEP = bool(_os.environ.get('WL_STREAM_FUSE'))   # ... with levels 2..4 fused in one launch
-_PAD_LL = _os.environ.get('WL_PAD_LL', '0') != '0'     # inner-level LL_j at a cache-line-aligned row pitch (measured neutral: off)
+_PAD_LL = False   # inner-level LL_j at a cache-line-aligned row pitch for the per-level path (measured neutral: off)
 
 
 class AFB2DMulti(Function):
     """J analysis levels as ONE autograd node: ``AFB2DMulti.apply(x, h0_row, h1_row, h0_col, h1_col,
     mode_int, J) -> (yl, yh_0, ..., yh_{J-1})``.
 
-    Forward = one specialised tile-kernel launch per level (generic kernel for unusual tap counts /
-    float64); the experimental streaming kernels are selected with WL_STREAM=1.  Backward = the chain of J
-    AFB2D.backward steps of the reference (synthesis with the stored analysis taps + crop,
-    dwt/lowlevel.py:350-365), coarsest level first."""
+    Forward: up to three levels at a time in ONE launch of the streaming kernel (wl_dwt2d_analysis_fused: LL_j stay
+    in LDS) whenever the engine takes the configuration - enough planes to fill the chip, even tap count <= 12,
+    16-byte rows - otherwise one specialised tile-kernel launch per level (generic kernel for unusual tap counts /
+    float64).  Backward = the chain of J AFB2D.backward steps of the reference (synthesis with the stored analysis
+    taps + crop, dwt/lowlevel.py:350-365), coarsest level first."""
 
     @staticmethod
     def forward(ctx, x, h0_row, h1_row, h0_col, h1_col, mode, J):
@@ -107,21 +109,11 @@ class AFB2DMulti(Function):
         ctx.mode = mode
         shapes, yh, ll, done = [], [], x, 0
         while done < J:
-            # default: one specialised tile-kernel launch per level (wl_dwt2d_analysis).  WL_STREAM=1 selects
-            # the streaming kernels instead (level 1 alone, then up to three levels fused with WL_STREAM_FUSE=1):
-            # they move fewer bytes but are currently instruction-bound and slower - see DESIGN.md.
-            res, n = None, 1
-            if _STREAM:
-                n = 1 if (done == 0 or not _FUSE_DEEP) else min(3, J - done)
-                res = ops.afb2d_fused(ll, h0_row, h1_row, h0_col, h1_col, mode, n)
-                if res is None and n > 1:
-                    n = 1
-                    res = ops.afb2d_fused(ll, h0_row, h1_row, h0_col, h1_col, mode, 1)
+            n = min(3, J - done)
+            res = ops.afb2d_fused(ll, h0_row, h1_row, h0_col, h1_col, mode, n) if FUSED_LEVELS else None
             if res is None:
                 n = 1
                 shapes.append(tuple(ll.shape[-2:]))
-                # LL_j of the inner levels is internal: keep it at a cache-line-aligned row pitch (aligned stores
-                # here, aligned 8-byte loads in the next level); the last level's yl is dense like every output
                 ll, high = ops.afb2d(ll, h0_row, h1_row, h0_col, h1_col, mode, pad_ll=_PAD_LL and done + 1 < J)
                 yh.append(high)
             else:
@@ -134,6 +126,7 @@ class AFB2DMulti(Function):
         return (ll,) + tuple(yh)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dyl, *dyh):
         dx = None
         if ctx.needs_input_grad[0]:

@@ -21,6 +21,40 @@ def _check_tensor(t, name):
                            % (name, t.device))
 
 
+class _NoGuard(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOGUARD = _NoGuard()
+
+
+def _device_of(t):
+    """Make t's device current around a launch: the C ABI launches on the CURRENT HIP device with the stream it is
+    handed, so a tensor on cuda:1 while cuda:0 is current must switch first (ATen does the same for the reference)."""
+    return torch.cuda.device(t.device) if t.is_cuda else _NOGUARD
+
+
+def _same_device(*ts):
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError('pytorch_wavelets_amd: tensors on different devices (%s, %s)' % (dev, t.device))
+
+
+def _call(name, ref, *args):
+    """One C-ABI call with ref's device current."""
+    with _device_of(ref):
+        return getattr(_backend(), name)(*args)
+
+
 def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else None
 
@@ -57,7 +91,7 @@ def afb2d(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, pad_ll=False):
     else:
         ll = torch.empty((N, C, Kh, Kw), dtype=x.dtype, device=x.device)
     highs = torch.empty((N, C, 3, Kh, Kw), dtype=x.dtype, device=x.device)
-    rc = _backend().wl_dwt2d_analysis_strided(x.data_ptr(), x.stride(1), x.stride(2), ll.data_ptr(), ll.stride(1),
+    rc = _call('wl_dwt2d_analysis_strided', x, x.data_ptr(), x.stride(1), x.stride(2), ll.data_ptr(), ll.stride(1),
                                               ll.stride(2), highs.data_ptr(), _DTYPES[x.dtype], N * C, H, W,
                                               hwl.data_ptr(), hwh.data_ptr(), Lw, hhl.data_ptr(), hhh.data_ptr(), Lh,
                                               mode, _stream(x))
@@ -76,7 +110,9 @@ def sfb2d(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None):
         if highs.dtype != ll.dtype:
             highs = highs.to(ll.dtype)
         highs = highs.contiguous()
-        assert highs.shape == (N, C, 3, Kh, Kw), (highs.shape, ll.shape)
+        if tuple(highs.shape) != (N, C, 3, Kh, Kw):
+            raise ValueError('highs %s does not match ll %s' % (tuple(highs.shape), tuple(ll.shape)))
+        _same_device(ll, highs)
     gwl, gwh, ghl, ghh = (_taps(g, ll) for g in (g_w_lo, g_w_hi, g_h_lo, g_h_hi))
     Lw, Lh = gwl.numel(), ghl.numel()
     OH = 2 * Kh if mode == 2 else 2 * Kh - Lh + 2
@@ -84,7 +120,7 @@ def sfb2d(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None):
     if out_hw is not None:
         OH, OW = min(OH, out_hw[0]), min(OW, out_hw[1])
     y = torch.empty((N, C, OH, OW), dtype=ll.dtype, device=ll.device)
-    rc = _backend().wl_dwt2d_synthesis(ll.data_ptr(), ll.stride(1), ll.stride(2),
+    rc = _call('wl_dwt2d_synthesis', ll, ll.data_ptr(), ll.stride(1), ll.stride(2),
                                        None if highs is None else highs.data_ptr(), y.data_ptr(),
                                        _DTYPES[ll.dtype], N * C, Kh, Kw, OH, OW, gwl.data_ptr(),
                                        gwh.data_ptr(), Lw, ghl.data_ptr(), ghh.data_ptr(), Lh, mode,
@@ -93,20 +129,33 @@ def sfb2d(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None):
     return y
 
 
+_CU_COUNT = {}
+
+
+def _num_cus(device):
+    if device.type != 'cuda':
+        return 2                      # the host emulation's tiny "chip" (tests/emu/wl_backend_emu.h)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _CU_COUNT:
+        _CU_COUNT[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
+    return _CU_COUNT[idx]
+
+
 def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=0):
-    """`nlev` analysis levels in one launch (LL_j stay in LDS).  Returns (yl, [yh_0..]) or None when
-    the streaming kernel does not cover the configuration (caller goes level by level)."""
+    """`nlev` (1..3) analysis levels in ONE launch of the streaming kernel (one workgroup per plane, LL_j stay in LDS,
+    HBM traffic = the algorithmic minimum).  Returns (yl, [yh_0..]) or None when the kernel does not cover the
+    configuration (caller goes level by level).  strips: 0 = only when the planes alone fill the chip, 1 = force."""
     import ctypes
-    import os
     _check_tensor(x, 'x')
-    if x.dtype == torch.float64 or nlev < 1 or nlev > 4 or os.environ.get('WL_DISABLE_FUSED'):
+    N, C, H, W = x.shape
+    L = h_w_lo.numel()
+    # the launcher's envelope, checked here first so that a decline costs no allocation
+    if (x.dtype == torch.float64 or nlev < 1 or nlev > 3 or h_h_lo.numel() != L or L % 2 or L > 12
+            or (W * x.element_size()) % 16 or (nlev > 1 and mode not in (0, 1, 4)) or x.numel() == 0
+            or (strips == 0 and N * C < _num_cus(x.device)) or strips > 1):
         return None
     x = x.contiguous()
-    N, C, H, W = x.shape
     hwl, hwh, hhl, hhh = (_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi))
-    L = hwl.numel()
-    if hhl.numel() != L:
-        return None
     yh = []
     h, w = H, W
     for _ in range(nlev):
@@ -114,9 +163,8 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=0):
         yh.append(torch.empty((N, C, 3, h, w), dtype=x.dtype, device=x.device))
     yl = torch.empty((N, C, h, w), dtype=x.dtype, device=x.device)
     ptrs = (ctypes.c_void_p * nlev)(*[t.data_ptr() for t in yh])
-    rc = _backend().wl_dwt2d_analysis_fused(x.data_ptr(), yl.data_ptr(), ptrs, _DTYPES[x.dtype], N * C, H, W,
-                                            nlev, hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(),
-                                            hhh.data_ptr(), L, mode, strips, _stream(x))
+    rc = _call('wl_dwt2d_analysis_fused', x, x.data_ptr(), yl.data_ptr(), ptrs, _DTYPES[x.dtype], N * C, H, W, nlev,
+               hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(), hhh.data_ptr(), L, mode, strips, _stream(x))
     if rc == -3:
         return None
     _lib.check(rc, 'wl_dwt2d_analysis_fused')
@@ -141,7 +189,7 @@ def dtcwt_fwd1(x, h0, h1, mode, skip_hps=False):
     He, We = H + (H & 1), W + (W & 1)
     ll = torch.empty((N, C, He, We), dtype=x.dtype, device=x.device)
     highs = None if skip_hps else torch.empty((N, C, 6, He // 2, We // 2, 2), dtype=x.dtype, device=x.device)
-    rc = _backend().wl_dtcwt_fwd_level1(x.data_ptr(), ll.data_ptr(), None if skip_hps else highs.data_ptr(),
+    rc = _call('wl_dtcwt_fwd_level1', x, x.data_ptr(), ll.data_ptr(), None if skip_hps else highs.data_ptr(),
                                         _DTYPES[x.dtype], N * C, H, W, t0.data_ptr(), t0.numel(), t1.data_ptr(),
                                         t1.numel(), mode, _stream(x))
     _lib.check(rc, 'wl_dtcwt_fwd_level1')
@@ -157,7 +205,7 @@ def dtcwt_fwd2(x, h0a, h0b, h1a, h1b, skip_hps=False):
     He, We = H + (2 if H % 4 else 0), W + (2 if W % 4 else 0)
     ll = torch.empty((N, C, He // 2, We // 2), dtype=x.dtype, device=x.device)
     highs = None if skip_hps else torch.empty((N, C, 6, He // 4, We // 4, 2), dtype=x.dtype, device=x.device)
-    rc = _backend().wl_dtcwt_fwd_level2(x.data_ptr(), ll.data_ptr(), None if skip_hps else highs.data_ptr(),
+    rc = _call('wl_dtcwt_fwd_level2', x, x.data_ptr(), ll.data_ptr(), None if skip_hps else highs.data_ptr(),
                                         _DTYPES[x.dtype], N * C, H, W, ta.data_ptr(), tb.data_ptr(), tc.data_ptr(),
                                         td.data_ptr(), ta.numel(), _stream(x))
     _lib.check(rc, 'wl_dtcwt_fwd_level2')
@@ -176,11 +224,13 @@ def dtcwt_inv1(ll, highs, g0, g1, mode):
         N, C, H, W = ll.shape
     ps = rs = 0
     if ll is not None:
-        assert tuple(ll.shape) == (N, C, H, W), (ll.shape, (N, C, H, W))
+        if tuple(ll.shape) != (N, C, H, W):
+            raise ValueError('lowpass %s does not match the highpass size %s' % (tuple(ll.shape), (N, C, H, W)))
+        _same_device(ll, highs)
         ll, ps, rs = _ll_view(ll, (N, C))
     t0, t1 = _taps(g0, ref), _taps(g1, ref)
     y = torch.empty((N, C, H, W), dtype=ref.dtype, device=ref.device)
-    rc = _backend().wl_dtcwt_inv_level1(None if ll is None else ll.data_ptr(), ps, rs,
+    rc = _call('wl_dtcwt_inv_level1', ref, None if ll is None else ll.data_ptr(), ps, rs,
                                         None if highs is None else highs.data_ptr(), y.data_ptr(),
                                         _DTYPES[ref.dtype], N * C, H, W, t0.data_ptr(), t0.numel(), t1.data_ptr(),
                                         t1.numel(), mode, _stream(ref))
@@ -200,11 +250,13 @@ def dtcwt_inv2(ll, highs, g0a, g0b, g1a, g1b):
         N, C, h, w = ll.shape
     ps = rs = 0
     if ll is not None:
-        assert tuple(ll.shape) == (N, C, h, w), (ll.shape, (N, C, h, w))
+        if tuple(ll.shape) != (N, C, h, w):
+            raise ValueError('lowpass %s does not match the highpass size %s' % (tuple(ll.shape), (N, C, h, w)))
+        _same_device(ll, highs)
         ll, ps, rs = _ll_view(ll, (N, C))
     ta, tb, tc, td = (_taps(g, ref) for g in (g0a, g0b, g1a, g1b))
     y = torch.empty((N, C, 2 * h, 2 * w), dtype=ref.dtype, device=ref.device)
-    rc = _backend().wl_dtcwt_inv_level2(None if ll is None else ll.data_ptr(), ps, rs,
+    rc = _call('wl_dtcwt_inv_level2', ref, None if ll is None else ll.data_ptr(), ps, rs,
                                         None if highs is None else highs.data_ptr(), y.data_ptr(),
                                         _DTYPES[ref.dtype], N * C, h, w, ta.data_ptr(), tb.data_ptr(), tc.data_ptr(),
                                         td.data_ptr(), ta.numel(), _stream(ref))
@@ -225,7 +277,7 @@ def scat_fwd1(x, h0, h1, mode, magbias, combine_colour, save):
     if save:
         dx = torch.empty((N, 6, C, h2, w2), dtype=x.dtype, device=x.device)
         dy = torch.empty_like(dx)
-    rc = _backend().wl_scat_fwd_level1(x.data_ptr(), z.data_ptr(), None if dx is None else dx.data_ptr(),
+    rc = _call('wl_scat_fwd_level1', x, x.data_ptr(), z.data_ptr(), None if dx is None else dx.data_ptr(),
                                        None if dy is None else dy.data_ptr(), _DTYPES[x.dtype], N, C, H, W,
                                        t0.data_ptr(), t0.numel(), t1.data_ptr(), t1.numel(), mode, float(magbias),
                                        1 if combine_colour else 0, _stream(x))
@@ -240,9 +292,16 @@ def scat_bwd1(dz, drdx, drdy, h0, h1, mode, combine_colour):
     _check_tensor(dz, 'dz')
     dz = dz.contiguous()
     N, _, C, h2, w2 = drdx.shape
+    if drdy.shape != drdx.shape or drdx.dtype != dz.dtype or drdy.dtype != dz.dtype:
+        raise ValueError('scat_bwd1: drdx %s / drdy %s / dz dtype mismatch' % (tuple(drdx.shape), tuple(drdy.shape)))
+    want = (N, 9, h2, w2) if combine_colour else (N, 7, C, h2, w2)
+    if tuple(dz.shape) != want:
+        raise ValueError('scat_bwd1: dz %s, expected %s' % (tuple(dz.shape), want))
+    _same_device(dz, drdx, drdy)
+    drdx, drdy = drdx.contiguous(), drdy.contiguous()
     t0, t1 = _taps(h0, dz), _taps(h1, dz)
     dx = torch.empty((N, C, 2 * h2, 2 * w2), dtype=dz.dtype, device=dz.device)
-    rc = _backend().wl_scat_bwd_level1(dz.data_ptr(), drdx.data_ptr(), drdy.data_ptr(), dx.data_ptr(), _DTYPES[dz.dtype],
+    rc = _call('wl_scat_bwd_level1', dz, dz.data_ptr(), drdx.data_ptr(), drdy.data_ptr(), dx.data_ptr(), _DTYPES[dz.dtype],
                                        N, C, 2 * h2, 2 * w2, t0.data_ptr(), t0.numel(), t1.data_ptr(), t1.numel(), mode,
                                        1 if combine_colour else 0, _stream(dz))
     if rc == -3:   # WL_ERR_UNSUPPORTED

@@ -4,6 +4,7 @@ ONE fused kernel (level-1 DTCWT + 2x2 LL average + smoothed magnitude, written s
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 from .. import ops
 from ..dwt.lowlevel import int_to_mode, mode_to_int   # noqa: F401  (re-exported like upstream)
@@ -25,6 +26,7 @@ class ScatLayerj1_f(Function):
         return Z
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dZ):
         dX = None
         if ctx.needs_input_grad[0]:

@@ -24,3 +24,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _reset_engine_options():
+    yield
+    try:
+        import _opts
+        _opts.set_generic(0)
+    except Exception:
+        pass

@@ -16,6 +16,8 @@
 
 // a deliberately tiny "chip" so that persistent kernels walk several tiles per workgroup in the tests
 static int wl_num_cus() { return 2; }
+static thread_local const char* wl_last_kernel_ptr = "";
+static const char* wl_last_kernel_name() { return wl_last_kernel_ptr; }
 
 struct WlEmuBlock {
     ucontext_t main;
@@ -24,6 +26,8 @@ struct WlEmuBlock {
     std::vector<char> state;        // 0 ready, 1 at barrier, 2 at shuffle, 3 done
     std::vector<float> shfl_in, shfl_out;
     std::vector<int> shfl_src;      // source lane (0..63) of a pending shuffle, -1 = the lane below (wl_shfl_up1)
+    struct Dma { char* dst; const char* src; };
+    std::vector<std::vector<Dma> > dma;   // per lane: asynchronous global->LDS copies not yet released by wl_wait_vm
     int cur;
     WlEmuBlock() : cur(0) {}
     ~WlEmuBlock() { for (size_t i = 0; i < stacks.size(); ++i) free(stacks[i]); }
@@ -45,6 +49,22 @@ static float wl_emu_shuffle(float v, int src) {
     b->state[me] = 2;
     swapcontext(&b->fib[me], &b->main);
     return b->shfl_out[me];
+}
+// LDS-DMA: the copy lands only when the issuing lane's wl_wait_vm<N> releases it (oldest first)
+void wl_dma16(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on) {
+    WlEmuBlock* b = wl_emu_cur_block;
+    WlEmuBlock::Dma d;
+    d.dst = lane_on ? ctx.smem + lds_off + 16 * (ctx.tid & 63) : nullptr;   // off lanes keep the per-wave count
+    d.src = (const char*)gsrc;
+    b->dma[b->cur].push_back(d);
+}
+void wl_emu_wait_vm(int n) {
+    WlEmuBlock* b = wl_emu_cur_block;
+    std::vector<WlEmuBlock::Dma>& q = b->dma[b->cur];
+    while ((int)q.size() > n) {
+        if (q.front().dst) memcpy(q.front().dst, q.front().src, 16);
+        q.erase(q.begin());
+    }
 }
 float wl_shfl_up1(float v) { return wl_emu_shuffle(v, -1); }
 float wl_shfl(float v, int src_lane) { return wl_emu_shuffle(v, src_lane & 63); }
@@ -68,7 +88,9 @@ static void wl_emu_entry(unsigned lo, unsigned hi) {
     ctx.smem = job->smem;
     ctx.sync_fn = wl_emu_sync;
     ctx.sync_arg = b;
+    ctx.lds_base = 0;
     K::run(*job->args, ctx);
+    if (!b->dma[ctx.tid].empty()) abort();   // a wave ended with LDS-DMA loads in flight (they would land in another workgroup's LDS)
     b->state[ctx.tid] = 3;
     // returning follows uc_link back to the scheduler
 }
@@ -77,6 +99,7 @@ template <typename K>
 static int wl_launch(const typename K::Args& a, int64_t nblocks, size_t lds, void* /*stream*/) {
     if (nblocks <= 0) return 0;
     if (lds > 160 * 1024) return -2;
+    wl_last_kernel_ptr = __PRETTY_FUNCTION__;
     const int nt = K::kThreads;
     const size_t kStack = 256 * 1024;
 #pragma omp parallel
@@ -88,6 +111,7 @@ static int wl_launch(const typename K::Args& a, int64_t nblocks, size_t lds, voi
         blk.shfl_in.resize(nt);
         blk.shfl_out.resize(nt);
         blk.shfl_src.resize(nt);
+        blk.dma.resize(nt);
         for (int i = 0; i < nt; ++i) blk.stacks[i] = (char*)malloc(kStack);
         char* smem = (char*)aligned_alloc(64, ((lds + 63) / 64 + 1) * 64);
         WlEmuJob<K> job;

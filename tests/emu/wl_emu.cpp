@@ -1,3 +1,4 @@
 // libwl_emu.so: the same kernel bodies and C ABI as libwavelets_hip.so, executed on the host.
 #include "wl_backend_emu.h"
 #include "../../pytorch_wavelets_amd/csrc/wl_api.inc"
+#include "../../pytorch_wavelets_amd/csrc/wl_rows_api.inc"

@@ -1,6 +1,8 @@
 """CPU tests: DTCWT / ScatLayer modules and autograd Functions on the host emulation of the kernels,
 against the reference's golden vectors (float64 arithmetic)."""
 import pytest
+
+import _opts
 import torch
 
 import _dtcwt_cases as D
@@ -53,7 +55,7 @@ def test_scat_backward_fused_equals_composed(monkeypatch):
     """The one-launch backward against prologue-in-torch + level-1 inverse (the fallback for other taps)."""
     grads = {}
     for generic in ('0', '1'):
-        monkeypatch.setenv('WL_GENERIC_ONLY', generic)
+        _opts.set_generic(generic)
         for comb in (False, True):
             torch.manual_seed(3)
             x = torch.randn(2, 3, 33, 30, dtype=torch.float32, requires_grad=True)
@@ -101,7 +103,7 @@ def test_specialised_equals_generic_on_random_shapes(seed, monkeypatch):
         x = torch.tensor(rng.randn(1, 2, H, W), dtype=torch.float32)
         out = {}
         for generic in ('0', '1'):
-            monkeypatch.setenv('WL_GENERIC_ONLY', generic)
+            _opts.set_generic(generic)
             xfm = pw.DTCWTForward(biort=biort, qshift=qshift, J=J)
             ifm = pw.DTCWTInverse(biort=biort, qshift=qshift)
             yl, yh = xfm(x)

@@ -3,6 +3,8 @@ vectors of the reference; 1e-5 relative (max-norm) in fp32.  Modelled on the ref
 tests/test_dtcwt.py (:86-346, :350-413) and tests/test_scatnet_fwd.py (:9-58)."""
 import numpy as np
 import pytest
+
+import _opts
 import torch
 
 import _dtcwt_cases as D
@@ -87,7 +89,7 @@ def test_specialised_equals_generic_random_shapes_gpu(seed, monkeypatch):
         x = torch.tensor(rng.randn(2, 3, H, W), dtype=torch.float32, device=DEV)
         out = {}
         for generic in ('0', '1'):
-            monkeypatch.setenv('WL_GENERIC_ONLY', generic)
+            _opts.set_generic(generic)
             xfm = pw.DTCWTForward(biort=biort, qshift=qshift, J=J).to(DEV)
             ifm = pw.DTCWTInverse(biort=biort, qshift=qshift).to(DEV)
             yl, yh = xfm(x)

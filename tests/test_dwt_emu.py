@@ -4,6 +4,8 @@ golden vectors.  (The real parity tests are the -m gpu ones; these keep the Pyth
 launch-geometry code and every kernel's indexing honest without a GPU.)"""
 import numpy as np
 import pytest
+
+import _opts
 import torch
 
 import _golden as G
@@ -89,24 +91,60 @@ def test_mode_errors():
                 pw.DWTForward(mode=bad)(torch.randn(1, 1, 8, 8))
 
 
-@pytest.mark.parametrize('name', ['dwt_01', 'dwt_05', 'dwt_06', 'dwt_09', 'dwt_14', 'dwt_10'])
-@pytest.mark.parametrize('strips', [0, 3])
-def test_streaming_kernels_fp32_on_emulator(name, strips):
-    """The streaming kernels (single level and 3-level fused, with and without splitting planes into
-    strips) through their C-ABI entry point, against the goldens."""
+def _fused(x, wave, mode, J):
     from pytorch_wavelets_amd import ops, filters
     from pytorch_wavelets_amd.dwt import lowlevel
-    meta, g = G.INDEX[name], G.load(name)
-    h0, h1 = filters.dwt_analysis_taps(meta['wave'])
+    h0, h1 = filters.dwt_analysis_taps(wave)
     th = [torch.tensor(v, dtype=torch.float32) for v in (h0, h1, h0, h1)]
-    x = torch.tensor(g['x'])
     with emu_backend.emulated():
-        res = ops.afb2d_fused(x, *th, lowlevel.mode_to_int(meta['mode']), meta['J'], strips=strips)
+        return ops.afb2d_fused(x, *th, lowlevel.mode_to_int(mode), J, strips=1)
+
+
+@pytest.mark.parametrize('name', ['dwt_00', 'dwt_01', 'dwt_02', 'dwt_04', 'dwt_09'])
+def test_streaming_kernel_fp32_goldens_on_emulator(name):
+    """The streaming multi-level analysis kernel (wl_dwt2d_analysis_fused: one workgroup per plane, LL_j in LDS
+    rings, LDS-DMA row loads released by counted waits) against the reference goldens - incl. the benchmark geometry
+    512x512 J=3 db4 symmetric (dwt_02)."""
+    meta, g = G.INDEX[name], G.load(name)
+    res = _fused(torch.tensor(g['x']), meta['wave'], meta['mode'], meta['J'])
     assert res is not None, 'the streaming kernel was expected to cover this case'
     yl, yh = res
     assert G.relerr(yl.numpy(), g, 'yl') < 1e-5
     for j in range(meta['J']):
         assert G.relerr(yh[j].numpy(), g, 'yh%d' % j) < 1e-5
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_streaming_kernel_vs_oracle_random_shapes(seed):
+    """Random heights (odd ones too), widths in multiples of four up to the ten-wave limit, every supported tap count
+    and mode (multi-level: zero / symmetric / reflect; single level: also periodic / periodization), fp32 and fp16."""
+    from oracle import wavelet_oracle as wo
+    from pytorch_wavelets_amd import filters
+    rng = np.random.RandomState(500 + seed)
+    wave = ['haar', 'db2', 'db3', 'db4', 'db5', 'db6'][seed]
+    h0, h1 = filters.dwt_analysis_taps(wave)
+    L = len(h0)
+    for mode in ('zero', 'symmetric', 'reflect', 'periodic', 'periodization'):
+        J = 1 if mode in ('periodic', 'periodization') else int(rng.randint(1, 4))
+        H = int(rng.randint(max(2, L), 90))
+        W = 4 * int(rng.randint(max(2, (L + 3) // 4), [20, 40, 90, 150][seed % 4]))
+        x = torch.tensor(rng.randn(1, 2, H, W), dtype=torch.float32)
+        oyl, oyh = wo.dwt_forward(x.double().numpy(), J, h0, h1, h0, h1, mode)
+        res = _fused(x, wave, mode, J)
+        if res is None:   # the launcher may decline (a level shorter than the filter); never silently wrong
+            assert min(H, W) < 2 ** (J - 1) * (2 * L), (wave, mode, H, W, J)
+            continue
+        yl, yh = res
+        for got, want in zip([yl] + list(yh), [oyl] + list(oyh)):
+            assert got.shape == want.shape
+            assert np.abs(got.numpy() - want).max() <= 1e-5 * np.abs(want).max(), (wave, mode, H, W, J)
+    # fp16 storage (fp32 accumulate): rows in multiples of eight
+    x = torch.tensor(rng.randn(1, 2, 40, 8 * int(rng.randint(3, 20))), dtype=torch.float32).half()
+    oyl, oyh = wo.dwt_forward(x.double().numpy(), 2, h0, h1, h0, h1, 'symmetric')
+    res = _fused(x, wave, 'symmetric', 2)
+    assert res is not None
+    for got, want in zip([res[0]] + list(res[1]), [oyl] + list(oyh)):
+        assert np.abs(got.float().numpy() - want).max() <= 3e-3 * np.abs(want).max()
 
 
 @pytest.mark.parametrize('name', ['dwt_01', 'dwt_03', 'dwt_06', 'dwt_07', 'dwt_08', 'dwt_14', 'dwt_15'])
@@ -139,7 +177,7 @@ def test_tile_equals_generic_on_random_shapes(seed, monkeypatch):
             x = torch.tensor(rng.randn(1, 2, H, W), dtype=torch.float32)
             out = {}
             for generic in ('0', '1'):
-                monkeypatch.setenv('WL_GENERIC_ONLY', generic)
+                _opts.set_generic(generic)
                 xfm = pw.DWTForward(J=J, wave=wave, mode=mode)
                 ifm = pw.DWTInverse(wave=wave, mode=mode)
                 with emu_backend.emulated():
@@ -166,7 +204,7 @@ def test_strided_input_and_padded_inner_ll(monkeypatch):
     big = torch.randn(2, 3, 70, 150)
     x = big[..., :131]                       # unit column stride, row pitch 150, uniform plane stride
     for generic in ('0', '1'):
-        monkeypatch.setenv('WL_GENERIC_ONLY', generic)
+        _opts.set_generic(generic)
         for mode in ('symmetric', 'periodization', 'zero'):
             outs = []
             for pad, inp in ((False, x.contiguous()), (True, x)):
