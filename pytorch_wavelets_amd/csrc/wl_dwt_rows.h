@@ -24,6 +24,18 @@
 
 #define WL_ROWS_MAXLEV 3
 #define WL_ROWS_WAVES 11
+// WL_ROWS_ABLATE (tools/ab builds only, never defined in the product): 1 = no global stores, 2 = no DMA loads
+#ifndef WL_ROWS_ABLATE
+#define WL_ROWS_ABLATE 0
+#endif
+#if (WL_ROWS_ABLATE & 8) && defined(__HIPCC__)
+#define WL_TICK() __builtin_readcyclecounter()
+#else
+#define WL_TICK() 0ull
+#endif
+#ifndef WL_ROWS_DEPTH
+#define WL_ROWS_DEPTH 3
+#endif
 
 struct WlRowsLevel {
     int Hs, Ws;         // source rows / cols of this level
@@ -74,7 +86,7 @@ struct WlRowsSched {
     }
 };
 
-template <typename T, int LT, int PPR, int D = 3>
+template <typename T, int LT, int PPR, int D = WL_ROWS_DEPTH>
 struct WlAfbRows {
     typedef WlRowsArgs<T> Args;
     static const int kThreads = 64 * WL_ROWS_WAVES;
@@ -104,17 +116,27 @@ struct WlAfbRows {
 #pragma unroll
                 for (int p = 0; p < PPR; ++p) {
                     const int byte = (p * 64 + lane) * 16;
-                    wl_dma16(ctx, dst + p * 1024, grow + byte, byte < row_bytes);
+                    if (!(WL_ROWS_ABLATE & 2)) wl_dma16(ctx, dst + p * 1024, grow + byte, byte < row_bytes);
                 }
             }
         };
         for (int h = 0; h < D; ++h) issue(h);
+        unsigned long long tw = 0, tb = 0, ti = 0;
         for (int hb = 0; hb < a.nhb; ++hb) {
-            if (hb < nhb0) wl_wait_vm<(D - 1) * NL>();   // the rows of this half-batch have landed
+            const unsigned long long c0 = WL_TICK();
+            if (hb < nhb0 && !(WL_ROWS_ABLATE & 2)) wl_wait_vm<(D - 1) * NL>();   // the rows of this half-batch have landed
+            const unsigned long long c1 = WL_TICK();
             ctx.sync();
+            const unsigned long long c2 = WL_TICK();
             if (hb < nhb0) issue(hb + D);                // its slot was consumed in half-batch hb-1
+            const unsigned long long c3 = WL_TICK();
+            tw += c1 - c0; tb += c2 - c1; ti += c3 - c2;
         }
         wl_wait_vm<0>();   // nothing may land after the workgroup has released its LDS
+        if ((WL_ROWS_ABLATE & 8) && lane == 0) {
+            T* o = a.ll + (size_t)plane * a.ll_ps;
+            o[8] = (T)(float)(tw >> 6); o[9] = (T)(float)(tb >> 6); o[10] = (T)(float)(ti >> 6);
+        }
     }
 
     // ---- compute waves of level j -----------------------------------------------------------------------------
@@ -183,8 +205,13 @@ struct WlAfbRows {
 
         WlRowsSched sc;
         sc.init();
+        unsigned long long tb = 0, tf = 0, ts = 0, c3 = WL_TICK();
         for (int hb = 0; hb < a.nhb; ++hb) {
+            const unsigned long long c0 = WL_TICK();
+            ts += c0 - c3;
             ctx.sync();
+            const unsigned long long c1 = WL_TICK();
+            tb += c1 - c0;
             const int n = wl_uniform(sc.feeds_now(a, j, LT));
             for (int i = 0; i < n; ++i) {
                 const int f = sc.fed[j] + i;
@@ -230,23 +257,33 @@ struct WlAfbRows {
                         }
                         const unsigned ob = ((unsigned)orow * (unsigned)g.Kw + (unsigned)k) * (unsigned)sizeof(T);
                         const unsigned bpb = bplane * (unsigned)sizeof(T);
+                        const bool st = !(WL_ROWS_ABLATE & 1) || (lh + hl + hh + ll == 12345.f);   // product: always true
+                        if (st) {
                         *reinterpret_cast<T*>(hp + ob) = (T)lh;                // W-lo / H-hi
                         *reinterpret_cast<T*>(hp + (bpb + ob)) = (T)hl;        // W-hi / H-lo
                         *reinterpret_cast<T*>(hp + (2 * bpb + ob)) = (T)hh;    // W-hi / H-hi
+                        }
                         if (last) {
-                            *reinterpret_cast<T*>(llp + ((unsigned)orow * (unsigned)a.ll_rs + (unsigned)k) * (unsigned)sizeof(T)) = (T)ll;
+                            if (st)
+                                *reinterpret_cast<T*>(llp + ((unsigned)orow * (unsigned)a.ll_rs + (unsigned)k) * (unsigned)sizeof(T)) = (T)ll;
                         } else {
                             *reinterpret_cast<T*>(smem + (nring + (orow & rmask) * npitch + k * (int)sizeof(T))) = (T)ll;
                         }
                     }
                 }
             }
+            c3 = WL_TICK();
+            tf += c3 - c1;
             // advance the levels this wave depends on (same arithmetic in every wave: the schedule is shared)
             int nn[WL_ROWS_MAXLEV];
 #pragma unroll
             for (int q = 0; q < WL_ROWS_MAXLEV; ++q) nn[q] = q < j ? sc.feeds_now(a, q, LT) : (q == j ? n : 0);
 #pragma unroll
             for (int q = 0; q < WL_ROWS_MAXLEV; ++q) sc.fed[q] = wl_uniform(sc.fed[q] + nn[q]);
+        }
+        if ((WL_ROWS_ABLATE & 8) && j == 0 && k == 64) {   // second level-1 wave (an interior one)
+            T* o = a.ll + (size_t)plane * a.ll_ps;
+            o[0] = (T)(float)(tb >> 6); o[1] = (T)(float)(tf >> 6); o[2] = (T)(float)(ts >> 6);
         }
     }
 
