@@ -4,18 +4,27 @@
 // two small launches, and its 259-float band rows leave in 256-byte pieces that never line up with cache lines.  Here
 //   * every input row is read from HBM exactly once, as whole 1 KiB wave-wide LDS-DMA loads (global_load_lds_dwordx4)
 //     issued D half-batches ahead by a dedicated loader wave - no VGPRs, no LDS write instructions, no halo re-reads;
+//   * the boundary extension along W is materialised once per row as a few halo cells next to the row in LDS (the
+//     loader patches them after the row has landed; for LL_j rows the producing lane writes them), so EVERY lane
+//     reads its L row-filter samples as one base address + constant offsets;
 //   * a lane owns ONE output column of its level and keeps the L-row sliding window of that column's row-filtered
-//     (lo,hi) pair in registers: per pair of new source rows it runs the row filter (samples straight from the LDS
-//     ring) and the column filter (registers only) - one LDS crossing per sample, no intermediate planes, one
-//     barrier per four input rows;
+//     (lo,hi) pair in registers (a rotating buffer: no register shifts): per pair of new source rows it runs the row
+//     filter (samples straight from the LDS ring) and the column filter (registers only) - one LDS crossing per
+//     sample, no intermediate planes, one barrier per four input rows;
 //   * LL_j rows go to a small LDS ring that the waves of level j+1 consume a few rows behind - LL_1 .. LL_{J-1}
 //     never touch HBM; HBM traffic = x in + yl, yh[j] out = the algorithmic minimum of SURVEY.md 8(d);
 //   * every band row of every level is written by consecutive lanes of consecutive waves within one half-batch, so
 //     the partial cache lines at its ends are completed in the same L2 a few hundred cycles later.
+// The kernel is bound by INSTRUCTION ISSUE, not by arithmetic: a SIMD issues about one instruction per four cycles
+// for all of its waves together (rocprofv3: SQ_ACTIVE_INST_ANY ~ 90 % of the kernel's cycles in the first version).
+// Hence: v_pk_fma_f32 on (lo,hi) pairs with the broadcast sample picked by op_sel (half the instructions of scalar
+// FMAs), taps in scalar registers, the schedule as a host-built table instead of per-wave scalar arithmetic (that
+// alone was 57 % of all instructions), and the roles dealt out so that every SIMD carries the same load.
 // Roles are per WAVE (wave-uniform branches, each role has its own lean body): level-1 / level-2 / level-3 compute
-// waves and the loader.  All waves follow the same deterministic schedule (WlRowsSched): per half-batch level 1
-// consumes 4 extended input rows (2 feeds), level j+1 consumes whatever LL_j rows were complete at the barrier.
-// The launcher simulates the same schedule on the host and refuses geometries whose rings would be overrun.
+// waves and the loader.  All waves follow the same deterministic schedule: per half-batch level 1 consumes 4
+// extended input rows (2 feeds), level j+1 consumes whatever LL_j rows were complete at the barrier.  The launcher
+// simulates it on the host (WlRowsSched), refuses geometries whose rings would be overrun, and hands the result to
+// the kernel as a table.
 //
 // Restates DWTForward.forward's level loop (reference dwt/transform2d.py:63-74) = J x AFB2D.forward
 // (dwt/lowlevel.py:336-347) = 2J x afb1d (:91-172): filter along W, then along H, per level.
@@ -24,7 +33,9 @@
 
 #define WL_ROWS_MAXLEV 3
 #define WL_ROWS_WAVES 11
-// WL_ROWS_ABLATE (tools/ab builds only, never defined in the product): 1 = no global stores, 2 = no DMA loads
+#define WL_ROWS_MAXHB 1536      // half-batches the schedule table (kernel argument) can hold
+// WL_ROWS_ABLATE (tools/build_ab.sh builds only, never defined in the product): 1 = no global stores, 2 = no DMA
+// loads, 8 = in-kernel cycle counters written over a few LL samples
 #ifndef WL_ROWS_ABLATE
 #define WL_ROWS_ABLATE 0
 #endif
@@ -37,12 +48,41 @@
 #define WL_ROWS_DEPTH 3
 #endif
 
+// acc += tap * s.x  /  acc += tap * s.y  on (lo,hi) pairs: ONE v_pk_fma_f32, the broadcast half chosen by op_sel
+#if defined(__HIPCC__)
+WL_DEV void wl_pk_fma_x(wl_v2& acc, wl_v2 tap, wl_v2 s) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(tap), "v"(s));
+}
+WL_DEV void wl_pk_fma_y(wl_v2& acc, wl_v2 tap, wl_v2 s) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(tap), "v"(s));
+}
+WL_DEV wl_v2 wl_pk_mul_x(wl_v2 tap, wl_v2 s) {
+    wl_v2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "s"(tap), "v"(s));
+    return r;
+}
+WL_DEV wl_v2 wl_pk_mul_y(wl_v2 tap, wl_v2 s) {
+    wl_v2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "s"(tap), "v"(s));
+    return r;
+}
+WL_DEV wl_v2 wl_uniform_v2(wl_v2 v) { return wl_v2{wl_uniform_f(v.x), wl_uniform_f(v.y)}; }
+#else
+inline void wl_pk_fma_x(wl_v2& acc, wl_v2 tap, wl_v2 s) { acc.x = __builtin_fmaf(tap.x, s.x, acc.x); acc.y = __builtin_fmaf(tap.y, s.x, acc.y); }
+inline void wl_pk_fma_y(wl_v2& acc, wl_v2 tap, wl_v2 s) { acc.x = __builtin_fmaf(tap.x, s.y, acc.x); acc.y = __builtin_fmaf(tap.y, s.y, acc.y); }
+inline wl_v2 wl_pk_mul_x(wl_v2 tap, wl_v2 s) { return wl_v2{tap.x * s.x, tap.y * s.x}; }
+inline wl_v2 wl_pk_mul_y(wl_v2 tap, wl_v2 s) { return wl_v2{tap.x * s.y, tap.y * s.y}; }
+inline wl_v2 wl_uniform_v2(wl_v2 v) { return v; }
+#endif
+
 struct WlRowsLevel {
     int Hs, Ws;         // source rows / cols of this level
     int Kh, Kw;         // output rows / cols
     int ring_off;       // LDS byte offset of this level's SOURCE ring (level 0: the input ring)
-    int ring_pitch;     // bytes per ring row; the element at column Ws of every ring row is a permanent zero
-    int wave0, nwaves;  // compute waves of this level: wave0 .. wave0+nwaves-1, 64 columns each
+    int ring_pitch;     // bytes per ring row: [left halo | Ws samples | right halo]
+    int pad;            // byte offset of sample 0 inside a ring row (multiple of 16)
+    int hl, hr;         // halo cells left / right of the samples (boundary extension along W)
+    int nwaves;         // 64-column chunks of this level (each chunk is one compute wave)
 };
 
 template <typename T>
@@ -60,13 +100,20 @@ struct WlRowsArgs {
     int nhb;            // half-batches (= barriers of the main loop) until every level has finished
     int ring_rows;      // rows of the LL rings (power of two)
     int zero_off;       // LDS byte offset of an all-zero row (zero padding above / below the plane)
-    int zero_bytes;
-    int loader_wave;
+    int lds_bytes;
+    // role of every wave: level (0..nlev-1) and first column of its 64-column chunk; -1 = loader, -2 = spare.  Waves w
+    // and w+4 share a SIMD, so the launcher deals the roles out for equal instruction load per SIMD.
+    signed char role_level[WL_ROWS_WAVES];
+    short role_col0[WL_ROWS_WAVES];
     WlRowsLevel g[WL_ROWS_MAXLEV];
+    // the schedule, simulated on the host (WlRowsSched): one byte per half-batch, bits 2j+1:2j = feeds of level j.
+    // Looked up by every wave instead of being recomputed: the scalar instructions of the schedule arithmetic were
+    // 57 % of all instructions issued by the first version of this kernel (rocprofv3 SQ_INSTS_SALU).
+    unsigned sched[WL_ROWS_MAXHB / 4];
 };
 
-// The schedule every wave (and the launcher) steps through: fed[j] = feeds level j has consumed.  A feed is one pair
-// of extended source rows (2f+base, 2f+base+1); the first (L-2)/2 feeds of a level only fill its window.
+// The schedule the LAUNCHER steps through to fill WlRowsArgs::sched: fed[j] = feeds level j has consumed.  A feed is
+// one pair of extended source rows (2f+base, 2f+base+1); the first (L-2)/2 feeds of a level only fill its window.
 struct WlRowsSched {
     int fed[WL_ROWS_MAXLEV];
     WL_HD void init() { for (int j = 0; j < WL_ROWS_MAXLEV; ++j) fed[j] = 0; }
@@ -81,8 +128,7 @@ struct WlRowsSched {
         const int e = a.base + 2 * fed[j];
         const bool ok0 = left > 0 && wl_ext1(e, Hs, a.ext) < avail && wl_ext1(e + 1, Hs, a.ext) < avail;
         const bool ok1 = left > 1 && wl_ext1(e + 2, Hs, a.ext) < avail && wl_ext1(e + 3, Hs, a.ext) < avail;
-        const int n = ok0 ? (ok1 ? 2 : 1) : 0;
-        return n;
+        return ok0 ? (ok1 ? 2 : 1) : 0;
     }
 };
 
@@ -94,29 +140,51 @@ struct WlAfbRows {
     static const int NL = 4 * PPR;         // DMA instructions per half-batch (4 rows x PPR pieces of 1 KiB)
     static const int WARM = (LT - 2) / 2;  // feeds that only fill the window
     static const int NSLOT = D + 1;        // half-batch slots of the input ring
+    static const int SZ = (int)sizeof(T);
+    static const int NPH = LT / 2;         // feed phases of the rotating window
     static_assert((D - 1) * NL < 64, "prefetch distance exceeds the vmcnt range");
+    static_assert(NPH >= 1 && NPH <= 6, "feed_any covers up to six phases");
 
     // ---- loader wave ------------------------------------------------------------------------------------------
     static WL_DEV void loader(const Args& a, const WlCtx& ctx, int64_t plane, int lane) {
         const WlRowsLevel& g = a.g[0];
         const char* xp = reinterpret_cast<const char*>(a.x + (size_t)plane * a.x_ps);
-        const int row_bytes = g.Ws * (int)sizeof(T);
+        const int row_bytes = g.Ws * SZ;
+        const int row_stride = a.x_rs * SZ;
         const int nhb0 = (g.Kh + WARM + 1) / 2;                  // half-batches in which level 1 runs
         const int e_last = a.base + 2 * (g.Kh + WARM) - 1;       // last extended row level 1 consumes
+        const int ring = g.ring_off, pitch = g.ring_pitch, pad = g.pad, Hs = g.Hs, base = a.base, ext = a.ext;
+        // halo cells of the 4 rows of a slot: item = (row r, cell c); a lane handles items lane and lane + 64
+        const int NH = g.hl + g.hr;
+        int hdst[2], hsrc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int it = lane + 64 * u;
+            hdst[u] = hsrc[u] = -1;
+            if (ext != WL_EXT_ZERO && it < 4 * NH) {
+                const int r = it / NH, c = it - r * NH;
+                const int e = c < g.hl ? c - g.hl : g.Ws + (c - g.hl);
+                const int s = wl_ext(e, g.Ws, ext);
+                hdst[u] = r * pitch + pad + e * SZ;
+                hsrc[u] = s < 0 ? -1 : r * pitch + pad + s * SZ;
+            }
+        }
         auto issue = [&](int h) {
-            const int slot = h % NSLOT;
+            const int slot = ring + (h % NSLOT) * 4 * pitch + pad;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int e = a.base + 4 * h + r;
+                int e = base + 4 * h + r;
                 e = e < e_last ? e : e_last;
-                int src = wl_ext(e, g.Hs, a.ext);
-                src = src < 0 ? 0 : src;                          // zero rows: a dummy row keeps the DMA count exact
-                const char* grow = xp + (size_t)src * a.x_rs * sizeof(T);
-                const unsigned dst = (unsigned)(g.ring_off + (slot * 4 + r) * g.ring_pitch);
+                int src = e;
+                if ((unsigned)e >= (unsigned)Hs) {               // above / below the plane (rare): full extension rule
+                    src = wl_ext(e, Hs, ext);
+                    src = src < 0 ? 0 : src;                     // zero rows: a dummy row keeps the DMA count exact
+                }
+                const char* grow = xp + (size_t)src * row_stride;
 #pragma unroll
                 for (int p = 0; p < PPR; ++p) {
                     const int byte = (p * 64 + lane) * 16;
-                    if (!(WL_ROWS_ABLATE & 2)) wl_dma16(ctx, dst + p * 1024, grow + byte, byte < row_bytes);
+                    if (!(WL_ROWS_ABLATE & 2)) wl_dma16(ctx, (unsigned)(slot + r * pitch + p * 1024), grow + byte, byte < row_bytes);
                 }
             }
         };
@@ -124,7 +192,13 @@ struct WlAfbRows {
         unsigned long long tw = 0, tb = 0, ti = 0;
         for (int hb = 0; hb < a.nhb; ++hb) {
             const unsigned long long c0 = WL_TICK();
-            if (hb < nhb0 && !(WL_ROWS_ABLATE & 2)) wl_wait_vm<(D - 1) * NL>();   // the rows of this half-batch have landed
+            if (hb < nhb0) {
+                if (!(WL_ROWS_ABLATE & 2)) wl_wait_vm<(D - 1) * NL>();   // the rows of this half-batch have landed
+                char* slot = ctx.smem + ring + (hb % NSLOT) * 4 * pitch;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (hdst[u] >= 0) *reinterpret_cast<T*>(slot + hdst[u]) = hsrc[u] < 0 ? (T)0 : *reinterpret_cast<const T*>(slot + hsrc[u]);
+            }
             const unsigned long long c1 = WL_TICK();
             ctx.sync();
             const unsigned long long c2 = WL_TICK();
@@ -140,148 +214,179 @@ struct WlAfbRows {
     }
 
     // ---- compute waves of level j -----------------------------------------------------------------------------
-    // FAST = 1: no lane of the wave touches the boundary extension and the sample origin 2k+base is even, so the L
-    // samples of a row are one per-lane base address + constant offsets, read two elements at a time.
-    // All arithmetic is plain scalar-tap FMAs (taps in SGPRs, four independent accumulator chains): v_pk_fma_f32 has
-    // no throughput advantage on gfx950 and costs a register pair per broadcast sample.
-    template <int FAST, int j>
-    static WL_DEV void compute(const Args& a, const WlCtx& ctx, int64_t plane, int wave, int lane) {
+    struct Lane {               // per lane
+        wl_v2 win[LT];          // row-filtered (lo,hi) of the last L extended rows of column k, as a ROTATING buffer:
+                                //   feed phase PH writes slots 2PH, 2PH+1; tap t of the column filter reads slot 2PH+2+t
+        unsigned ob;            // byte offset of this lane's next output sample inside a band plane
+        int off;                // byte offset of its first row-filter sample inside a ring row
+        int ndst, hx0, hx1;     // next level's ring row: its LL sample and the halo cells it is the source of
+    };
+    struct Role {               // per wave (wave-uniform)
+        wl_v2 tw[LT], th[LT];   // (lo,hi) tap pairs along W / along H
+        char* hp0; char* hp1; char* hp2; char* llp;   // band planes of this (plane, level); LL plane of the last level
+        unsigned rowb, llrowb, kb;
+        int nring, npitch, rmask;
+        bool last, halo;
+    };
+
+    // one feed: row-filter the two new source rows (LDS byte offsets row0/row1, wave-uniform) into the window, and -
+    // once the window is full - column-filter it into one sample of each of the four sub-bands.
+    template <int PH>
+    static WL_DEV void feed(Lane& L, const Role& R, char* smem, int row0, int row1, bool emit, int orow) {
+        const char* p0 = smem + (row0 + L.off);
+        const char* p1 = smem + (row1 + L.off);
+        wl_v2 s0[LT / 2], s1[LT / 2];
+        if (SZ == 4) {
+#pragma unroll
+            for (int u = 0; u < LT / 2; ++u) {
+                const wl_f2 t0 = *reinterpret_cast<const wl_f2*>(p0 + 8 * u);
+                const wl_f2 t1 = *reinterpret_cast<const wl_f2*>(p1 + 8 * u);
+                s0[u] = wl_v2{t0.x, t0.y}; s1[u] = wl_v2{t1.x, t1.y};
+            }
+        } else {
+            typedef T Pair2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int u = 0; u < LT / 2; ++u) {
+                const Pair2 t0 = *reinterpret_cast<const Pair2*>(p0 + 2 * SZ * u);
+                const Pair2 t1 = *reinterpret_cast<const Pair2*>(p1 + 2 * SZ * u);
+                s0[u] = wl_v2{(float)t0.x, (float)t0.y}; s1[u] = wl_v2{(float)t1.x, (float)t1.y};
+            }
+        }
+        // four independent chains (even / odd taps of either row): dependent v_pk_fma_f32 need a wait state in between
+        wl_v2 a0 = wl_pk_mul_x(R.tw[0], s0[0]), a1 = wl_pk_mul_x(R.tw[0], s1[0]);
+        wl_v2 b0 = wl_pk_mul_y(R.tw[1], s0[0]), b1 = wl_pk_mul_y(R.tw[1], s1[0]);
+#pragma unroll
+        for (int u = 1; u < LT / 2; ++u) {
+            wl_pk_fma_x(a0, R.tw[2 * u], s0[u]);
+            wl_pk_fma_x(a1, R.tw[2 * u], s1[u]);
+            wl_pk_fma_y(b0, R.tw[2 * u + 1], s0[u]);
+            wl_pk_fma_y(b1, R.tw[2 * u + 1], s1[u]);
+        }
+        a0 += b0;
+        a1 += b1;
+        L.win[(2 * PH) % LT] = a0;
+        L.win[(2 * PH + 1) % LT] = a1;
+        if (!emit) return;
+        // column filter: (LL, W-lo/H-hi) and (W-hi/H-lo, HH), two chains each (even / odd taps)
+        wl_v2 cl = wl_pk_mul_x(R.th[0], L.win[(2 * PH + 2) % LT]), ch = wl_pk_mul_y(R.th[0], L.win[(2 * PH + 2) % LT]);
+        wl_v2 cl2 = wl_pk_mul_x(R.th[1], L.win[(2 * PH + 3) % LT]), ch2 = wl_pk_mul_y(R.th[1], L.win[(2 * PH + 3) % LT]);
+#pragma unroll
+        for (int t = 2; t < LT; t += 2) {
+            wl_pk_fma_x(cl, R.th[t], L.win[(2 * PH + 2 + t) % LT]);
+            wl_pk_fma_y(ch, R.th[t], L.win[(2 * PH + 2 + t) % LT]);
+            wl_pk_fma_x(cl2, R.th[t + 1], L.win[(2 * PH + 3 + t) % LT]);
+            wl_pk_fma_y(ch2, R.th[t + 1], L.win[(2 * PH + 3 + t) % LT]);
+        }
+        cl += cl2;
+        ch += ch2;
+        const unsigned ob = L.ob;
+        L.ob = ob + R.rowb;
+        const bool st = !(WL_ROWS_ABLATE & 1) || (cl.x + cl.y + ch.x + ch.y == 12345.f);   // product: always true
+        if (st) {
+            *reinterpret_cast<T*>(R.hp0 + ob) = (T)cl.y;    // W-lo / H-hi
+            *reinterpret_cast<T*>(R.hp1 + ob) = (T)ch.x;    // W-hi / H-lo
+            *reinterpret_cast<T*>(R.hp2 + ob) = (T)ch.y;    // W-hi / H-hi
+        }
+        if (R.last) {
+            if (st) *reinterpret_cast<T*>(R.llp + ((unsigned)orow * R.llrowb + R.kb)) = (T)cl.x;
+        } else {
+            char* nrow = smem + (R.nring + (orow & R.rmask) * R.npitch);
+            *reinterpret_cast<T*>(nrow + L.ndst) = (T)cl.x;
+            if (R.halo) {   // only waves that own a boundary column of the next level
+                if (L.hx0 >= 0) *reinterpret_cast<T*>(nrow + L.hx0) = (T)cl.x;
+                if (L.hx1 >= 0) *reinterpret_cast<T*>(nrow + L.hx1) = (T)cl.x;
+            }
+        }
+    }
+
+    static WL_DEV void feed_any(int ph, Lane& L, const Role& R, char* smem, int row0, int row1, bool emit, int orow) {
+        switch (ph) {
+            case 0: feed<0>(L, R, smem, row0, row1, emit, orow); break;
+            case 1: feed<(1 < NPH ? 1 : 0)>(L, R, smem, row0, row1, emit, orow); break;
+            case 2: feed<(2 < NPH ? 2 : 0)>(L, R, smem, row0, row1, emit, orow); break;
+            case 3: feed<(3 < NPH ? 3 : 0)>(L, R, smem, row0, row1, emit, orow); break;
+            case 4: feed<(4 < NPH ? 4 : 0)>(L, R, smem, row0, row1, emit, orow); break;
+            default: feed<(5 < NPH ? 5 : 0)>(L, R, smem, row0, row1, emit, orow); break;
+        }
+    }
+
+    template <int j>
+    static WL_DEV void compute(const Args& a, const WlCtx& ctx, int64_t plane, int col0, int lane) {
         const WlRowsLevel& g = a.g[j];
-        const int k = (wave - g.wave0) * 64 + lane;
+        const int k = col0 + lane;
         const bool active = k < g.Kw;
-        const bool last = j == a.nlev - 1;
         char* const smem = ctx.smem;
-        float twl[LT], twh[LT], thl[LT], thh[LT];
+        Role R;
 #pragma unroll
         for (int t = 0; t < LT; ++t) {
-            twl[t] = wl_uniform_f(a.h_w_lo[t]); twh[t] = wl_uniform_f(a.h_w_hi[t]);
-            thl[t] = wl_uniform_f(a.h_h_lo[t]); thh[t] = wl_uniform_f(a.h_h_hi[t]);
+            R.tw[t] = wl_uniform_v2(wl_v2{a.h_w_lo[t], a.h_w_hi[t]});
+            R.th[t] = wl_uniform_v2(wl_v2{a.h_h_lo[t], a.h_h_hi[t]});
         }
-        // where this lane's L row-filter samples live inside a ring row (bytes); zero padding -> the row's zero cell
-        int off[FAST ? 1 : LT];
-        if (FAST) {
-            off[0] = (2 * (active ? k : 0) + a.base) * (int)sizeof(T);
-        } else {
-#pragma unroll
-            for (int t = 0; t < LT; ++t) {
-                const int c = active ? wl_ext(2 * k + a.base + t, g.Ws, a.ext) : 0;
-                off[t] = (c < 0 ? g.Ws : c) * (int)sizeof(T);
-            }
-        }
-        float wlo[LT], whi[LT];   // the window: row-filtered (lo, hi) of the last L extended rows of column k
-#pragma unroll
-        for (int t = 0; t < LT; ++t) wlo[t] = whi[t] = 0.f;
+        R.last = j == a.nlev - 1;
         const unsigned bplane = (unsigned)g.Kh * (unsigned)g.Kw;
-        char* const hp = reinterpret_cast<char*>(a.yh[j] + (size_t)plane * 3 * bplane);
-        char* const llp = last ? reinterpret_cast<char*>(a.ll + (size_t)plane * a.ll_ps) : nullptr;
-        const int rmask = a.ring_rows - 1;
-        const int zrow = a.zero_off;
-        const int ring = g.ring_off, pitch = g.ring_pitch, Hs = g.Hs;
-        const int nring = j + 1 < WL_ROWS_MAXLEV ? a.g[j + 1 < WL_ROWS_MAXLEV ? j + 1 : j].ring_off : 0;
-        const int npitch = j + 1 < WL_ROWS_MAXLEV ? a.g[j + 1 < WL_ROWS_MAXLEV ? j + 1 : j].ring_pitch : 0;
-
-        auto load_row = [&](int row_off, float (&v)[LT]) {   // row_off: wave-uniform LDS byte offset of the row
-            if (FAST) {
-                const char* p = smem + (row_off + off[0]);
-                if (sizeof(T) == 4) {
+        R.hp0 = reinterpret_cast<char*>(a.yh[j] + (size_t)plane * 3 * bplane);
+        R.hp1 = R.hp0 + (size_t)bplane * SZ;
+        R.hp2 = R.hp1 + (size_t)bplane * SZ;
+        R.llp = R.last ? reinterpret_cast<char*>(a.ll + (size_t)plane * a.ll_ps) : nullptr;
+        R.rowb = (unsigned)g.Kw * SZ; R.llrowb = (unsigned)a.ll_rs * SZ; R.kb = (unsigned)k * SZ;
+        R.rmask = a.ring_rows - 1;
+        const WlRowsLevel& gn = a.g[j + 1 < WL_ROWS_MAXLEV ? j + 1 : j];
+        R.nring = gn.ring_off; R.npitch = gn.ring_pitch;
+        Lane L;
 #pragma unroll
-                    for (int u = 0; u < LT / 2; ++u) {
-                        const wl_f2 t2 = *reinterpret_cast<const wl_f2*>(p + 8 * u);
-                        v[2 * u] = t2.x; v[2 * u + 1] = t2.y;
-                    }
-                } else {
-                    typedef T Pair2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-                    for (int u = 0; u < LT / 2; ++u) {
-                        const Pair2 t2 = *reinterpret_cast<const Pair2*>(p + 2 * sizeof(T) * u);
-                        v[2 * u] = (float)t2.x; v[2 * u + 1] = (float)t2.y;
-                    }
+        for (int t = 0; t < LT; ++t) L.win[t] = wl_v2{0.f, 0.f};
+        L.ob = (unsigned)k * SZ;
+        L.off = g.pad + (2 * (active ? k : 0) + a.base) * SZ;   // halo cells included: always >= 0
+        // the halo cells of the NEXT level's ring rows whose source column is k - at most one on either side
+        L.ndst = gn.pad + k * SZ; L.hx0 = L.hx1 = -1;
+        if (!R.last && active && a.ext != WL_EXT_ZERO) {
+            for (int c = 0; c < gn.hl + gn.hr; ++c) {
+                const int e = c < gn.hl ? c - gn.hl : gn.Ws + (c - gn.hl);
+                if (wl_ext(e, gn.Ws, a.ext) == k) {
+                    if (e < 0) L.hx0 = gn.pad + e * SZ; else L.hx1 = gn.pad + e * SZ;
                 }
-            } else {
-#pragma unroll
-                for (int t = 0; t < LT; ++t) v[t] = (float)*reinterpret_cast<const T*>(smem + (row_off + off[t]));
             }
-        };
+        }
+        // does any lane of this wave own a halo cell?  (columns near either edge of the next level's rows)
+        R.halo = !R.last && a.ext != WL_EXT_ZERO && (col0 <= gn.hl + 1 || col0 + 63 >= gn.Ws - gn.hr - 2);
+        const int rmask = R.rmask, zrow = a.zero_off, ring = g.ring_off, pitch = g.ring_pitch, Hs = g.Hs;
+        const bool zmode = a.ext == WL_EXT_ZERO;
 
-        WlRowsSched sc;
-        sc.init();
+        int fed = 0, ph = 0;    // feeds this level has consumed, and fed % NPH (wave-uniform)
         unsigned long long tb = 0, tf = 0, ts = 0, c3 = WL_TICK();
         for (int hb = 0; hb < a.nhb; ++hb) {
             const unsigned long long c0 = WL_TICK();
             ts += c0 - c3;
+            const int n = wl_uniform((int)(a.sched[hb >> 2] >> (8 * (hb & 3) + 2 * j)) & 3);   // read before the barrier
             ctx.sync();
             const unsigned long long c1 = WL_TICK();
             tb += c1 - c0;
-            const int n = wl_uniform(sc.feeds_now(a, j, LT));
             for (int i = 0; i < n; ++i) {
-                const int f = sc.fed[j] + i;
-                const int e = a.base + 2 * f;
+                const int e = a.base + 2 * fed;
                 // the two source rows of this feed (wave-uniform LDS offsets)
                 int r0, r1;
                 if (j == 0) {
-                    const int slot = ring + ((hb % NSLOT) * 4 + 2 * i) * pitch;
-                    const bool zmode = a.ext == WL_EXT_ZERO;
-                    r0 = (zmode && (unsigned)e >= (unsigned)Hs) ? zrow : slot;
-                    r1 = (zmode && (unsigned)(e + 1) >= (unsigned)Hs) ? zrow : slot + pitch;
+                    r0 = ring + ((hb % NSLOT) * 4 + 2 * i) * pitch;
+                    r1 = r0 + pitch;
+                    if (zmode) {
+                        if ((unsigned)e >= (unsigned)Hs) r0 = zrow;
+                        if ((unsigned)(e + 1) >= (unsigned)Hs) r1 = zrow;
+                    }
                 } else {
-                    const int s0 = wl_ext1(e, Hs, a.ext), s1 = wl_ext1(e + 1, Hs, a.ext);
+                    int s0 = e, s1 = e + 1;
+                    if (e < 0 || e + 1 >= Hs) { s0 = wl_ext1(e, Hs, a.ext); s1 = wl_ext1(e + 1, Hs, a.ext); }   // top / bottom rows only
                     r0 = s0 < 0 ? zrow : ring + (s0 & rmask) * pitch;
                     r1 = s1 < 0 ? zrow : ring + (s1 & rmask) * pitch;
                 }
                 r0 = wl_uniform(r0); r1 = wl_uniform(r1);
-                if (active) {
-                    float v0[LT], v1[LT];
-                    load_row(r0, v0);
-                    load_row(r1, v1);
-                    float l0 = 0.f, h0 = 0.f, l1 = 0.f, h1 = 0.f;
-#pragma unroll
-                    for (int t = 0; t < LT; ++t) {
-                        l0 = __builtin_fmaf(twl[t], v0[t], l0);
-                        h0 = __builtin_fmaf(twh[t], v0[t], h0);
-                        l1 = __builtin_fmaf(twl[t], v1[t], l1);
-                        h1 = __builtin_fmaf(twh[t], v1[t], h1);
-                    }
-#pragma unroll
-                    for (int t = 0; t < LT - 2; ++t) { wlo[t] = wlo[t + 2]; whi[t] = whi[t + 2]; }
-                    wlo[LT - 2] = l0; whi[LT - 2] = h0;
-                    wlo[LT - 1] = l1; whi[LT - 1] = h1;
-                    if (f >= WARM) {
-                        const int orow = f - WARM;
-                        float ll = 0.f, lh = 0.f, hl = 0.f, hh = 0.f;
-#pragma unroll
-                        for (int t = 0; t < LT; ++t) {
-                            ll = __builtin_fmaf(thl[t], wlo[t], ll);
-                            lh = __builtin_fmaf(thh[t], wlo[t], lh);
-                            hl = __builtin_fmaf(thl[t], whi[t], hl);
-                            hh = __builtin_fmaf(thh[t], whi[t], hh);
-                        }
-                        const unsigned ob = ((unsigned)orow * (unsigned)g.Kw + (unsigned)k) * (unsigned)sizeof(T);
-                        const unsigned bpb = bplane * (unsigned)sizeof(T);
-                        const bool st = !(WL_ROWS_ABLATE & 1) || (lh + hl + hh + ll == 12345.f);   // product: always true
-                        if (st) {
-                        *reinterpret_cast<T*>(hp + ob) = (T)lh;                // W-lo / H-hi
-                        *reinterpret_cast<T*>(hp + (bpb + ob)) = (T)hl;        // W-hi / H-lo
-                        *reinterpret_cast<T*>(hp + (2 * bpb + ob)) = (T)hh;    // W-hi / H-hi
-                        }
-                        if (last) {
-                            if (st)
-                                *reinterpret_cast<T*>(llp + ((unsigned)orow * (unsigned)a.ll_rs + (unsigned)k) * (unsigned)sizeof(T)) = (T)ll;
-                        } else {
-                            *reinterpret_cast<T*>(smem + (nring + (orow & rmask) * npitch + k * (int)sizeof(T))) = (T)ll;
-                        }
-                    }
-                }
+                if (active) feed_any(ph, L, R, smem, r0, r1, fed >= WARM, fed - WARM);
+                ++fed;
+                ph = ph + 1 == NPH ? 0 : ph + 1;
             }
             c3 = WL_TICK();
             tf += c3 - c1;
-            // advance the levels this wave depends on (same arithmetic in every wave: the schedule is shared)
-            int nn[WL_ROWS_MAXLEV];
-#pragma unroll
-            for (int q = 0; q < WL_ROWS_MAXLEV; ++q) nn[q] = q < j ? sc.feeds_now(a, q, LT) : (q == j ? n : 0);
-#pragma unroll
-            for (int q = 0; q < WL_ROWS_MAXLEV; ++q) sc.fed[q] = wl_uniform(sc.fed[q] + nn[q]);
         }
-        if ((WL_ROWS_ABLATE & 8) && j == 0 && k == 64) {   // second level-1 wave (an interior one)
+        if ((WL_ROWS_ABLATE & 8) && j == 0 && k == 64) {   // second level-1 wave
             T* o = a.ll + (size_t)plane * a.ll_ps;
             o[0] = (T)(float)(tb >> 6); o[1] = (T)(float)(tf >> 6); o[2] = (T)(float)(ts >> 6);
         }
@@ -291,38 +396,18 @@ struct WlAfbRows {
         const int tid = ctx.tid;
         const int wave = wl_uniform(tid >> 6), lane = tid & 63;
         const int64_t plane = ctx.bid;
-        // permanent zeros: the zero row and the zero cell (column Ws) of every ring row
-        for (int i = tid * 4; i < a.zero_bytes; i += kThreads * 4) *reinterpret_cast<int*>(ctx.smem + a.zero_off + i) = 0;
-        for (int j = 0; j < a.nlev; ++j) {
-            const WlRowsLevel& g = a.g[j];
-            const int rows = j == 0 ? 4 * NSLOT : a.ring_rows;
-            for (int r = tid; r < rows; r += kThreads)
-                *reinterpret_cast<T*>(ctx.smem + g.ring_off + r * g.ring_pitch + g.Ws * (int)sizeof(T)) = (T)0;
+        // all of LDS starts as zeros: the zero row, and halo cells that stay zero in zero-padding mode
+        for (int i = tid * 16; i < a.lds_bytes; i += kThreads * 16) {
+            wl_f4 z; z.x = z.y = z.z = z.w = 0.f;
+            *reinterpret_cast<wl_f4*>(ctx.smem + i) = z;
         }
-        if (wave == a.loader_wave) {
-            loader(a, ctx, plane, lane);
-            return;
-        }
-        int lev = -1;
-        for (int j = 0; j < a.nlev; ++j)
-            if (wave >= a.g[j].wave0 && wave < a.g[j].wave0 + a.g[j].nwaves) lev = j;
-        if (lev < 0) {   // spare wave: keeps the barrier count
-            for (int hb = 0; hb < a.nhb; ++hb) ctx.sync();
-            return;
-        }
-        // interior waves (no lane touches the boundary extension, even sample origin) read their samples as vectors
-        const WlRowsLevel& g = a.g[lev];
-        const int kmin = (wave - g.wave0) * 64;
-        const int kmax = kmin + 63 < g.Kw - 1 ? kmin + 63 : g.Kw - 1;
-        const bool fast = kmax >= kmin && !(a.base & 1) && 2 * kmin + a.base >= 0 && 2 * kmax + a.base + LT - 1 <= g.Ws - 1;
-        if (fast) {
-            if (lev == 0) compute<1, 0>(a, ctx, plane, wave, lane);
-            else if (lev == 1) compute<1, 1>(a, ctx, plane, wave, lane);
-            else compute<1, 2>(a, ctx, plane, wave, lane);
-        } else {
-            if (lev == 0) compute<0, 0>(a, ctx, plane, wave, lane);
-            else if (lev == 1) compute<0, 1>(a, ctx, plane, wave, lane);
-            else compute<0, 2>(a, ctx, plane, wave, lane);
-        }
+        ctx.sync();
+        const int lev = wl_uniform(a.role_level[wave]), col0 = wl_uniform(a.role_col0[wave]);
+        if (lev == -1) loader(a, ctx, plane, lane);
+        else if (lev == 0) compute<0>(a, ctx, plane, col0, lane);
+        else if (lev == 1) compute<1>(a, ctx, plane, col0, lane);
+        else if (lev == 2) compute<2>(a, ctx, plane, col0, lane);
+        else
+            for (int hb = 0; hb < a.nhb; ++hb) ctx.sync();   // spare wave: keeps the barrier count
     }
 };

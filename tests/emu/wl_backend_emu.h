@@ -50,6 +50,9 @@ static float wl_emu_shuffle(float v, int src) {
     swapcontext(&b->fib[me], &b->main);
     return b->shfl_out[me];
 }
+float wl_shfl_up1(float v) { return wl_emu_shuffle(v, -1); }
+float wl_shfl(float v, int src_lane) { return wl_emu_shuffle(v, src_lane & 63); }
+
 // LDS-DMA: the copy lands only when the issuing lane's wl_wait_vm<N> releases it (oldest first)
 void wl_dma16(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on) {
     WlEmuBlock* b = wl_emu_cur_block;
@@ -58,16 +61,18 @@ void wl_dma16(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on
     d.src = (const char*)gsrc;
     b->dma[b->cur].push_back(d);
 }
+// The counter is per WAVE: the wait is a wave-level rendezvous (all lanes have issued the same loads; all their
+// copies have landed before any lane goes on), like the lockstep execution of the hardware.
 void wl_emu_wait_vm(int n) {
     WlEmuBlock* b = wl_emu_cur_block;
+    wl_emu_shuffle(0.f, b->cur & 63);
     std::vector<WlEmuBlock::Dma>& q = b->dma[b->cur];
     while ((int)q.size() > n) {
         if (q.front().dst) memcpy(q.front().dst, q.front().src, 16);
         q.erase(q.begin());
     }
+    wl_emu_shuffle(0.f, b->cur & 63);
 }
-float wl_shfl_up1(float v) { return wl_emu_shuffle(v, -1); }
-float wl_shfl(float v, int src_lane) { return wl_emu_shuffle(v, src_lane & 63); }
 
 template <typename K>
 struct WlEmuJob {

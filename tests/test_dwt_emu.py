@@ -131,8 +131,9 @@ def test_streaming_kernel_vs_oracle_random_shapes(seed):
         x = torch.tensor(rng.randn(1, 2, H, W), dtype=torch.float32)
         oyl, oyh = wo.dwt_forward(x.double().numpy(), J, h0, h1, h0, h1, mode)
         res = _fused(x, wave, mode, J)
-        if res is None:   # the launcher may decline (a level shorter than the filter); never silently wrong
-            assert min(H, W) < 2 ** (J - 1) * (2 * L), (wave, mode, H, W, J)
+        if res is None:   # the launcher may decline (a level shorter than the filter, or periodization with
+            # L % 4 == 0 whose samples sit on odd addresses); never silently wrong
+            assert min(H, W) < 2 ** (J - 1) * (2 * L) or (mode == 'periodization' and L % 4 == 0), (wave, mode, H, W, J)
             continue
         yl, yh = res
         for got, want in zip([yl] + list(yh), [oyl] + list(oyh)):

@@ -171,8 +171,8 @@ def test_errors_and_edge_cases():
 
 @pytest.mark.parametrize('wave,mode,J,shape', [
     ('db4', 'symmetric', 3, (2, 2, 200, 136)), ('db2', 'zero', 3, (1, 3, 97, 204)),
-    ('db3', 'reflect', 2, (1, 2, 130, 80)), ('db6', 'periodization', 1, (2, 2, 256, 320)),
-    ('db4', 'periodic', 1, (1, 2, 112, 64)), ('haar', 'zero', 3, (1, 2, 64, 640)), ('db5', 'symmetric', 3, (3, 1, 301, 512)),
+    ('db3', 'reflect', 2, (1, 2, 130, 80)), ('db5', 'periodization', 1, (2, 2, 256, 320)),
+    ('db4', 'periodic', 1, (1, 2, 112, 64)), ('haar', 'zero', 3, (1, 2, 64, 512)), ('db5', 'symmetric', 3, (3, 1, 301, 512)),
 ])
 def test_streaming_kernel_vs_oracle(wave, mode, J, shape):
     """The streaming multi-level analysis kernel through its C-ABI entry point (forced: strips=1): LDS-DMA row loads,
