@@ -8,7 +8,7 @@
 //     loader patches them after the row has landed; for LL_j rows the producing lane writes them), so EVERY lane
 //     reads its L row-filter samples as one base address + constant offsets;
 //   * a lane owns ONE output column of its level and keeps the L-row sliding window of that column's row-filtered
-//     (lo,hi) pair in registers (a rotating buffer: no register shifts): per pair of new source rows it runs the row
+//     (lo,hi) pair in registers: per pair of new source rows it runs the row
 //     filter (samples straight from the LDS ring) and the column filter (registers only) - one LDS crossing per
 //     sample, no intermediate planes, one barrier per four input rows;
 //   * LL_j rows go to a small LDS ring that the waves of level j+1 consume a few rows behind - LL_1 .. LL_{J-1}
@@ -32,7 +32,12 @@
 #include "wl_common.h"
 
 #define WL_ROWS_MAXLEV 3
-#define WL_ROWS_WAVES 11
+#ifndef WL_ROWS_WAVES
+#define WL_ROWS_WAVES 12
+#endif
+#ifndef WL_ROWS_LOADERS
+#define WL_ROWS_LOADERS 2       // loader waves: each issues the DMA of 4 / WL_ROWS_LOADERS rows of a half-batch (1, 2 or 4)
+#endif
 #define WL_ROWS_MAXHB 1536      // half-batches the schedule table (kernel argument) can hold
 // WL_ROWS_ABLATE (tools/build_ab.sh builds only, never defined in the product): 1 = no global stores, 2 = no DMA
 // loads, 8 = in-kernel cycle counters written over a few LL samples
@@ -101,7 +106,7 @@ struct WlRowsArgs {
     int ring_rows;      // rows of the LL rings (power of two)
     int zero_off;       // LDS byte offset of an all-zero row (zero padding above / below the plane)
     int lds_bytes;
-    // role of every wave: level (0..nlev-1) and first column of its 64-column chunk; -1 = loader, -2 = spare.  Waves w
+    // role of every wave: level (0..nlev-1) and first column of its 64-column chunk; -1 = loader (col0 = its index), -2 = spare.  Waves w
     // and w+4 share a SIMD, so the launcher deals the roles out for equal instruction load per SIMD.
     signed char role_level[WL_ROWS_WAVES];
     short role_col0[WL_ROWS_WAVES];
@@ -136,17 +141,16 @@ template <typename T, int LT, int PPR, int D = WL_ROWS_DEPTH>
 struct WlAfbRows {
     typedef WlRowsArgs<T> Args;
     static const int kThreads = 64 * WL_ROWS_WAVES;
-    static const int kMinWaves = 6;        // two workgroups per CU: 22 waves on 4 SIMDs
-    static const int NL = 4 * PPR;         // DMA instructions per half-batch (4 rows x PPR pieces of 1 KiB)
+    static const int kMinWaves = 6;        // two workgroups per CU: 24 waves on 4 SIMDs
+    static const int LROWS = 4 / WL_ROWS_LOADERS;   // rows of a half-batch one loader wave is responsible for
+    static const int NL = LROWS * PPR;     // DMA instructions per half-batch and loader wave (PPR pieces of 1 KiB per row)
     static const int WARM = (LT - 2) / 2;  // feeds that only fill the window
     static const int NSLOT = D + 1;        // half-batch slots of the input ring
     static const int SZ = (int)sizeof(T);
-    static const int NPH = LT / 2;         // feed phases of the rotating window
     static_assert((D - 1) * NL < 64, "prefetch distance exceeds the vmcnt range");
-    static_assert(NPH >= 1 && NPH <= 6, "feed_any covers up to six phases");
 
     // ---- loader wave ------------------------------------------------------------------------------------------
-    static WL_DEV void loader(const Args& a, const WlCtx& ctx, int64_t plane, int lane) {
+    static WL_DEV void loader(const Args& a, const WlCtx& ctx, int64_t plane, int lane, int lidx) {
         const WlRowsLevel& g = a.g[0];
         const char* xp = reinterpret_cast<const char*>(a.x + (size_t)plane * a.x_ps);
         const int row_bytes = g.Ws * SZ;
@@ -154,15 +158,16 @@ struct WlAfbRows {
         const int nhb0 = (g.Kh + WARM + 1) / 2;                  // half-batches in which level 1 runs
         const int e_last = a.base + 2 * (g.Kh + WARM) - 1;       // last extended row level 1 consumes
         const int ring = g.ring_off, pitch = g.ring_pitch, pad = g.pad, Hs = g.Hs, base = a.base, ext = a.ext;
-        // halo cells of the 4 rows of a slot: item = (row r, cell c); a lane handles items lane and lane + 64
+        const int rfirst = lidx * LROWS;   // this loader's rows of every slot: rfirst .. rfirst + LROWS - 1
+        // halo cells of those rows: item = (row r, cell c); a lane handles items lane and lane + 64
         const int NH = g.hl + g.hr;
         int hdst[2], hsrc[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int it = lane + 64 * u;
             hdst[u] = hsrc[u] = -1;
-            if (ext != WL_EXT_ZERO && it < 4 * NH) {
-                const int r = it / NH, c = it - r * NH;
+            if (ext != WL_EXT_ZERO && it < LROWS * NH) {
+                const int r = rfirst + it / NH, c = it % NH;
                 const int e = c < g.hl ? c - g.hl : g.Ws + (c - g.hl);
                 const int s = wl_ext(e, g.Ws, ext);
                 hdst[u] = r * pitch + pad + e * SZ;
@@ -172,7 +177,8 @@ struct WlAfbRows {
         auto issue = [&](int h) {
             const int slot = ring + (h % NSLOT) * 4 * pitch + pad;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int rr = 0; rr < LROWS; ++rr) {
+                const int r = rfirst + rr;
                 int e = base + 4 * h + r;
                 e = e < e_last ? e : e_last;
                 int src = e;
@@ -215,8 +221,7 @@ struct WlAfbRows {
 
     // ---- compute waves of level j -----------------------------------------------------------------------------
     struct Lane {               // per lane
-        wl_v2 win[LT];          // row-filtered (lo,hi) of the last L extended rows of column k, as a ROTATING buffer:
-                                //   feed phase PH writes slots 2PH, 2PH+1; tap t of the column filter reads slot 2PH+2+t
+        wl_v2 win[LT];          // row-filtered (lo,hi) of the last L extended rows of column k, oldest first
         unsigned ob;            // byte offset of this lane's next output sample inside a band plane
         int off;                // byte offset of its first row-filter sample inside a ring row
         int ndst, hx0, hx1;     // next level's ring row: its LL sample and the halo cells it is the source of
@@ -229,13 +234,10 @@ struct WlAfbRows {
         bool last, halo;
     };
 
-    // one feed: row-filter the two new source rows (LDS byte offsets row0/row1, wave-uniform) into the window, and -
-    // once the window is full - column-filter it into one sample of each of the four sub-bands.
-    template <int PH>
-    static WL_DEV void feed(Lane& L, const Role& R, char* smem, int row0, int row1, bool emit, int orow) {
+    // the L samples of this lane in two ring rows (LDS byte offsets row0/row1, wave-uniform), as (even, odd) pairs
+    static WL_DEV void load_rows(const Lane& L, const char* smem, int row0, int row1, wl_v2 (&s0)[LT / 2], wl_v2 (&s1)[LT / 2]) {
         const char* p0 = smem + (row0 + L.off);
         const char* p1 = smem + (row1 + L.off);
-        wl_v2 s0[LT / 2], s1[LT / 2];
         if (SZ == 4) {
 #pragma unroll
             for (int u = 0; u < LT / 2; ++u) {
@@ -252,8 +254,11 @@ struct WlAfbRows {
                 s0[u] = wl_v2{(float)t0.x, (float)t0.y}; s1[u] = wl_v2{(float)t1.x, (float)t1.y};
             }
         }
-        // four independent chains (even / odd taps of either row): dependent v_pk_fma_f32 need a wait state in between
-        wl_v2 a0 = wl_pk_mul_x(R.tw[0], s0[0]), a1 = wl_pk_mul_x(R.tw[0], s1[0]);
+    }
+    // row filter of two rows: four independent chains (even / odd taps of either row; dependent v_pk_fma_f32 need a
+    // wait state in between)
+    static WL_DEV void row_pass(const Role& R, const wl_v2 (&s0)[LT / 2], const wl_v2 (&s1)[LT / 2], wl_v2& a0, wl_v2& a1) {
+        a0 = wl_pk_mul_x(R.tw[0], s0[0]); a1 = wl_pk_mul_x(R.tw[0], s1[0]);
         wl_v2 b0 = wl_pk_mul_y(R.tw[1], s0[0]), b1 = wl_pk_mul_y(R.tw[1], s1[0]);
 #pragma unroll
         for (int u = 1; u < LT / 2; ++u) {
@@ -264,18 +269,19 @@ struct WlAfbRows {
         }
         a0 += b0;
         a1 += b1;
-        L.win[(2 * PH) % LT] = a0;
-        L.win[(2 * PH + 1) % LT] = a1;
-        if (!emit) return;
-        // column filter: (LL, W-lo/H-hi) and (W-hi/H-lo, HH), two chains each (even / odd taps)
-        wl_v2 cl = wl_pk_mul_x(R.th[0], L.win[(2 * PH + 2) % LT]), ch = wl_pk_mul_y(R.th[0], L.win[(2 * PH + 2) % LT]);
-        wl_v2 cl2 = wl_pk_mul_x(R.th[1], L.win[(2 * PH + 3) % LT]), ch2 = wl_pk_mul_y(R.th[1], L.win[(2 * PH + 3) % LT]);
+    }
+    // column filter of the window w[0..L) (oldest first) into one sample of each sub-band, and their stores:
+    // (LL, W-lo/H-hi) and (W-hi/H-lo, HH), two chains each (even / odd taps)
+    template <bool LAST, bool HALO>
+    static WL_DEV void col_pass(Lane& L, const Role& R, char* smem, const wl_v2* w, int orow) {
+        wl_v2 cl = wl_pk_mul_x(R.th[0], w[0]), ch = wl_pk_mul_y(R.th[0], w[0]);
+        wl_v2 cl2 = wl_pk_mul_x(R.th[1], w[1]), ch2 = wl_pk_mul_y(R.th[1], w[1]);
 #pragma unroll
         for (int t = 2; t < LT; t += 2) {
-            wl_pk_fma_x(cl, R.th[t], L.win[(2 * PH + 2 + t) % LT]);
-            wl_pk_fma_y(ch, R.th[t], L.win[(2 * PH + 2 + t) % LT]);
-            wl_pk_fma_x(cl2, R.th[t + 1], L.win[(2 * PH + 3 + t) % LT]);
-            wl_pk_fma_y(ch2, R.th[t + 1], L.win[(2 * PH + 3 + t) % LT]);
+            wl_pk_fma_x(cl, R.th[t], w[t]);
+            wl_pk_fma_y(ch, R.th[t], w[t]);
+            wl_pk_fma_x(cl2, R.th[t + 1], w[t + 1]);
+            wl_pk_fma_y(ch2, R.th[t + 1], w[t + 1]);
         }
         cl += cl2;
         ch += ch2;
@@ -287,27 +293,46 @@ struct WlAfbRows {
             *reinterpret_cast<T*>(R.hp1 + ob) = (T)ch.x;    // W-hi / H-lo
             *reinterpret_cast<T*>(R.hp2 + ob) = (T)ch.y;    // W-hi / H-hi
         }
-        if (R.last) {
+        if (LAST) {
             if (st) *reinterpret_cast<T*>(R.llp + ((unsigned)orow * R.llrowb + R.kb)) = (T)cl.x;
         } else {
             char* nrow = smem + (R.nring + (orow & R.rmask) * R.npitch);
             *reinterpret_cast<T*>(nrow + L.ndst) = (T)cl.x;
-            if (R.halo) {   // only waves that own a boundary column of the next level
+            if (HALO) {   // only waves that own a boundary column of the next level
                 if (L.hx0 >= 0) *reinterpret_cast<T*>(nrow + L.hx0) = (T)cl.x;
                 if (L.hx1 >= 0) *reinterpret_cast<T*>(nrow + L.hx1) = (T)cl.x;
             }
         }
     }
 
-    static WL_DEV void feed_any(int ph, Lane& L, const Role& R, char* smem, int row0, int row1, bool emit, int orow) {
-        switch (ph) {
-            case 0: feed<0>(L, R, smem, row0, row1, emit, orow); break;
-            case 1: feed<(1 < NPH ? 1 : 0)>(L, R, smem, row0, row1, emit, orow); break;
-            case 2: feed<(2 < NPH ? 2 : 0)>(L, R, smem, row0, row1, emit, orow); break;
-            case 3: feed<(3 < NPH ? 3 : 0)>(L, R, smem, row0, row1, emit, orow); break;
-            case 4: feed<(4 < NPH ? 4 : 0)>(L, R, smem, row0, row1, emit, orow); break;
-            default: feed<(5 < NPH ? 5 : 0)>(L, R, smem, row0, row1, emit, orow); break;
-        }
+    // one feed: row-filter the two new source rows into the window and - once the window is full - emit one output row
+    template <bool LAST, bool HALO>
+    static WL_DEV void feed1(Lane& L, const Role& R, char* smem, int row0, int row1, bool emit, int orow) {
+        wl_v2 s0[LT / 2], s1[LT / 2], a0, a1;
+        load_rows(L, smem, row0, row1, s0, s1);
+        row_pass(R, s0, s1, a0, a1);
+#pragma unroll
+        for (int t = 0; t < LT - 2; ++t) L.win[t] = L.win[t + 2];
+        L.win[LT - 2] = a0;
+        L.win[LT - 1] = a1;
+        if (emit) col_pass<LAST, HALO>(L, R, smem, L.win, orow);
+    }
+    // two feeds of the steady state (both emit): all four rows are requested from LDS before the first FMA, the
+    // window moves once (by four rows) instead of twice
+    template <bool LAST, bool HALO>
+    static WL_DEV void feed2(Lane& L, const Role& R, char* smem, int row0, int row1, int row2, int row3, int orow) {
+        wl_v2 s0[LT / 2], s1[LT / 2], s2[LT / 2], s3[LT / 2];
+        load_rows(L, smem, row0, row1, s0, s1);
+        load_rows(L, smem, row2, row3, s2, s3);
+        wl_v2 w[LT + 4];
+#pragma unroll
+        for (int t = 0; t < LT; ++t) w[t] = L.win[t];
+        row_pass(R, s0, s1, w[LT], w[LT + 1]);
+        col_pass<LAST, HALO>(L, R, smem, w + 2, orow);
+        row_pass(R, s2, s3, w[LT + 2], w[LT + 3]);
+        col_pass<LAST, HALO>(L, R, smem, w + 4, orow + 1);
+#pragma unroll
+        for (int t = 0; t < LT; ++t) L.win[t] = w[t + 4];
     }
 
     template <int j>
@@ -327,7 +352,7 @@ struct WlAfbRows {
         R.hp0 = reinterpret_cast<char*>(a.yh[j] + (size_t)plane * 3 * bplane);
         R.hp1 = R.hp0 + (size_t)bplane * SZ;
         R.hp2 = R.hp1 + (size_t)bplane * SZ;
-        R.llp = R.last ? reinterpret_cast<char*>(a.ll + (size_t)plane * a.ll_ps) : nullptr;
+        R.llp = reinterpret_cast<char*>(a.ll + (size_t)plane * a.ll_ps);
         R.rowb = (unsigned)g.Kw * SZ; R.llrowb = (unsigned)a.ll_rs * SZ; R.kb = (unsigned)k * SZ;
         R.rmask = a.ring_rows - 1;
         const WlRowsLevel& gn = a.g[j + 1 < WL_ROWS_MAXLEV ? j + 1 : j];
@@ -349,10 +374,38 @@ struct WlAfbRows {
         }
         // does any lane of this wave own a halo cell?  (columns near either edge of the next level's rows)
         R.halo = !R.last && a.ext != WL_EXT_ZERO && (col0 <= gn.hl + 1 || col0 + 63 >= gn.Ws - gn.hr - 2);
+        if (R.last) main_loop<j, true, false>(a, ctx, plane, L, R, active, k);
+        else if (R.halo) main_loop<j, false, true>(a, ctx, plane, L, R, active, k);
+        else main_loop<j, false, false>(a, ctx, plane, L, R, active, k);
+    }
+
+    template <int j, bool LAST, bool HALO>
+    static WL_DEV void main_loop(const Args& a, const WlCtx& ctx, int64_t plane, Lane& L, const Role& R, bool active, int k) {
+        const WlRowsLevel& g = a.g[j];
+        char* const smem = ctx.smem;
         const int rmask = R.rmask, zrow = a.zero_off, ring = g.ring_off, pitch = g.ring_pitch, Hs = g.Hs;
         const bool zmode = a.ext == WL_EXT_ZERO;
+        // LDS byte offsets (wave-uniform) of the two source rows of feed f = (2f+base, 2f+base+1); i = its index in
+        // the half-batch hb
+        auto rows_of = [&](int f, int hb, int i, int& r0, int& r1) {
+            const int e = a.base + 2 * f;
+            if (j == 0) {
+                r0 = ring + ((hb % NSLOT) * 4 + 2 * i) * pitch;
+                r1 = r0 + pitch;
+                if (zmode) {
+                    if ((unsigned)e >= (unsigned)Hs) r0 = zrow;
+                    if ((unsigned)(e + 1) >= (unsigned)Hs) r1 = zrow;
+                }
+            } else {
+                int s0 = e, s1 = e + 1;
+                if (e < 0 || e + 1 >= Hs) { s0 = wl_ext1(e, Hs, a.ext); s1 = wl_ext1(e + 1, Hs, a.ext); }   // top / bottom rows only
+                r0 = s0 < 0 ? zrow : ring + (s0 & rmask) * pitch;
+                r1 = s1 < 0 ? zrow : ring + (s1 & rmask) * pitch;
+            }
+            r0 = wl_uniform(r0); r1 = wl_uniform(r1);
+        };
 
-        int fed = 0, ph = 0;    // feeds this level has consumed, and fed % NPH (wave-uniform)
+        int fed = 0;            // feeds this level has consumed (wave-uniform)
         unsigned long long tb = 0, tf = 0, ts = 0, c3 = WL_TICK();
         for (int hb = 0; hb < a.nhb; ++hb) {
             const unsigned long long c0 = WL_TICK();
@@ -361,27 +414,19 @@ struct WlAfbRows {
             ctx.sync();
             const unsigned long long c1 = WL_TICK();
             tb += c1 - c0;
-            for (int i = 0; i < n; ++i) {
-                const int e = a.base + 2 * fed;
-                // the two source rows of this feed (wave-uniform LDS offsets)
-                int r0, r1;
-                if (j == 0) {
-                    r0 = ring + ((hb % NSLOT) * 4 + 2 * i) * pitch;
-                    r1 = r0 + pitch;
-                    if (zmode) {
-                        if ((unsigned)e >= (unsigned)Hs) r0 = zrow;
-                        if ((unsigned)(e + 1) >= (unsigned)Hs) r1 = zrow;
-                    }
-                } else {
-                    int s0 = e, s1 = e + 1;
-                    if (e < 0 || e + 1 >= Hs) { s0 = wl_ext1(e, Hs, a.ext); s1 = wl_ext1(e + 1, Hs, a.ext); }   // top / bottom rows only
-                    r0 = s0 < 0 ? zrow : ring + (s0 & rmask) * pitch;
-                    r1 = s1 < 0 ? zrow : ring + (s1 & rmask) * pitch;
+            if (n == 2 && fed >= WARM) {            // the steady state of level 1
+                int r0, r1, r2, r3;
+                rows_of(fed, hb, 0, r0, r1);
+                rows_of(fed + 1, hb, 1, r2, r3);
+                if (active) feed2<LAST, HALO>(L, R, smem, r0, r1, r2, r3, fed - WARM);
+                fed += 2;
+            } else {
+                for (int i = 0; i < n; ++i) {
+                    int r0, r1;
+                    rows_of(fed, hb, i, r0, r1);
+                    if (active) feed1<LAST, HALO>(L, R, smem, r0, r1, fed >= WARM, fed - WARM);
+                    ++fed;
                 }
-                r0 = wl_uniform(r0); r1 = wl_uniform(r1);
-                if (active) feed_any(ph, L, R, smem, r0, r1, fed >= WARM, fed - WARM);
-                ++fed;
-                ph = ph + 1 == NPH ? 0 : ph + 1;
             }
             c3 = WL_TICK();
             tf += c3 - c1;
@@ -403,7 +448,7 @@ struct WlAfbRows {
         }
         ctx.sync();
         const int lev = wl_uniform(a.role_level[wave]), col0 = wl_uniform(a.role_col0[wave]);
-        if (lev == -1) loader(a, ctx, plane, lane);
+        if (lev == -1) loader(a, ctx, plane, lane, col0);
         else if (lev == 0) compute<0>(a, ctx, plane, col0, lane);
         else if (lev == 1) compute<1>(a, ctx, plane, col0, lane);
         else if (lev == 2) compute<2>(a, ctx, plane, col0, lane);
