@@ -156,6 +156,7 @@ WL_HD int wl_ext_padded(int v, int n, int pad_lo, int pad_hi, int ext) {
 }
 
 WL_HD int wl_cdiv(int a, int b) { return (a + b - 1) / b; }
+WL_HD int64_t wl_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 WL_HD int wl_align_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // XCD-aware block remap (MI355X: workgroup b is dispatched to XCD b % 8, each XCD has its own L2).  Returns the

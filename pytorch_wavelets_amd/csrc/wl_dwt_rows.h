@@ -340,7 +340,6 @@ struct WlAfbRows {
         const WlRowsLevel& g = a.g[j];
         const int k = col0 + lane;
         const bool active = k < g.Kw;
-        char* const smem = ctx.smem;
         Role R;
 #pragma unroll
         for (int t = 0; t < LT; ++t) {

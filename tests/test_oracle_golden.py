@@ -36,6 +36,23 @@ def test_dwt_oracle_vs_reference(name):
         assert np.abs(rec[..., :x.shape[-2], :x.shape[-1]] - x).max() < 1e-9
 
 
+@pytest.mark.parametrize('name', [n for n in G.cases('dwt') if n != 'dwt_17'])
+def test_torch_cpu_restatement_vs_reference(name):
+    """oracle/torch_cpu.py (the reference's gather + grouped conv2d / conv_transpose2d formulation on PyTorch-CPU, the
+    `cpu_baseline` of bench.py) against the same goldens."""
+    import torch
+    from oracle import torch_cpu as tc
+    meta, g = G.INDEX[name], G.load(name)
+    h0, h1 = F.dwt_analysis_taps(meta['wave'])
+    g0, g1 = F.dwt_synthesis_taps(meta['wave'])
+    x = torch.tensor(g['x']).double()
+    yl, yh = tc.dwt_forward(x, meta['J'], h0, h1, meta['mode'])
+    assert G.relerr(yl.numpy(), g, 'yl') < TOL
+    for j in range(meta['J']):
+        assert G.relerr(yh[j].numpy(), g, 'yh%d' % j) < TOL
+    assert G.relerr(tc.dwt_inverse(yl, yh, g0, g1, meta['mode']).numpy(), g, 'rec') < TOL
+
+
 def test_dwt_config0_shapes():
     """BASELINE configs[0]: DWTForward(J=1,'haar','zero') on 1x3x64x64."""
     g = G.load('dwt_00')
