@@ -160,6 +160,25 @@ def test_tile_kernels_fp32_on_emulator(name):
     assert G.relerr(rec.numpy(), g, 'rec') < 1e-5
 
 
+def test_fp16_config5_reference_golden_on_emulator():
+    """BASELINE configs[4] at reduced size (J=4 db8 periodization, float16 data and taps, fp32 accumulate) against
+    the golden generated from the real reference in fp32 on the rounded input (oracle/pin_fp16_config5.py)."""
+    meta, g = G.INDEX['dwt_h16'], G.load('dwt_h16')
+    torch.set_default_dtype(torch.float32)
+    xfm = pw.DWTForward(J=meta['J'], wave=meta['wave'], mode=meta['mode']).half()
+    ifm = pw.DWTInverse(wave=meta['wave'], mode=meta['mode']).half()
+    with emu_backend.emulated():
+        yl, yh = xfm(torch.tensor(g['x']))
+        rec = ifm((torch.tensor(g['yl']).half(), [torch.tensor(g['yh%d' % j]).half() for j in range(meta['J'])]))
+        kern = emu_backend.handle().wl_last_kernel().decode()
+    assert yl.dtype == torch.float16 and 'WlSfbTile<_Float16, 16' in kern.replace('half', '_Float16')
+    # float16 taps + one float16 rounding of LL per level (half-ulp 4.9e-4 each): 3e-3 after four levels
+    assert G.relerr(yl.float().numpy(), g, 'yl') < 3e-3
+    for j in range(meta['J']):
+        assert G.relerr(yh[j].float().numpy(), g, 'yh%d' % j) < 2e-3
+    assert G.relerr(rec.float().numpy(), g, 'rec') < 2e-3
+
+
 @pytest.mark.parametrize('seed', range(8))
 def test_tile_equals_generic_on_random_shapes(seed, monkeypatch):
     """Property test: specialised tile kernels (float32) == generic kernels on shapes around the tile, run and

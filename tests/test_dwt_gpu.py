@@ -113,6 +113,64 @@ def test_dwt_fp64_and_fp16_io():
     assert rel(yl, oyl) < 2e-3 and rel(yh[1], oyh[1]) < 2e-3
 
 
+def _last_kernel():
+    from pytorch_wavelets_amd import _lib
+    return _lib.get().wl_last_kernel().decode().split('K = ')[-1].rstrip(']')
+
+
+def test_fp16_config5_reference_golden():
+    """BASELINE configs[4] (DWT J=4 db8 periodization, float16) against the golden generated from the REAL reference
+    (oracle/pin_fp16_config5.py: reference in fp32 on the fp16-rounded input): forward, inverse of the rounded
+    coefficients, and the kernel the engine dispatched - float16 rows in multiples of four take the four-element
+    staging instantiation WlAfbTile<_Float16, 16, 16, 64, 1, 1>."""
+    meta, g = G.INDEX['dwt_h16'], G.load('dwt_h16')
+    xfm = pw.DWTForward(J=meta['J'], wave=meta['wave'], mode=meta['mode']).to(DEV).half()
+    ifm = pw.DWTInverse(wave=meta['wave'], mode=meta['mode']).to(DEV).half()
+    x = torch.tensor(g['x'], device=DEV)
+    assert x.dtype == torch.float16
+    pw.DWTForward(J=1, wave=meta['wave'], mode=meta['mode']).to(DEV).half()(x)
+    assert _last_kernel() == 'WlAfbTile<_Float16, 16, 16, 64, 1, 1>', _last_kernel()
+    yl, yh = xfm(x)
+    assert yl.dtype == torch.float16
+    # float16 taps + one float16 rounding of LL per level (half-ulp 4.9e-4 each): 3e-3 after four levels
+    assert G.relerr(npy(yl.float()), g, 'yl') < 3e-3
+    for j in range(meta['J']):
+        assert G.relerr(npy(yh[j].float()), g, 'yh%d' % j) < 2e-3
+    rec = ifm((torch.tensor(g['yl'], device=DEV).half(), [torch.tensor(g['yh%d' % j], device=DEV).half() for j in range(meta['J'])]))
+    assert G.relerr(npy(rec.float()), g, 'rec') < 2e-3
+    assert 'WlSfbTile<_Float16, 16' in _last_kernel()
+
+
+@pytest.mark.parametrize('W', [2048, 2046])
+def test_fp16_config5_full_plane_size(W):
+    """configs[4] at its real plane size, 2 x 16 x 2048 x W float16 (W = 2048: four-element staging loads; W = 2046:
+    rows that are not a multiple of four take the pair-staging instantiation): J=4 forward against the oracle in
+    float64 on the rounded input (two sampled planes), inverse, round trip."""
+    torch.manual_seed(8)
+    x = torch.randn(2, 16, 2048, W, device=DEV).half()
+    xfm = pw.DWTForward(J=4, wave='db8', mode='periodization').to(DEV).half()
+    ifm = pw.DWTInverse(wave='db8', mode='periodization').to(DEV).half()
+    pw.DWTForward(J=1, wave='db8', mode='periodization').to(DEV).half()(x)
+    assert _last_kernel() == ('WlAfbTile<_Float16, 16, 16, 64, 1, 1>' if W % 4 == 0 else 'WlAfbTile<_Float16, 16, 16, 64, 1, 0>'), _last_kernel()
+    yl, yh = xfm(x)
+    assert yl.shape == (2, 16, 128, (W + 15) // 16) and yh[0].shape == (2, 16, 3, 1024, W // 2)
+    h0, h1 = F.dwt_analysis_taps('db8')
+    g0, g1 = F.dwt_synthesis_taps('db8')
+    # the module's taps are float16 too (.half() converts the buffers, as it does upstream)
+    h0h, h1h = np.float16(h0).astype(np.float64), np.float16(h1).astype(np.float64)
+    for n, c in ((0, 0), (1, 15)):
+        xs = x[n:n + 1, c:c + 1].double().cpu().numpy()
+        oyl, oyh = wo.dwt_forward(xs, 4, h0h, h1h, h0h, h1h, 'periodization')
+        assert rel(yl[n:n + 1, c:c + 1].float(), oyl) < 3e-3   # one float16 rounding of LL per level
+        for a, b in zip(yh, oyh):
+            assert rel(a[n:n + 1, c:c + 1].float(), b) < 2e-3
+    rec = ifm((yl, yh))
+    assert rec.shape == x.shape and rec.dtype == torch.float16
+    # four levels of float16 rounding each way
+    assert float((rec.float() - x.float()).abs().max()) < 2e-2 * float(x.float().abs().max())
+    assert float((rec.float() - x.float()).pow(2).mean().sqrt()) < 2e-3
+
+
 def test_full_size_properties_config1():
     """BASELINE configs[1] at full size (128x3x512x512 fp32): shapes, round trip, linearity and a
     sampled oracle check (the oracle on the full batch would take minutes)."""
