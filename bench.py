@@ -36,41 +36,71 @@ def algorithmic_bytes_fwd(N, C, H, W, J, L, itemsize):
     return N * C * (n_in + n_out) * itemsize
 
 
+def source_digest():
+    """sha256 over the engine's sources: profiles/*_hbm_traffic.json records the digest of the build it was measured
+    on, and the roofline only quotes it when it matches what is running."""
+    import hashlib
+    h = hashlib.sha256()
+    for d, exts in ((os.path.join(ROOT, 'pytorch_wavelets_amd', 'csrc'), ('.h', '.inc', '.hip')),
+                    (os.path.join(ROOT, 'include'), ('.h',))):
+        for f in sorted(os.listdir(d)):
+            if f.endswith(exts):
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(args):
-    """The oracle's C port (oracle/dwt_port.c, OpenMP) - or the numpy oracle if the port is not
-    built - timed on this host's cores on a bounded sample of the same workload."""
+    """The reference's CPU path, restated: oracle/torch_cpu.py = its gather + grouped conv2d / conv_transpose2d
+    formulation on PyTorch-CPU (the reference itself is Python on ATen and cannot travel to this box; the restatement is
+    pinned to its golden vectors by tests/test_oracle_golden.py), all host cores, on a bounded sample of the workload.
+    The OpenMP C port of the numpy oracle (oracle/dwt_port.c) is timed next to it."""
     import numpy as np
+    from oracle import torch_cpu as tc
     from pytorch_wavelets_amd import filters
     h0, h1 = filters.dwt_analysis_taps('db4')
     g0, g1 = filters.dwt_synthesis_taps('db4')
-    rng = np.random.RandomState(0)
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    n = 16
+    x = torch.randn(n, 3, 512, 512, generator=torch.Generator().manual_seed(0))
+
+    def once():
+        with torch.no_grad():
+            yl, yh = tc.dwt_forward(x, 3, h0, h1, 'symmetric')
+            return tc.dwt_inverse(yl, yh, g0, g1, 'symmetric')
+    once()
+    reps, t0 = 0, time.perf_counter()
+    while reps < 3 or time.perf_counter() - t0 < 10.0:
+        once()
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    out = {'value': round(x.numel() / dt / 1e6, 2), 'unit': 'Mpixels/s', 'cores': ncores, 'kind': 'restated-torch',
+           'torch_threads': torch.get_num_threads(),
+           'sample': 'oracle/torch_cpu.py (the reference\'s conv2d / conv_transpose2d formulation on PyTorch-CPU, fp32), '
+                     'fwd+inv J=3 db4 symmetric on %dx3x512x512, %d reps; the real reference measured 16.2 Mpixels/s on '
+                     '8 vCPU in the authoring container (BASELINE.md)' % (n, reps)}
     try:
         from oracle import dwt_port
-        ncores = os.cpu_count() or 1
-        n = max(2, min(64, ncores))
-        x = rng.randn(n, 3, 512, 512).astype(np.float32)
-        dwt_port.fwd_inv(x, 3, h0, h1, g0, g1, 'symmetric', threads=ncores)    # warm-up
+        rng = np.random.RandomState(0)
+        m = max(2, min(64, ncores))
+        xp = rng.randn(m, 3, 512, 512).astype(np.float32)
+        dwt_port.fwd_inv(xp, 3, h0, h1, g0, g1, 'symmetric', threads=ncores)
         reps, t0 = 0, time.perf_counter()
-        while reps < 3 or time.perf_counter() - t0 < 10.0:
-            dwt_port.fwd_inv(x, 3, h0, h1, g0, g1, 'symmetric', threads=ncores)
+        while reps < 3 or time.perf_counter() - t0 < 5.0:
+            dwt_port.fwd_inv(xp, 3, h0, h1, g0, g1, 'symmetric', threads=ncores)
             reps += 1
-        dt = (time.perf_counter() - t0) / reps
-        return {'value': round(x.size / dt / 1e6, 2), 'unit': 'Mpixels/s', 'cores': ncores, 'kind': 'port',
-                'sample': 'oracle/dwt_port.c (OpenMP fp32 port of the oracle), fwd+inv J=3 db4 symmetric on '
-                          '%dx3x512x512, %d reps' % (n, reps)}
-    except Exception:
-        from oracle import wavelet_oracle as wo
-        x = rng.randn(2, 3, 512, 512).astype(np.float32).astype(np.float64)
-        t0 = time.perf_counter()
-        reps = 0
-        while reps < 2 or time.perf_counter() - t0 < 10.0:
-            yl, yh = wo.dwt_forward(x, 3, h0, h1, h0, h1, 'symmetric')
-            wo.dwt_inverse(yl, yh, g0, g1, g0, g1, 'symmetric')
-            reps += 1
-        dt = (time.perf_counter() - t0) / reps
-        return {'value': round(x.size / dt / 1e6, 2), 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'port',
-                'sample': 'numpy float64 oracle (oracle/wavelet_oracle.py), fwd+inv J=3 db4 symmetric on '
-                          '2x3x512x512, %d reps' % reps}
+        out['c_port'] = {'value': round(xp.size / ((time.perf_counter() - t0) / reps) / 1e6, 2), 'unit': 'Mpixels/s',
+                         'kind': 'port', 'sample': 'oracle/dwt_port.c (OpenMP, one plane per thread) on %dx3x512x512' % m}
+    except Exception as e:   # the C port is optional
+        out['c_port'] = {'error': str(e)[:80]}
+    return out
+
+
+def _kernel_name(lib):
+    """Functor of the kernel this thread launched last, as the engine reports it (wl_last_kernel)."""
+    raw = lib.wl_last_kernel().decode()
+    return raw.split('K = ')[-1].rstrip(']') if 'K = ' in raw else raw
 
 
 def main():
@@ -81,26 +111,73 @@ def main():
     ap.add_argument('--batch', type=int, default=128, help='images per GPU (BASELINE configs[1]: 128)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the DTCWT / ScatLayer / fp16 context timings')
+    ap.add_argument('--emulate', action='store_true',
+                    help='TEST ONLY: run the whole harness on CPU tensors through the host emulation of the kernels '
+                         '(tests/emu) with the gloo backend - exercises the multi-rank control flow without a GPU')
     args = ap.parse_args()
 
     import __graft_entry__ as ge
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if rank == 0:
-        ge.build()
+    emu = args.emulate
+    if emu:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import emu_backend
+        from pytorch_wavelets_amd import ops
+        ops._TEST_BACKEND = lib = emu_backend.handle()
+    else:
+        if rank == 0:
+            ge.build()
     import pytorch_wavelets_amd as pw
     from pytorch_wavelets_amd import parallel
-
-    assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    dev = torch.device('cuda', local_rank)
-    torch.cuda.set_device(dev)
+    if not emu:
+        from pytorch_wavelets_amd import _lib
+        assert torch.cuda.is_available(), 'bench.py needs a GPU'
+        dev = torch.device('cuda', local_rank)
+        torch.cuda.set_device(dev)
+    else:
+        dev = torch.device('cpu')
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)   # nccl == RCCL on ROCm
+        if emu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)   # nccl == RCCL on ROCm
         dist.barrier()
+    if not emu:
+        lib = _lib.get()
+
+    def sync():
+        if not emu:
+            torch.cuda.synchronize()
+
+    class _Timer(object):
+        """HIP events on the launch stream (wall clock in emulation mode)."""
+        def __init__(self):
+            self.e0 = self.e1 = None
+            if not emu:
+                self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def run(self, fn, n):
+            fn()
+            sync()
+            if emu:
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                return (time.perf_counter() - t0) * 1e3 / n
+            self.e0.record()
+            for _ in range(n):
+                fn()
+            self.e1.record()
+            torch.cuda.synchronize()
+            return self.e0.elapsed_time(self.e1) / n
+    timer = _Timer()
 
     N, C, H, W, J, wave, mode = args.batch, 3, 512, 512, 3, 'db4', 'symmetric'
+    if emu:
+        H = W = 64
     xfm = pw.DWTForward(J=J, wave=wave, mode=mode).to(dev)
     ifm = pw.DWTInverse(wave=wave, mode=mode).to(dev)
     if world > 1:
@@ -112,7 +189,7 @@ def main():
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     def step():
         with torch.no_grad():
@@ -133,97 +210,75 @@ def main():
         dt = float(tmax.item())
     err = float((rec - x).abs().max() / x.abs().max())
 
-    # ---- per-kernel roofline: forward transform timed alone with HIP events on the launch stream
+    # ---- per-kernel roofline.  The forward transform is ONE launch of the streaming kernel (all J levels, LL_j in
+    # LDS): it is the dominant kernel, timed alone with HIP events on the launch stream; its algorithmic bytes are
+    # x in + yl, yh[j] out.  The kernel names are the engine's own report of what it dispatched.
     with torch.no_grad():
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        xfm(x)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(args.steps):
-            yl, yh = xfm(x)
-        e1.record()
-        torch.cuda.synchronize()
-        fwd_ms = e0.elapsed_time(e1) / args.steps
-        ifm((yl, yh))
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(args.steps):
-            ifm((yl, yh))
-        e1.record()
-        torch.cuda.synchronize()
-        inv_ms = e0.elapsed_time(e1) / args.steps
+        yl, yh = xfm(x)
+        fwd_launches = 0
+        fwd_ms = timer.run(lambda: xfm(x), args.steps)
+        fwd_kernel = _kernel_name(lib)
+        inv_ms = timer.run(lambda: ifm((yl, yh)), args.steps)
+        inv_kernel = _kernel_name(lib)
+    from pytorch_wavelets_amd.dwt import lowlevel as _ll
+    fused = 'WlAfbRows' in fwd_kernel
+    fwd_launches = 1 if fused else J
     fwd_bytes = algorithmic_bytes_fwd(N, C, H, W, J, 8, 4)
     fwd_gbs = fwd_bytes / (fwd_ms * 1e-3) / 1e9
     inv_gbs = fwd_bytes / (inv_ms * 1e-3) / 1e9
-    # dominant kernel = the level-1 analysis launch, timed alone: algorithmic bytes = x in, ll_1 + yh_0 out
+    # the same forward as one tile-kernel launch per level (the round-1 path), for the record
     with torch.no_grad():
-        xfm1 = pw.DWTForward(J=1, wave=wave, mode=mode).to(dev)
-        xfm1(x)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(args.steps):
-            xfm1(x)
-        e1.record()
-        torch.cuda.synchronize()
-        l1_ms = e0.elapsed_time(e1) / args.steps
-    l1_bytes = algorithmic_bytes_fwd(N, C, H, W, 1, 8, 4)
-    l1_gbs = l1_bytes / (l1_ms * 1e-3) / 1e9
+        _ll.FUSED_LEVELS = False
+        tile_ms = timer.run(lambda: xfm(x), args.steps)
+        tile_kernel = _kernel_name(lib)
+        _ll.FUSED_LEVELS = True
     # what a plain device copy of the same footprint achieves on this box (read + write bytes / time)
     with torch.no_grad():
         cdst = torch.empty_like(x)
-        cdst.copy_(x)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(args.steps):
-            cdst.copy_(x)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 2 * x.numel() * 4 / (e0.elapsed_time(e1) / args.steps * 1e-3) / 1e9
+        copy_gbs = 2 * x.numel() * 4 / (timer.run(lambda: cdst.copy_(x), args.steps) * 1e-3) / 1e9
         del cdst
     # the other BASELINE configs (parity-test cases, not the metric): timed once on rank 0 at N=1 as context
     other = None
-    if world == 1 and not args.no_other_configs:
+    if world == 1 and not args.no_other_configs and not emu:
         other = {}
-
-        def timed(fn, n=10):
-            fn()
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(n):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / n
         with torch.no_grad():
             xd = torch.randn(64, 3, 512, 512, device=dev)
             dx, di = pw.DTCWTForward(J=3).to(dev), pw.DTCWTInverse().to(dev)
             dyl, dyh = dx(xd)
-            tf, ti = timed(lambda: dx(xd)), timed(lambda: di((dyl, dyh)))
+            tf, ti = timer.run(lambda: dx(xd), 10), timer.run(lambda: di((dyl, dyh)), 10)
             other['dtcwt_j3_near_sym_a_qshift_a_64x3x512x512_fp32'] = {
                 'fwd_ms': round(tf, 4), 'inv_ms': round(ti, 4), 'fwd_inv_mpix_s': round(xd.numel() / (tf + ti) / 1e3, 1),
-                'fwd_frac_of_hbm_peak_at_20B_per_px': round(20 * xd.numel() / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                'fwd_frac_of_hbm_peak_at_20B_per_px': round(20 * xd.numel() / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                'inv_frac_of_hbm_peak_at_20B_per_px': round(20 * xd.numel() / (ti * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             del xd, dyl, dyh
             xs = torch.randn(256, 3, 256, 256, device=dev)
             sl = pw.ScatLayer().to(dev)
-            ts = timed(lambda: sl(xs))
+            ts = timer.run(lambda: sl(xs), 10)
             other['scatlayer_256x3x256x256_fp32_one_gpu'] = {
                 'fwd_ms': round(ts, 4), 'mpix_s': round(xs.numel() / ts / 1e3, 1),
                 'frac_of_hbm_peak_at_11B_per_px': round(11 * xs.numel() / (ts * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             del xs
-            xh = torch.randn(8, 16, 2048, 2048, device=dev).half()
+            xh = torch.randn(32, 16, 2048, 2048, device=dev, dtype=torch.float16)   # configs[4] at its full size (4.3 GB)
             hx = pw.DWTForward(J=4, wave='db8', mode='periodization').to(dev).half()
-            th = timed(lambda: hx(xh), 5)
-            other['dwt_j4_db8_periodization_8x16x2048x2048_fp16'] = {
-                'fwd_ms': round(th, 4), 'mpix_s': round(xh.numel() / th / 1e3, 1),
-                'frac_of_hbm_peak_at_4B_per_px': round(4 * xh.numel() / (th * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                'note': 'batch reduced from 32 to 8 images of 16 channels'}
-            del xh
-    info = pw.engine_info(xfm, x)
+            hi = pw.DWTInverse(wave='db8', mode='periodization').to(dev).half()
+            hyl, hyh = hx(xh)
+            th = timer.run(lambda: hx(xh), 3)
+            hk = _kernel_name(lib)
+            tih = timer.run(lambda: hi((hyl, hyh)), 3)
+            other['dwt_j4_db8_periodization_32x16x2048x2048_fp16'] = {
+                'fwd_ms': round(th, 4), 'inv_ms': round(tih, 4), 'fwd_mpix_s': round(xh.numel() / th / 1e3, 1),
+                'fwd_frac_of_hbm_peak_at_4B_per_px': round(4 * xh.numel() / (th * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                'inv_frac_of_hbm_peak_at_4B_per_px': round(4 * xh.numel() / (tih * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                'last_fwd_kernel': hk}
+            del xh, hyl, hyh
+    # HBM traffic of the dominant kernel: only from a PMC summary measured on THIS build of the sources
     traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-    if os.path.exists(tpath):
+    tpath = os.path.join(ROOT, 'profiles', 'r02_hbm_traffic.json')
+    if os.path.exists(tpath) and not emu:
         try:
-            traffic = json.load(open(tpath)).get(info['fwd_kernel'], {}).get('hbm_bytes_corrected')
+            tj = json.load(open(tpath))
+            if tj.get('source_digest') == source_digest():
+                traffic = tj.get('kernels', {}).get(fwd_kernel, {}).get('hbm_bytes_corrected')
         except Exception:
             traffic = None
 
@@ -237,30 +292,34 @@ def main():
             'ms_per_step': round(dt / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'DWTForward+DWTInverse J=3 db4 symmetric, %dx3x512x512 fp32 per GPU '
-                                   '(BASELINE configs[1])' % N,
+            'config': {'workload': 'DWTForward+DWTInverse J=3 db4 symmetric, %dx3x%dx%d fp32 per GPU '
+                                   '(BASELINE configs[1])' % (N, H, W),
                        'global_batch': world * N, 'parallelism': 'batch-sharded x%d, no data-path collective' % world,
-                       'fwd_path': info['fwd_path'], 'inv_path': info['inv_path']},
-            'roofline': {'bound': 'hbm', 'kernel': info['fwd_kernel'] + ' (level-1 launch)',
-                         'achieved': round(l1_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(l1_gbs / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                         'algorithmic_bytes_per_launch': l1_bytes, 'avg_launch_ms': round(l1_ms, 4),
-                         'device_copy_gbs': round(copy_gbs, 1), 'frac_of_device_copy': round(l1_gbs / copy_gbs, 4),
-                         'forward_all_levels': {'achieved': round(fwd_gbs, 1), 'frac': round(fwd_gbs / HBM_PEAK_GBS, 4),
-                                                'algorithmic_bytes': fwd_bytes, 'avg_ms': round(fwd_ms, 4),
-                                                'launches': info['fwd_launches']},
-                         'inverse': {'kernel': info['inv_kernel'], 'achieved': round(inv_gbs, 1),
+                       'fwd_path': ('one launch of the streaming kernel for all %d levels (LL_j in LDS)' % J) if fused
+                                   else 'one tile-kernel launch per level',
+                       'inv_path': 'one polyphase tile-kernel launch per level'},
+            'roofline': {'bound': 'hbm', 'kernel': fwd_kernel + (' (all %d levels, one launch)' % J if fused else ' (last level)'),
+                         'achieved': round(fwd_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(fwd_gbs / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'algorithmic_bytes_per_launch': fwd_bytes, 'avg_launch_ms': round(fwd_ms, 4),
+                         'launches_per_forward': fwd_launches,
+                         'device_copy_gbs': round(copy_gbs, 1), 'frac_of_device_copy': round(fwd_gbs / copy_gbs, 4),
+                         'forward_per_level_tile_kernels': {'kernel': tile_kernel, 'avg_ms': round(tile_ms, 4),
+                                                            'frac': round(fwd_bytes / (tile_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                         'inverse': {'kernel': inv_kernel, 'achieved': round(inv_gbs, 1),
                                      'frac': round(inv_gbs / HBM_PEAK_GBS, 4), 'avg_ms': round(inv_ms, 4),
-                                     'launches_per_inverse': info['inv_launches']}},
+                                     'launches_per_inverse': J}},
             'fwd_mpix_s': round(N * C * H * W / (fwd_ms * 1e-3) / 1e6, 1),
             'inv_mpix_s': round(N * C * H * W / (inv_ms * 1e-3) / 1e6, 1),
             'roundtrip_rel_err': err,
         }
+        if emu:
+            out['data'] = 'synthetic (HOST EMULATION of the kernels: control-flow test, not a measurement)'
         if other is not None:
             out['other_configs'] = other
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not emu:
             out['cpu_baseline'] = cpu_baseline(args)
-        elif world > 1:
+        elif world > 1 or emu:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
     if world > 1:
