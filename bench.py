@@ -61,7 +61,6 @@ def cpu_baseline(args):
     h0, h1 = filters.dwt_analysis_taps('db4')
     g0, g1 = filters.dwt_synthesis_taps('db4')
     ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
     n = 16
     x = torch.randn(n, 3, 512, 512, generator=torch.Generator().manual_seed(0))
 
@@ -69,17 +68,25 @@ def cpu_baseline(args):
         with torch.no_grad():
             yl, yh = tc.dwt_forward(x, 3, h0, h1, 'symmetric')
             return tc.dwt_inverse(yl, yh, g0, g1, 'symmetric')
-    once()
-    reps, t0 = 0, time.perf_counter()
-    while reps < 3 or time.perf_counter() - t0 < 10.0:
+    # ATen's grouped convolutions do not scale to hundreds of threads (256 threads measured 20x slower than 8 on the
+    # MI355X host): time a few intra-op pool sizes for ~3 s each and report the best one, with the cores it used
+    tried, best = {}, None
+    for nt in sorted(set(t for t in (8, 16, 32, 64, ncores) if t <= ncores)):
+        torch.set_num_threads(nt)
         once()
-        reps += 1
-    dt = (time.perf_counter() - t0) / reps
-    out = {'value': round(x.numel() / dt / 1e6, 2), 'unit': 'Mpixels/s', 'cores': ncores, 'kind': 'restated-torch',
-           'torch_threads': torch.get_num_threads(),
+        reps, t0 = 0, time.perf_counter()
+        while reps < 2 or time.perf_counter() - t0 < 3.0:
+            once()
+            reps += 1
+        mp = x.numel() / ((time.perf_counter() - t0) / reps) / 1e6
+        tried[str(nt)] = round(mp, 2)
+        if best is None or mp > best[1]:
+            best = (nt, mp, reps)
+    out = {'value': round(best[1], 2), 'unit': 'Mpixels/s', 'cores': best[0], 'kind': 'restated-torch',
+           'host_cores': ncores, 'mpix_s_by_torch_threads': tried,
            'sample': 'oracle/torch_cpu.py (the reference\'s conv2d / conv_transpose2d formulation on PyTorch-CPU, fp32), '
-                     'fwd+inv J=3 db4 symmetric on %dx3x512x512, %d reps; the real reference measured 16.2 Mpixels/s on '
-                     '8 vCPU in the authoring container (BASELINE.md)' % (n, reps)}
+                     'fwd+inv J=3 db4 symmetric on %dx3x512x512, %d reps at the best thread count; the real reference '
+                     'measured 16.2 Mpixels/s on 8 vCPU in the authoring container (BASELINE.md)' % (n, best[2])}
     try:
         from oracle import dwt_port
         rng = np.random.RandomState(0)
@@ -278,7 +285,9 @@ def main():
         try:
             tj = json.load(open(tpath))
             if tj.get('source_digest') == source_digest():
-                traffic = tj.get('kernels', {}).get(fwd_kernel, {}).get('hbm_bytes_corrected')
+                for k, v in tj.get('kernels', {}).items():   # rocprof prints defaulted template arguments too
+                    if k.strip().startswith(fwd_kernel.rstrip('>')):
+                        traffic = v.get('hbm_bytes_corrected')
         except Exception:
             traffic = None
 
