@@ -142,6 +142,24 @@ int wl_scat_bwd_level1(const void* dz, const void* drdx, const void* drdy, void*
                        int H, int W, const void* h0, int L0, const void* h1, int L1, int mode, int combine_colour,
                        void* stream);
 
+/* ---- single-axis building blocks -------------------------------------------------------------------------------
+ * One strided / dilated correlation with boundary extension along the middle axis of a dense (outer, n, inner) tensor:
+ *   y[o, out_offset + out_stride*k, i] = sum_{t<ntaps} h[tap_offset + tap_stride*t] * ext(x[o,:,i], start + step*k + tap_step*t)
+ * for k in [0,K); y index = o*y_outer_stride + q*inner + i.  h1/y1 (nullable) = a second tap set / output on the same
+ * samples.  `ext`: 0 zero, 1 symmetric (half-sample), 2 reflect (whole-sample), 3 periodic, 4 periodization, 5 replicate.
+ * Replaces the ATen bodies of afb1d on one axis (AFB1D.forward, dwt/lowlevel.py:368-407 -> :91-172), afb1d_atrous
+ * (:175-223) and the DTCWT primitives colfilter / rowfilter / coldfilt / rowdfilt / colifilt / rowifilt
+ * (dtcwt/lowlevel.py:70-239), each of which is one to four such correlations. */
+int wl_corr1d(const void* x, void* y0, void* y1, int dtype, int64_t outer, int n, int64_t inner, int64_t y_outer_stride,
+              int K, const void* h0, const void* h1, int tap_offset, int tap_stride, int ntaps, int start, int step,
+              int tap_step, int ext, int out_offset, int out_stride, void* stream);
+
+/* 1-D two-channel synthesis bank along the middle axis = sfb1d (dwt/lowlevel.py:226-271; SFB1D.forward :697-727 and
+ * AFB1D.backward :409-424): lo, hi (outer, K, inner) [hi may be NULL = zeros] -> y (outer, ny, inner) with
+ * ny <= 2K-L+2 (2K for periodization, whose single fold of the wrapped tail is reproduced literally). */
+int wl_synth1d(const void* lo, const void* hi, void* y, int dtype, int64_t outer, int K, int64_t inner, int ny,
+               const void* g0, const void* g1, int L, int mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -563,3 +563,80 @@ def scat_layer_backward(dZ, saved, h0o, h1o, mode='symmetric', combine_colour=Fa
     imags = dr * drdy
     highs = np.stack([np.moveaxis(reals, 1, 2), np.moveaxis(imags, 1, 2)], axis=-1)
     return inv_j1(ll, highs, h0o, h1o, mode)
+
+
+# ----------------------------------------------------------------------------------------------
+# 1-D DWT and the undecimated (a-trous) bank
+# ----------------------------------------------------------------------------------------------
+def dwt1d_forward(x, J, h0, h1, mode):
+    """DWT1DForward.forward (dwt/transform1d.py:38-59): J x AFB1D (dwt/lowlevel.py:368-407 = afb1d along the last
+    axis).  x (N,C,L) -> (yl, [yh_0..])."""
+    mode_to_int(mode)
+    lo = np.asarray(x)[:, :, None, :]
+    highs = []
+    for _ in range(J):
+        lo, hi = afb1d(lo, h0, h1, mode, axis=3)
+        highs.append(hi[:, :, 0])
+    return lo[:, :, 0], highs
+
+
+def dwt1d_inverse(yl, yh, g0, g1, mode):
+    """DWT1DInverse.forward (dwt/transform1d.py:93-115): coarsest first, None = zeros, 'unpad' by one sample."""
+    mode_to_int(mode)
+    x0 = np.asarray(yl)
+    for x1 in yh[::-1]:
+        if x1 is None:
+            x1 = np.zeros_like(x0)
+        if x0.shape[-1] > x1.shape[-1]:
+            x0 = x0[..., :-1]
+        x0 = sfb1d(x0[:, :, None, :], np.asarray(x1)[:, :, None, :], g0, g1, mode, axis=3)[:, :, 0]
+    return x0
+
+
+def _ext_any(idx, n, mode):
+    """ext_index plus the two paddings only mypad knows (dwt/lowlevel.py:28-88): 'constant' (zeros) and 'replicate'."""
+    if mode == 'constant':
+        mode = 'zero'
+    if mode == 'replicate':
+        idx = np.asarray(idx, dtype=np.int64)
+        return np.clip(idx, 0, n - 1), np.ones(idx.shape, dtype=bool)
+    return ext_index(idx, n, mode)
+
+
+def afb1d_atrous(x, h0, h1, mode='periodic', axis=-1, dilation=1):
+    """dwt/lowlevel.py:175-223: pad (L*dil)//2 - dil before and (L*dil)//2 after with mypad(mode), then a dilated
+    cross-correlation with the stored (reversed) taps:  y_b[i] = sum_t h_b[t] * ext(x, i - (L2 - dil) + dil*t).
+    Returns (lo, hi), same length as x along `axis`."""
+    if mode not in ('zero', 'constant', 'symmetric', 'reflect', 'periodic', 'replicate'):
+        raise ValueError("Unkown pad type: {}".format(mode))
+    x = np.asarray(x)
+    axis = axis % x.ndim
+    n = x.shape[axis]
+    outs = []
+    for h in (h0, h1):
+        h = np.asarray(h, dtype=x.dtype).ravel()
+        L = h.size
+        L2 = (L * dilation) // 2
+        K = n + 2 * L2 - dilation - dilation * (L - 1)
+        i = np.arange(K)
+        y = 0
+        for t in range(L):
+            src, valid = _ext_any(i - (L2 - dilation) + dilation * t, n, mode)
+            v = np.take(x, src, axis=axis)
+            if not valid.all():
+                shp = [1] * x.ndim
+                shp[axis] = -1
+                v = v * valid.reshape(shp)
+            y = y + h[t] * v
+        outs.append(y)
+    return outs[0], outs[1]
+
+
+def afb2d_atrous(x, h0_col, h1_col, h0_row, h1_row, mode, dilation=1):
+    """dwt/lowlevel.py:475-521: rows (the *row* pair along W) then columns; (N, 4C, H, W) with channel 4c + 2r + b."""
+    lo, hi = afb1d_atrous(x, h0_row, h1_row, mode, 3, dilation)
+    outs = []
+    for r in (lo, hi):
+        outs.extend(afb1d_atrous(r, h0_col, h1_col, mode, 2, dilation))
+    n, c = x.shape[:2]
+    return np.stack(outs, axis=2).reshape(n, 4 * c, outs[0].shape[2], outs[0].shape[3])

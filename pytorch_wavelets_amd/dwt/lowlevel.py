@@ -137,6 +137,120 @@ class AFB2DMulti(Function):
         return dx, None, None, None, None, None, None
 
 
+class AFB1D(Function):
+    """One level of 1-D analysis.  ``AFB1D.apply(x:(N,C,L), h0, h1, mode_int) -> (x0, x1)`` each (N,C,L')
+    (reference dwt/lowlevel.py:368-424).  Backward = synthesis with the same stored taps, cropped to the input length."""
+
+    @staticmethod
+    def forward(ctx, x, h0, h1, mode):
+        _check_bank_mode(mode)
+        ctx.save_for_backward(h0, h1)
+        ctx.shape = x.shape[2]
+        ctx.mode = mode
+        return ops.afb1d(x, h0, h1, mode, 2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dx0, dx1):
+        dx = None
+        if ctx.needs_input_grad[0]:
+            h0, h1 = ctx.saved_tensors
+            dx = ops.sfb1d(dx0, dx1, h0, h1, ctx.mode, 2, out_len=ctx.shape)
+        return dx, None, None, None
+
+
+class SFB1D(Function):
+    """One level of 1-D synthesis.  ``SFB1D.apply(low, high, g0, g1, mode_int) -> y`` (reference dwt/lowlevel.py:697-743).
+    Backward = analysis with the stored synthesis taps."""
+
+    @staticmethod
+    def forward(ctx, low, high, g0, g1, mode):
+        _check_bank_mode(mode)
+        ctx.mode = mode
+        ctx.save_for_backward(g0, g1)
+        return ops.sfb1d(low, high, g0, g1, mode, 2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dlow, dhigh = None, None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            g0, g1 = ctx.saved_tensors
+            dlow, dhigh = ops.afb1d(dy, g0, g1, ctx.mode, 2)
+        return dlow, dhigh, None, None, None
+
+
+def _as_taps(h, x):
+    """Array-likes are the pywt-ordered filters (reversed into cross-correlation taps, as the reference does when it is
+    handed arrays); tensors are taken as already prepared."""
+    if isinstance(h, torch.Tensor):
+        return h
+    return torch.tensor(np.copy(np.array(h, dtype=np.float64).ravel()[::-1]), dtype=torch.float, device=x.device)
+
+
+def afb1d(x, h0, h1, mode='zero', dim=-1):
+    """Function-level 1-D analysis along one axis of a 4-D tensor (reference dwt/lowlevel.py:91-172): returns the
+    lowpass and highpass sub-bands interleaved along the channel axis, (N, 2C, H', W') with channel 2c = low."""
+    d = dim % 4
+    lo, hi = ops.afb1d(x, _as_taps(h0, x), _as_taps(h1, x), mode_to_int(mode), d)
+    n, c = lo.shape[:2]
+    return torch.stack([lo, hi], dim=2).reshape(n, 2 * c, lo.shape[2], lo.shape[3])
+
+
+def sfb1d(lo, hi, g0, g1, mode='zero', dim=-1):
+    """Function-level 1-D synthesis along one axis of 4-D tensors (reference dwt/lowlevel.py:226-271); array-like
+    filters are used as given (no reversal), like upstream."""
+    d = dim % 4
+
+    def prep(g):
+        return g if isinstance(g, torch.Tensor) else torch.tensor(np.copy(np.array(g, dtype=np.float64).ravel()),
+                                                                  dtype=torch.float, device=lo.device)
+    return ops.sfb1d(lo, hi, prep(g0), prep(g1), mode_to_int(mode), d)
+
+
+_ATROUS_EXT = {'zero': ops.EXT_ZERO, 'constant': ops.EXT_ZERO, 'symmetric': ops.EXT_SYM, 'reflect': ops.EXT_REFL,
+               'periodic': ops.EXT_PERIODIC, 'replicate': ops.EXT_REPLICATE}
+
+
+def afb1d_atrous(x, h0, h1, mode='periodic', dim=-1, dilation=1):
+    """Undecimated (a-trous) 1-D analysis along one axis (reference dwt/lowlevel.py:175-223): the taps are dilated, the
+    signal is padded by (L*dilation)//2 - dilation before and (L*dilation)//2 after with `mode`, the output keeps the
+    input size.  Returns (N, 2C, H, W) with channel 2c = low.  NB like upstream the padding is done by ``mypad``, which
+    knows 'symmetric', 'periodic', 'constant', 'reflect', 'replicate' and 'zero' - 'periodization' raises."""
+    if mode not in _ATROUS_EXT:
+        raise ValueError("Unkown pad type: {}".format(mode))
+    d = dim % 4
+    t0, t1 = _as_taps(h0, x), _as_taps(h1, x)
+    L = t0.numel()
+    L2 = (L * dilation) // 2
+    n = x.shape[d]
+    K = n + 2 * L2 - dilation - dilation * (L - 1)
+    lo, hi = ops.corr1d(x, d, t0, t1, K, -(L2 - dilation), 1, dilation, _ATROUS_EXT[mode])
+    nb, c = lo.shape[:2]
+    return torch.stack([lo, hi], dim=2).reshape(nb, 2 * c, lo.shape[2], lo.shape[3])
+
+
+def afb2d_atrous(x, filts, mode='periodization', dilation=1):
+    """One undecimated 2-D level (reference dwt/lowlevel.py:475-521): rows then columns; returns (N, 4C, H, W) with
+    channel 4c + 2r + b (r: band along W, b: band along H), i.e. (ll, lh, hl, hh) per input channel."""
+    tensorize = [not isinstance(f, torch.Tensor) for f in filts]
+    if len(filts) == 2:
+        h0, h1 = filts
+        if True in tensorize:
+            h0_col, h1_col, h0_row, h1_row = prep_filt_afb2d(h0, h1, device=x.device)
+        else:
+            h0_col, h0_row, h1_col, h1_row = h0, h0.transpose(2, 3), h1, h1.transpose(2, 3)
+    elif len(filts) == 4:
+        if True in tensorize:
+            h0_col, h1_col, h0_row, h1_row = prep_filt_afb2d(*filts, device=x.device)
+        else:
+            h0_col, h1_col, h0_row, h1_row = filts
+    else:
+        raise ValueError("Unknown form for input filts")
+    lohi = afb1d_atrous(x, h0_row, h1_row, mode=mode, dim=3, dilation=dilation)
+    return afb1d_atrous(lohi, h0_col, h1_col, mode=mode, dim=2, dilation=dilation)
+
+
 def afb2d(x, filts, mode='zero'):
     """Function-level analysis (reference dwt/lowlevel.py:427-472): ``filts`` is a 2- or 4-tuple
     of arrays / tensors (h0_col, h1_col[, h0_row, h1_row]); here the *col* pair really filters

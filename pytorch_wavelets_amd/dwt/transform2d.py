@@ -75,6 +75,39 @@ class DWTInverse(nn.Module):
         return ll
 
 
+class SWTForward(nn.Module):
+    """2-D stationary (undecimated) wavelet transform, ``pytorch_wavelets.dwt.transform2d.SWTForward`` (reference
+    transform2d.py:151-212; not exported from the package upstream either).  One list entry per level, each
+    (N, 4C, H, W) with the four sub-bands (ll, lh, hl, hh) of channel c at channels 4c..4c+3 - which is what the
+    reference's level returns (its docstring promises (N, C, 4, H, W), its code does not reshape).
+
+    Two upstream defects are NOT reproduced: the default ``mode='periodization'`` raises in upstream's ``mypad``
+    (here too: use 'periodic', 'symmetric', 'reflect', 'zero', 'constant' or 'replicate'), and J > 1 crashes upstream
+    (it indexes the 4-D level output as if it were 5-D); here level j+1 filters the ll channels of level j with the
+    filters dilated by 2**j, which is the documented intent."""
+
+    def __init__(self, J=1, wave='db1', mode='periodization'):
+        super().__init__()
+        h0_col, h1_col, h0_row, h1_row = _resolve_bank(wave, 'dec_lo', 'dec_hi')
+        filts = lowlevel.prep_filt_afb2d(h0_col, h1_col, h0_row, h1_row)
+        self.register_buffer('h0_col', filts[0])
+        self.register_buffer('h1_col', filts[1])
+        self.register_buffer('h0_row', filts[2])
+        self.register_buffer('h1_row', filts[3])
+        self.J = J
+        self.mode = mode
+
+    def forward(self, x):
+        ll = x
+        coeffs = []
+        filts = (self.h0_col, self.h1_col, self.h0_row, self.h1_row)
+        for j in range(self.J):
+            y = lowlevel.afb2d_atrous(ll, filts, self.mode, 2 ** j)
+            coeffs.append(y)
+            ll = y[:, 0::4]
+        return coeffs
+
+
 def describe_path(module, x=None):
     """Kernel names / launch counts of the DWT path (bench.py labels its roofline with this)."""
     J = getattr(module, 'J', 3)

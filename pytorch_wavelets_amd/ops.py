@@ -171,6 +171,93 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=0):
     return yl, yh
 
 
+# ---------------------------------------------------------------------------------------------- single axis
+EXT_ZERO, EXT_SYM, EXT_REFL, EXT_PERIODIC, EXT_PER, EXT_REPLICATE = 0, 1, 2, 3, 4, 5
+_MODE_TO_EXT = {0: EXT_ZERO, 1: EXT_SYM, 2: EXT_PER, 4: EXT_REFL, 6: EXT_PERIODIC}
+
+
+def corr1d(x, dim, h0, h1, K, start, step, tap_step=1, ext=EXT_SYM, taps=None, out=None, out_offset=0, out_stride=1,
+           ny=None):
+    """y[.., out_offset + out_stride*k, ..] = sum_t h[t] * ext(x, start + step*k + tap_step*t) along axis `dim` of a
+    dense tensor, k in [0,K).  h1 (optional) = a second tap set on the same samples -> returns (y0, y1).  `taps` =
+    (offset, stride, count) selects a sub-sequence of the stored taps; `out` = tensors to write into (interleaved
+    outputs of several calls); ny = length of the output axis (default out_offset + out_stride*K)."""
+    _check_tensor(x, 'x')
+    x = x.contiguous()
+    dim = dim % x.dim()
+    n = x.shape[dim]
+    outer = 1
+    for v in x.shape[:dim]:
+        outer *= v
+    inner = 1
+    for v in x.shape[dim + 1:]:
+        inner *= v
+    t0 = _taps(h0, x)
+    t1 = None if h1 is None else _taps(h1, x)
+    off, ts, nt = taps if taps is not None else (0, 1, t0.numel())
+    if ny is None:
+        ny = out_offset + out_stride * K
+    shape = list(x.shape)
+    shape[dim] = ny
+    if out is None:
+        alloc = torch.empty if (out_stride == 1 and out_offset == 0 and ny == K) else torch.zeros
+        out = (alloc(shape, dtype=x.dtype, device=x.device),
+               None if h1 is None else alloc(shape, dtype=x.dtype, device=x.device))
+    y0, y1 = out
+    if x.numel() and K:
+        rc = _call('wl_corr1d', x, x.data_ptr(), y0.data_ptr(), None if y1 is None else y1.data_ptr(), _DTYPES[x.dtype],
+                   outer, n, inner, ny * inner, K, t0.data_ptr(), None if t1 is None else t1.data_ptr(), off, ts, nt,
+                   start, step, tap_step, ext, out_offset, out_stride, _stream(x))
+        _lib.check(rc, 'wl_corr1d')
+    return (y0, y1) if h1 is not None else y0
+
+
+def afb1d(x, h0, h1, mode, dim):
+    """One analysis level along one axis: (lo, hi), each with coeff_len(n) samples along `dim` (taps = the stored,
+    reversed ones).  y[k] = sum_j h[j] * ext(x, 2k + base + j)."""
+    n, L = x.shape[dim], h0.numel()
+    K = coeff_len(n, L, mode)
+    if mode == 2:
+        if n + (n & 1) < L - 1:
+            raise NotImplementedError('periodization of a signal shorter than the filter along one axis '
+                                      '(the reference folds only once there): not implemented for the 1-D operators')
+        base = 1 - L // 2
+    else:
+        base = -((2 * (K - 1) - n + L) // 2)
+    return corr1d(x, dim, h0, h1, K, base, 2, 1, _MODE_TO_EXT[mode])
+
+
+def sfb1d(lo, hi, g0, g1, mode, dim, out_len=None):
+    """One synthesis level along one axis (hi may be None = zeros); out_len crops (analysis backward)."""
+    _check_tensor(lo, 'lo')
+    lo = lo.contiguous()
+    dim = dim % lo.dim()
+    K, L = lo.shape[dim], g0.numel()
+    if hi is not None:
+        hi = hi.to(lo.dtype).contiguous()
+        if hi.shape != lo.shape:
+            raise ValueError('lo %s and hi %s differ in shape' % (tuple(lo.shape), tuple(hi.shape)))
+        _same_device(lo, hi)
+    ny = 2 * K if mode == 2 else 2 * K - L + 2
+    if out_len is not None:
+        ny = min(ny, out_len)
+    outer = 1
+    for v in lo.shape[:dim]:
+        outer *= v
+    inner = 1
+    for v in lo.shape[dim + 1:]:
+        inner *= v
+    shape = list(lo.shape)
+    shape[dim] = ny
+    y = torch.empty(shape, dtype=lo.dtype, device=lo.device)
+    t0, t1 = _taps(g0, lo), _taps(g1, lo)
+    if y.numel():
+        rc = _call('wl_synth1d', lo, lo.data_ptr(), None if hi is None else hi.data_ptr(), y.data_ptr(), _DTYPES[lo.dtype],
+                   outer, K, inner, ny, t0.data_ptr(), t1.data_ptr(), L, mode, _stream(lo))
+        _lib.check(rc, 'wl_synth1d')
+    return y
+
+
 # ---------------------------------------------------------------------------------------------- DTCWT
 def _ll_view(ll, ref_shape):
     """(ptr, plane_stride, row_stride) of a (N,C,h,w) view whose rows are unit-stride."""

@@ -1,0 +1,105 @@
+"""Shared checks for the single-axis APIs (1-D DWT, stationary transform, DTCWT primitives, function-level banks) against
+the goldens generated from the real reference by oracle/pin_extras.py.  Used by the emulator tests (CPU tensors) and by
+the -m gpu tests (device tensors, the real library)."""
+import numpy as np
+import torch
+
+import _golden as G
+import pytorch_wavelets_amd as pw
+from pytorch_wavelets_amd import filters
+from pytorch_wavelets_amd.dtcwt import lowlevel as dtl
+from pytorch_wavelets_amd.dwt import lowlevel as dwl
+from pytorch_wavelets_amd.dwt.transform2d import SWTForward
+
+
+def _t(a, dev, dtype):
+    return torch.tensor(np.asarray(a), device=dev).to(dtype)
+
+
+def check_dwt1d(name, dev, dtype, tol):
+    meta, g = G.INDEX[name], G.load(name)
+    J = meta['J']
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        xfm = pw.DWT1DForward(J=J, wave=meta['wave'], mode=meta['mode']).to(dev)
+        ifm = pw.DWT1DInverse(wave=meta['wave'], mode=meta['mode']).to(dev)
+    finally:
+        torch.set_default_dtype(prev)
+    assert xfm.h0.shape == (1, 1, len(filters.Wavelet(meta['wave']).dec_lo))
+    x = _t(g['x'], dev, dtype).requires_grad_(True)
+    yl, yh = xfm(x)
+    assert G.relerr(yl.detach().cpu().numpy(), g, 'yl') < tol
+    for j in range(J):
+        assert G.relerr(yh[j].detach().cpu().numpy(), g, 'yh%d' % j) < tol
+    rec = ifm((yl, yh))
+    assert G.relerr(rec.detach().cpu().numpy(), g, 'rec') < tol
+    loss = (yl * _t(g['gl'], dev, dtype)).sum() + sum((yh[j] * _t(g['gh%d' % j], dev, dtype)).sum() for j in range(J))
+    dx, = torch.autograd.grad(loss, x)
+    assert G.relerr(dx.cpu().numpy(), g, 'dx') < tol
+    ylr = _t(g['yl'], dev, dtype).requires_grad_(True)
+    yhr = [_t(g['yh%d' % j], dev, dtype).requires_grad_(True) for j in range(J)]
+    gr = torch.autograd.grad((ifm((ylr, yhr)) * _t(g['gy'], dev, dtype)).sum(), [ylr] + yhr)
+    assert G.relerr(gr[0].cpu().numpy(), g, 'dyl') < tol
+    for j in range(J):
+        assert G.relerr(gr[1 + j].cpu().numpy(), g, 'dyh%d' % j) < tol
+    # None highs are zeros (transform1d.py:104-106)
+    rec0 = ifm((yl.detach(), [None] * J))   # (no 'unpad' happens then, exactly as upstream)
+    assert rec0.ndim == 3 and bool(torch.isfinite(rec0).all())
+
+
+def check_swt(name, dev, dtype, tol):
+    meta, g = G.INDEX[name], G.load(name)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        m = SWTForward(J=2, wave=meta['wave'], mode=meta['mode']).to(dev)
+    finally:
+        torch.set_default_dtype(prev)
+    x = _t(g['x'], dev, dtype)
+    y = m(x)
+    assert len(y) == 2 and y[0].shape == y[1].shape == (x.shape[0], 4 * x.shape[1]) + tuple(x.shape[2:])
+    assert G.relerr(y[0].cpu().numpy(), g, 'y') < tol
+    # the dilated bank on the same input (the level-2 OPERATOR of the reference; its SWTForward cannot reach level 2)
+    filts = (m.h0_col, m.h1_col, m.h0_row, m.h1_row)
+    assert G.relerr(dwl.afb2d_atrous(x, filts, meta['mode'], 2).cpu().numpy(), g, 'y_dil2') < tol
+
+
+def check_prims(dev, dtype, tol):
+    g = G.load('ext_prims')
+    h0o, g0o, h1o, g1o = filters.biort('near_sym_b')
+    h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b = filters.qshift('qshift_b')
+    P = lambda v: dtl.prep_filt(v, 1).to(dev).to(dtype)   # noqa: E731
+    X = _t(g['X'], dev, dtype)
+    res = {
+        'colfilter': dtl.colfilter(X, P(h1o)), 'rowfilter': dtl.rowfilter(X, P(h0o)),
+        'colfilter_zero': dtl.colfilter(X, P(h0o), 'zero'),
+        'coldfilt': dtl.coldfilt(X, P(h0b), P(h0a)), 'coldfilt_hp': dtl.coldfilt(X, P(h1b), P(h1a), True),
+        'rowdfilt': dtl.rowdfilt(X, P(h0b), P(h0a)), 'rowdfilt_hp': dtl.rowdfilt(X, P(h1b), P(h1a), True),
+        'colifilt': dtl.colifilt(X, P(g0b), P(g0a)), 'colifilt_hp': dtl.colifilt(X, P(g1b), P(g1a), True),
+        'rowifilt': dtl.rowifilt(X, P(g0b), P(g0a)), 'rowifilt_hp': dtl.rowifilt(X, P(g1b), P(g1a), True),
+    }
+    for k, v in res.items():
+        assert G.relerr(v.cpu().numpy(), g, k) < tol, k
+    (a, b), (c, d) = dtl.q2c(X)
+    for k, v in (('q2c_1r', a), ('q2c_1i', b), ('q2c_2r', c), ('q2c_2i', d), ('c2q', dtl.c2q((a, b), (c, d)))):
+        assert G.relerr(v.cpu().numpy(), g, k) < tol, k
+    import pytest
+    with pytest.raises(ValueError, match='multiple of 4'):
+        dtl.coldfilt(X[:, :, :14], P(h0b), P(h0a))
+    with pytest.raises(ValueError, match='multiple of 2'):
+        dtl.rowifilt(X[:, :, :, :23], P(g0b), P(g0a))
+
+
+def check_afb1d_functions(dev, tol):
+    g = G.load('ext_afb1d')
+    w = filters.Wavelet('db3')
+    x = torch.tensor(g['x'], device=dev)
+    lohi = dwl.afb1d(x, w.dec_lo, w.dec_hi, mode='symmetric', dim=3)
+    assert G.relerr(lohi.cpu().numpy(), g, 'lohi') < tol
+    y = dwl.sfb1d(lohi[:, ::2].contiguous(), lohi[:, 1::2].contiguous(), w.rec_lo, w.rec_hi, mode='symmetric', dim=3)
+    assert G.relerr(y.cpu().numpy(), g, 'y') < tol
+
+
+DWT1D_CASES = sorted(k for k, v in G.INDEX.items() if v['kind'] == 'dwt1d')
+SWT_CASES = sorted(k for k, v in G.INDEX.items() if v['kind'] == 'swt')

@@ -1,0 +1,71 @@
+"""CPU tests (host emulation of the kernels): 1-D DWT modules, the stationary transform, the DTCWT 1-D primitives and
+the function-level banks against the goldens generated from the real reference (oracle/pin_extras.py)."""
+import numpy as np
+import pytest
+import torch
+
+import _ext_cases as E
+import _golden as G
+import emu_backend
+from oracle import wavelet_oracle as wo
+
+
+@pytest.mark.parametrize('name', E.DWT1D_CASES)
+def test_dwt1d_modules_and_gradients(name):
+    with emu_backend.emulated():
+        E.check_dwt1d(name, 'cpu', torch.float64, 5e-7)
+        E.check_dwt1d(name, 'cpu', torch.float32, 1e-5)
+
+
+@pytest.mark.parametrize('name', E.SWT_CASES)
+def test_swt_level_and_dilated_bank(name):
+    with emu_backend.emulated():
+        E.check_swt(name, 'cpu', torch.float64, 5e-7)
+
+
+def test_swt_second_level_is_the_dilated_bank_on_ll_and_bad_modes_raise():
+    """J > 1 (which upstream cannot run): level 2 = the a-trous bank with dilation 2 on the ll channels of level 1
+    (checked against the oracle); the default mode 'periodization' raises like upstream's mypad."""
+    from pytorch_wavelets_amd import filters
+    from pytorch_wavelets_amd.dwt.transform2d import SWTForward
+    rng = np.random.RandomState(3)
+    x = rng.randn(1, 2, 20, 24)
+    h0, h1 = filters.dwt_analysis_taps('db2')
+    torch.set_default_dtype(torch.float64)
+    try:
+        with emu_backend.emulated():
+            y = SWTForward(J=2, wave='db2', mode='periodic')(torch.tensor(x))
+            with pytest.raises(ValueError, match='Unkown pad type'):
+                SWTForward(J=1, wave='db2')(torch.tensor(x))
+    finally:
+        torch.set_default_dtype(torch.float32)
+    o1 = wo.afb2d_atrous(x, h0, h1, h0, h1, 'periodic', 1)
+    o2 = wo.afb2d_atrous(o1[:, 0::4], h0, h1, h0, h1, 'periodic', 2)
+    assert np.abs(y[0].numpy() - o1).max() < 1e-12 and np.abs(y[1].numpy() - o2).max() < 1e-12
+
+
+def test_dtcwt_primitives():
+    with emu_backend.emulated():
+        E.check_prims('cpu', torch.float64, 5e-7)
+        E.check_prims('cpu', torch.float32, 1e-5)
+
+
+def test_function_level_afb1d_sfb1d():
+    with emu_backend.emulated():
+        E.check_afb1d_functions('cpu', 1e-5)
+
+
+def test_oracle_extras_vs_reference_goldens():
+    """The numpy oracle's restatement of the 1-D DWT / a-trous bank / primitives reproduces the reference goldens."""
+    from pytorch_wavelets_amd import filters
+    for name in E.DWT1D_CASES:
+        meta, g = G.INDEX[name], G.load(name)
+        h0, h1 = filters.dwt_analysis_taps(meta['wave'])
+        g0, g1 = filters.dwt_synthesis_taps(meta['wave'])
+        yl, yh = wo.dwt1d_forward(g['x'].astype(np.float64), meta['J'], h0, h1, meta['mode'])
+        assert G.relerr(yl, g, 'yl') < 5e-7
+        assert G.relerr(wo.dwt1d_inverse(yl, yh, g0, g1, meta['mode']), g, 'rec') < 5e-7
+    for name in E.SWT_CASES:
+        meta, g = G.INDEX[name], G.load(name)
+        h0, h1 = filters.dwt_analysis_taps(meta['wave'])
+        assert G.relerr(wo.afb2d_atrous(g['x'].astype(np.float64), h0, h1, h0, h1, meta['mode'], 1), g, 'y') < 5e-7

@@ -1,0 +1,50 @@
+"""-m gpu: the single-axis kernels (wl_corr1d / wl_synth1d) behind DWT1DForward / DWT1DInverse, SWTForward, the
+function-level banks and the DTCWT 1-D primitives, through the C ABI on the MI355X, against the reference goldens."""
+import numpy as np
+import pytest
+import torch
+
+import _ext_cases as E
+from oracle import wavelet_oracle as wo
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.mark.parametrize('name', E.DWT1D_CASES)
+def test_dwt1d_modules_and_gradients(name):
+    E.check_dwt1d(name, DEV, torch.float32, 1e-5)
+    E.check_dwt1d(name, DEV, torch.float64, 5e-7)
+
+
+@pytest.mark.parametrize('name', E.SWT_CASES)
+def test_swt_level_and_dilated_bank(name):
+    E.check_swt(name, DEV, torch.float32, 1e-5)
+
+
+def test_dtcwt_primitives():
+    E.check_prims(DEV, torch.float32, 1e-5)
+    E.check_prims(DEV, torch.float64, 5e-7)
+
+
+def test_function_level_afb1d_sfb1d():
+    E.check_afb1d_functions(DEV, 1e-5)
+
+
+def test_dwt1d_long_signals_vs_oracle_and_fp16():
+    """Long rows (several workgroups per signal), odd length, float16 storage."""
+    import pytorch_wavelets_amd as pw
+    from pytorch_wavelets_amd import filters
+    torch.manual_seed(11)
+    x = torch.randn(3, 5, 100001)
+    h0, h1 = filters.dwt_analysis_taps('db6')
+    g0, g1 = filters.dwt_synthesis_taps('db6')
+    oyl, oyh = wo.dwt1d_forward(x.double().numpy(), 3, h0, h1, 'symmetric')
+    xfm, ifm = pw.DWT1DForward(J=3, wave='db6', mode='symmetric').to(DEV), pw.DWT1DInverse(wave='db6', mode='symmetric').to(DEV)
+    yl, yh = xfm(x.to(DEV))
+    rel = lambda a, b: float(np.abs(a.double().cpu().numpy() - b).max() / np.abs(b).max())   # noqa: E731
+    assert rel(yl, oyl) < 1e-5 and all(rel(a, b) < 1e-5 for a, b in zip(yh, oyh))
+    rec = ifm((yl, yh))
+    assert float((rec[..., :100001].cpu() - x).abs().max()) < 1e-4
+    yl16, yh16 = xfm.half()(x.half().to(DEV))
+    assert yl16.dtype == torch.float16 and rel(yl16, oyl) < 5e-3
