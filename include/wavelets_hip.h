@@ -127,9 +127,11 @@ int wl_dtcwt_inv_level2(const void* ll, int64_t ll_plane_stride, int ll_row_stri
 
 /* ScatLayer forward = ScatLayerj1_f.forward (scatternet/lowlevel.py:76-111): level-1 DTCWT + 2x2 average of LL +
  * smoothed magnitude sqrt(re^2+im^2+b^2)-b, written as z (N,7,C,He/2,We/2) [(N,3+6,..) with combine_colour].
- * drdx/drdy (N,6,C,He/2,We/2) receive re/r, im/r for the backward pass, or NULL. */
-int wl_scat_fwd_level1(const void* x, void* z, void* drdx, void* drdy, int dtype, int64_t N, int C, int H, int W,
-                       const void* h0, int L0, const void* h1, int L1, int mode, double magbias,
+ * drdx/drdy (N,6,C,He/2,We/2) receive re/r, im/r for the backward pass, or NULL.  ll (N,C,He,We) or NULL: the
+ * full-resolution level-1 lowpass as well - the input of the second scale of ScatLayerj2_f (scatternet/lowlevel.py:
+ * 214-222, :255-262), which needs both s0 at full size and the first-order magnitudes from the same filtering. */
+int wl_scat_fwd_level1(const void* x, void* z, void* drdx, void* drdy, void* ll, int dtype, int64_t N, int C, int H,
+                       int W, const void* h0, int L0, const void* h1, int L1, int mode, double magbias,
                        int combine_colour, void* stream);
 
 /* ScatLayer backward = ScatLayerj1_f.backward (scatternet/lowlevel.py:114-137) in ONE launch: the prologue

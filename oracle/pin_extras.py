@@ -123,5 +123,19 @@ lohi = rdl.afb1d(torch.tensor(x), w.dec_lo, w.dec_hi, mode='symmetric', dim=3)
 lo_, hi_ = lohi[:, ::2].contiguous(), lohi[:, 1::2].contiguous()
 y = rdl.sfb1d(lo_, hi_, w.rec_lo, w.rec_hi, mode='symmetric', dim=3)
 save('ext_afb1d', dict(kind='afb1d', wave='db3', mode='symmetric'), x=x, lohi=npy(lohi), y=npy(y))
+# ---- ScatLayerj2 (scatternet/layers.py:82-172) incl. its hand-written backward pass
+for ci, (shape, comb) in enumerate([((2, 3, 32, 40), False), ((1, 3, 32, 32), True), ((1, 2, 35, 29), False),
+                                    ((1, 1, 64, 48), False)]):
+    x = rng.randn(*shape)
+    m = pw.ScatLayerj2(combine_colour=comb)
+    xt = torch.tensor(x, requires_grad=True)
+    Z = m(xt)
+    f = [npy(getattr(m, n)).ravel() for n in ('h0o', 'h1o', 'h0a', 'h0b', 'h1a', 'h1b')]
+    assert rel(wo.scat_layer_j2_forward(x, *f, magbias=m.magbias, combine_colour=comb), npy(Z)) < TOL
+    gz = rng.randn(*Z.shape)
+    dx, = torch.autograd.grad((Z * torch.tensor(gz)).sum(), xt)
+    save('ext_scatj2_%d' % ci, dict(kind='scatj2', shape=list(shape), combine_colour=comb), x=x, Z=npy(Z), gz=gz, dx=npy(dx))
+    print('scatj2', shape, comb, 'ok')
+
 json.dump(index, open(idx_path, 'w'), indent=1, sort_keys=True)
 print('index updated:', sorted(k for k in index if k.startswith('ext_')))

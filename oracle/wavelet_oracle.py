@@ -640,3 +640,45 @@ def afb2d_atrous(x, h0_col, h1_col, h0_row, h1_row, mode, dilation=1):
         outs.extend(afb1d_atrous(r, h0_col, h1_col, mode, 2, dilation))
     n, c = x.shape[:2]
     return np.stack(outs, axis=2).reshape(n, 4 * c, outs[0].shape[2], outs[0].shape[3])
+
+
+def scat_layer_j2_forward(x, h0o, h1o, h0a, h0b, h1a, h1b, magbias=1e-2, combine_colour=False):
+    """ScatLayerj2.forward -> ScatLayerj2_f.forward (scatternet/layers.py:136-168, scatternet/lowlevel.py:205-295),
+    symmetric mode (the only one whose second scale runs upstream).  Returns (N,49C,H/4,W/4), or (N,51,H/4,W/4) when
+    combining colour."""
+    x = np.asarray(x)
+    ch, r, c = x.shape[1:]
+    rem = r % 8
+    if rem != 0:
+        x = np.concatenate([x[:, :, :(8 - rem) // 2], x, x[:, :, -((9 - rem) // 2):]], axis=2)
+    rem = c % 8
+    if rem != 0:
+        x = np.concatenate([x[:, :, :, :(8 - rem) // 2], x, x[:, :, :, -((9 - rem) // 2):]], axis=3)
+
+    def pool(a):
+        s = a.shape
+        return a.reshape(s[:-2] + (s[-2] // 2, 2, s[-1] // 2, 2)).mean(axis=(-3, -1))
+
+    def mags(highs, colour):
+        re, im = np.moveaxis(highs[..., 0], 2, 1), np.moveaxis(highs[..., 1], 2, 1)   # (N,6,C,h,w)
+        e = re ** 2 + im ** 2
+        if colour:
+            e = e.sum(axis=2, keepdims=True)
+        return np.sqrt(e + magbias ** 2) - magbias
+
+    s0, highs = fwd_j1(x, h0o, h1o, False, 'symmetric')
+    s1_j1 = mags(highs, combine_colour)                     # (N,6,C or 1,H/2,W/2)
+    s0, highs = fwd_j2plus(s0, h0a, h1a, h0b, h1b, False)
+    s1_j2 = mags(highs, combine_colour)                     # (N,6,C or 1,H/4,W/4)
+    s0 = pool(s0)
+    n = x.shape[0]
+    p = s1_j1.shape
+    s1 = s1_j1.reshape(n, 6 * p[2], p[3], p[4])
+    s1_ll, highs = fwd_j1(s1, h0o, h1o, False, 'symmetric')
+    s2_j1 = mags(highs, False)                              # (N,6,6C',h,w)
+    s1p = pool(s1_ll)
+    h, w = s1p.shape[-2:]
+    if combine_colour:
+        return np.concatenate([s0, s1p, s1_j2[:, :, 0], s2_j1.reshape(n, 36, h, w)], axis=1)
+    Z = np.concatenate([s0[:, None], s1p.reshape(n, 6, p[2], h, w), s1_j2, s2_j1.reshape(n, 36, p[2], h, w)], axis=1)
+    return Z.reshape(n, 49 * p[2], h, w)

@@ -9,7 +9,7 @@ __version__ = '0.1.0'
 from .dwt.transform2d import DWTForward, DWTInverse   # noqa: E402,F401
 from .dwt.transform1d import DWT1DForward, DWT1DInverse   # noqa: E402,F401
 from .dtcwt.transform2d import DTCWTForward, DTCWTInverse   # noqa: E402,F401
-from .scatternet import ScatLayer   # noqa: E402,F401
+from .scatternet import ScatLayer, ScatLayerj2   # noqa: E402,F401
 
 from . import parallel                                  # noqa: E402,F401
 
@@ -30,4 +30,4 @@ DWT1D = DWT1DForward
 IDWT1D = DWT1DInverse
 
 __all__ = ['__version__', 'DTCWTForward', 'DTCWTInverse', 'DWTForward', 'DWTInverse', 'DTCWT', 'IDTCWT',
-           'DWT', 'IDWT', 'DWT2D', 'IDWT2D', 'DWT1DForward', 'DWT1DInverse', 'DWT1D', 'IDWT1D', 'ScatLayer']
+           'DWT', 'IDWT', 'DWT2D', 'IDWT2D', 'DWT1DForward', 'DWT1DInverse', 'DWT1D', 'IDWT1D', 'ScatLayer', 'ScatLayerj2']

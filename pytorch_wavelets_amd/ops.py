@@ -351,25 +351,28 @@ def dtcwt_inv2(ll, highs, g0a, g0b, g1a, g1b):
     return y
 
 
-def scat_fwd1(x, h0, h1, mode, magbias, combine_colour, save):
+def scat_fwd1(x, h0, h1, mode, magbias, combine_colour, save, want_ll=False):
     """ScatLayer forward: x (N,C,H,W) -> Z (N,7,C,He/2,We/2) [(N,9,..) when combining colour] and, if
-    `save`, (re/r, im/r) of shape (N,6,C,He/2,We/2)."""
+    `save`, (re/r, im/r) of shape (N,6,C,He/2,We/2); with `want_ll` also the full-resolution level-1 lowpass
+    (N,C,He,We) from the same launch (ScatLayerj2's second scale filters it)."""
     _check_tensor(x, 'x')
     x = x.contiguous()
     N, C, H, W = x.shape
     t0, t1 = _taps(h0, x), _taps(h1, x)
     h2, w2 = (H + (H & 1)) // 2, (W + (W & 1)) // 2
     z = torch.empty((N, 9, h2, w2) if combine_colour else (N, 7, C, h2, w2), dtype=x.dtype, device=x.device)
-    dx = dy = None
+    dx = dy = ll = None
     if save:
         dx = torch.empty((N, 6, C, h2, w2), dtype=x.dtype, device=x.device)
         dy = torch.empty_like(dx)
+    if want_ll:
+        ll = torch.empty((N, C, 2 * h2, 2 * w2), dtype=x.dtype, device=x.device)
     rc = _call('wl_scat_fwd_level1', x, x.data_ptr(), z.data_ptr(), None if dx is None else dx.data_ptr(),
-                                       None if dy is None else dy.data_ptr(), _DTYPES[x.dtype], N, C, H, W,
-                                       t0.data_ptr(), t0.numel(), t1.data_ptr(), t1.numel(), mode, float(magbias),
-                                       1 if combine_colour else 0, _stream(x))
+               None if dy is None else dy.data_ptr(), None if ll is None else ll.data_ptr(), _DTYPES[x.dtype], N, C, H, W,
+               t0.data_ptr(), t0.numel(), t1.data_ptr(), t1.numel(), mode, float(magbias),
+               1 if combine_colour else 0, _stream(x))
     _lib.check(rc, 'wl_scat_fwd_level1')
-    return z, dx, dy
+    return (z, dx, dy, ll) if want_ll else (z, dx, dy)
 
 
 def scat_bwd1(dz, drdx, drdy, h0, h1, mode, combine_colour):

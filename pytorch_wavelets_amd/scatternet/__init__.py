@@ -1,1 +1,1 @@
-from .layers import ScatLayer   # noqa: F401
+from .layers import ScatLayer, ScatLayerj2   # noqa: F401

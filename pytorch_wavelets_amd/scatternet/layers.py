@@ -3,8 +3,8 @@ import torch
 import torch.nn as nn
 
 from ..dtcwt.lowlevel import prep_filt
-from ..filters import biort as _biort
-from .lowlevel import ScatLayerj1_f, mode_to_int
+from ..filters import biort as _biort, qshift as _qshift
+from .lowlevel import ScatLayerj1_f, mode_to_int, scat_layer_j2
 
 
 class ScatLayer(nn.Module):
@@ -36,6 +36,59 @@ class ScatLayer(nn.Module):
         if not self.combine_colour:
             b, _, c, h, w = Z.shape
             Z = Z.view(b, 7 * c, h, w)
+        return Z
+
+    def extra_repr(self):
+        return "biort='{}', mode='{}', magbias={}".format(self.biort, self.mode_str, self.magbias)
+
+
+class ScatLayerj2(nn.Module):
+    """Second-order DTCWT scattering over two scales (reference scatternet/layers.py:82-172):
+    ``ScatLayerj2(biort='near_sym_a', qshift='qshift_a', mode='symmetric', magbias=1e-2, combine_colour=False)(x)
+    -> (N, 49C, H/4, W/4)`` (51 channels when combining colour): lowpass, 6 first-order terms of either scale and the
+    36 second-order terms.  Inputs are extended to multiples of 8 like upstream."""
+
+    def __init__(self, biort='near_sym_a', qshift='qshift_a', mode='symmetric', magbias=1e-2, combine_colour=False):
+        super().__init__()
+        self.biort = biort
+        self.qshift = biort   # sic (upstream stores biort here)
+        self.mode_str = mode
+        self.mode = mode_to_int(mode)
+        self.magbias = magbias
+        self.combine_colour = combine_colour
+        if biort == 'near_sym_b_bp':
+            assert qshift == 'qshift_b_bp'
+            raise NotImplementedError("the rotationally symmetric band-pass variant ('near_sym_b_bp' / 'qshift_b_bp') "
+                                      "is not implemented by the gfx950 engine yet")
+        self.bandpass_diag = False
+        h0o, _, h1o, _ = _biort(biort)[:4]
+        self.h0o = torch.nn.Parameter(prep_filt(h0o, 1), False)
+        self.h1o = torch.nn.Parameter(prep_filt(h1o, 1), False)
+        h0a, h0b, _, _, h1a, h1b, _, _ = _qshift(qshift)[:8]
+        self.h0a = torch.nn.Parameter(prep_filt(h0a, 1), False)
+        self.h0b = torch.nn.Parameter(prep_filt(h0b, 1), False)
+        self.h1a = torch.nn.Parameter(prep_filt(h1a, 1), False)
+        self.h1b = torch.nn.Parameter(prep_filt(h1b, 1), False)
+
+    def forward(self, x):
+        ch, r, c = x.shape[1:]
+        rem = r % 8
+        if rem != 0:   # make the size a multiple of 8 by repeating border blocks (layers.py:138-150 upstream)
+            rows_after = (9 - rem) // 2
+            rows_before = (8 - rem) // 2
+            x = torch.cat((x[:, :, :rows_before], x, x[:, :, -rows_after:]), dim=2)
+        rem = c % 8
+        if rem != 0:
+            cols_after = (9 - rem) // 2
+            cols_before = (8 - rem) // 2
+            x = torch.cat((x[:, :, :, :cols_before], x, x[:, :, :, -cols_after:]), dim=3)
+        if self.combine_colour:
+            assert ch == 3
+        Z = scat_layer_j2(x, self.h0o, self.h1o, self.h0a, self.h0b, self.h1a, self.h1b, self.mode, self.magbias,
+                          self.combine_colour)
+        if not self.combine_colour:
+            b, _, c, h, w = Z.shape
+            Z = Z.reshape(b, 49 * c, h, w)
         return Z
 
     def extra_repr(self):

@@ -101,5 +101,24 @@ def check_afb1d_functions(dev, tol):
     assert G.relerr(y.cpu().numpy(), g, 'y') < tol
 
 
+def check_scatj2(name, dev, dtype, tol):
+    meta, g = G.INDEX[name], G.load(name)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        m = pw.ScatLayerj2(combine_colour=meta['combine_colour']).to(dev)
+    finally:
+        torch.set_default_dtype(prev)
+    assert sorted(n for n, _ in m.named_parameters()) == ['h0a', 'h0b', 'h0o', 'h1a', 'h1b', 'h1o']
+    x = _t(g['x'], dev, dtype).requires_grad_(True)
+    Z = m(x)
+    assert G.relerr(Z.detach().cpu().numpy(), g, 'Z') < tol
+    dx, = torch.autograd.grad((Z * _t(g['gz'], dev, dtype)).sum(), x)
+    assert G.relerr(dx.cpu().numpy(), g, 'dx') < tol
+    with torch.no_grad():
+        assert G.relerr(m(x.detach()).cpu().numpy(), g, 'Z') < tol   # no-grad path (nothing saved)
+
+
 DWT1D_CASES = sorted(k for k, v in G.INDEX.items() if v['kind'] == 'dwt1d')
 SWT_CASES = sorted(k for k, v in G.INDEX.items() if v['kind'] == 'swt')
+SCATJ2_CASES = sorted(k for k, v in G.INDEX.items() if v['kind'] == 'scatj2')

@@ -69,3 +69,32 @@ def test_oracle_extras_vs_reference_goldens():
         meta, g = G.INDEX[name], G.load(name)
         h0, h1 = filters.dwt_analysis_taps(meta['wave'])
         assert G.relerr(wo.afb2d_atrous(g['x'].astype(np.float64), h0, h1, h0, h1, meta['mode'], 1), g, 'y') < 5e-7
+
+
+@pytest.mark.parametrize('name', E.SCATJ2_CASES)
+def test_scatlayerj2_forward_and_backward(name):
+    """ScatLayerj2 (two fused ScatLayer launches + the level-2 DTCWT kernel) against the reference's forward and its
+    hand-written backward, incl. combine_colour and sizes that are not multiples of 8."""
+    with emu_backend.emulated():
+        E.check_scatj2(name, 'cpu', torch.float64, 5e-7)
+        E.check_scatj2(name, 'cpu', torch.float32, 2e-5)
+
+
+def test_scatlayerj2_refuses_what_upstream_refuses():
+    import pytorch_wavelets_amd as pw
+    with emu_backend.emulated():
+        with pytest.raises(NotImplementedError):
+            pw.ScatLayerj2(mode='zero')(torch.randn(1, 1, 16, 16))   # upstream: rowdfilt knows only 'symmetric'
+    with pytest.raises(NotImplementedError):
+        pw.ScatLayerj2(biort='near_sym_b_bp', qshift='qshift_b_bp')
+
+
+def test_oracle_scatlayerj2_vs_reference_goldens():
+    from pytorch_wavelets_amd import filters
+    for name in E.SCATJ2_CASES:
+        meta, g = G.INDEX[name], G.load(name)
+        h0o, _, h1o, _ = filters.biort('near_sym_a')[:4]
+        h0a, h0b, _, _, h1a, h1b, _, _ = filters.qshift('qshift_a')[:8]
+        f = [np.asarray(v, dtype=np.float64).ravel()[::-1] for v in (h0o, h1o, h0a, h0b, h1a, h1b)]
+        Z = wo.scat_layer_j2_forward(g['x'].astype(np.float64), *f, combine_colour=meta['combine_colour'])
+        assert G.relerr(Z, g, 'Z') < 5e-7

@@ -48,3 +48,9 @@ def test_dwt1d_long_signals_vs_oracle_and_fp16():
     assert float((rec[..., :100001].cpu() - x).abs().max()) < 1e-4
     yl16, yh16 = xfm.half()(x.half().to(DEV))
     assert yl16.dtype == torch.float16 and rel(yl16, oyl) < 5e-3
+
+
+@pytest.mark.parametrize('name', E.SCATJ2_CASES)
+def test_scatlayerj2_forward_and_backward(name):
+    E.check_scatj2(name, DEV, torch.float32, 2e-5)
+    E.check_scatj2(name, DEV, torch.float64, 5e-7)
