@@ -137,5 +137,23 @@ for ci, (shape, comb) in enumerate([((2, 3, 32, 40), False), ((1, 3, 32, 32), Tr
     save('ext_scatj2_%d' % ci, dict(kind='scatj2', shape=list(shape), combine_colour=comb), x=x, Z=npy(Z), gz=gz, dx=npy(dx))
     print('scatj2', shape, comb, 'ok')
 
+# ---- rotationally symmetric variants (near_sym_b_bp / qshift_b_bp): ScatLayer and ScatLayerj2, forward + backward.
+# (No separate numpy restatement: the engine's rot path is the reference's own decomposition into the single-axis
+#  primitives pinned above; these goldens pin the composition.)
+rot_cases = [('ScatLayer', dict(biort='near_sym_b_bp'), (2, 3, 32, 40)),
+             ('ScatLayer', dict(biort='near_sym_b_bp', combine_colour=True), (1, 3, 33, 31)),
+             ('ScatLayer', dict(biort='near_sym_b_bp', mode='zero'), (1, 2, 24, 20)),
+             ('ScatLayerj2', dict(biort='near_sym_b_bp', qshift='qshift_b_bp'), (1, 2, 32, 40)),
+             ('ScatLayerj2', dict(biort='near_sym_b_bp', qshift='qshift_b_bp', combine_colour=True), (1, 3, 35, 29))]
+for ci, (cls, kw, shape) in enumerate(rot_cases):
+    x = rng.randn(*shape)
+    m = getattr(pw, cls)(**kw)
+    xt = torch.tensor(x, requires_grad=True)
+    Z = m(xt)
+    gz = rng.randn(*Z.shape)
+    dx, = torch.autograd.grad((Z * torch.tensor(gz)).sum(), xt)
+    save('ext_rot_%d' % ci, dict(kind='rot', cls=cls, kwargs=kw, shape=list(shape)), x=x, Z=npy(Z), gz=gz, dx=npy(dx))
+    print('rot', cls, kw, shape, 'ok')
+
 json.dump(index, open(idx_path, 'w'), indent=1, sort_keys=True)
 print('index updated:', sorted(k for k in index if k.startswith('ext_')))

@@ -208,3 +208,137 @@ class INV_J2PLUS(Function):
             dh = to_layout(dh, *ctx.dims) if need_h else None
             dl = dl if need_l else None
         return dl, dh, None, None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Rotationally symmetric variants ('near_sym_b_bp' / 'qshift_b_bp'): the diagonal sub-band is filtered by a third,
+# band-pass pair h2 on both axes (reference transform_funcs.py:124-149, :187-223, :252-276, :310-340).  They are not on
+# the fused hot path: each level is the reference's own decomposition into seven single-axis filters, every one a
+# launch of the engine's correlation kernel (dtcwt/lowlevel.py here), plus q2c / c2q index shuffles.
+# ---------------------------------------------------------------------------------------------------------------------
+def highs_to_orientations(lh, hl, hh, o_dim):
+    """Three quad sub-bands -> six orientations 15..165 degrees, stacked along o_dim (reference :61-73)."""
+    from .lowlevel import q2c
+    (d15r, d15i), (d165r, d165i) = q2c(lh)
+    (d45r, d45i), (d135r, d135i) = q2c(hh)
+    (d75r, d75i), (d105r, d105i) = q2c(hl)
+    return (torch.stack([d15r, d45r, d75r, d105r, d135r, d165r], dim=o_dim),
+            torch.stack([d15i, d45i, d75i, d105i, d135i, d165i], dim=o_dim))
+
+
+def orientations_to_highs(reals, imags, o_dim):
+    """Inverse of highs_to_orientations (reference :76-96)."""
+    from .lowlevel import c2q
+    r = torch.unbind(reals, dim=o_dim)
+    i = torch.unbind(imags, dim=o_dim)
+    lh = c2q((r[0], i[0]), (r[5], i[5]))
+    hl = c2q((r[2], i[2]), (r[3], i[3]))
+    hh = c2q((r[1], i[1]), (r[4], i[4]))
+    return lh, hl, hh
+
+
+def fwd_j1_rot(x, h0, h1, h2, skip_hps, o_dim, mode):
+    """Level-1 forward with the band-pass diagonal (reference :124-149).  mode: 'symmetric' or anything else = zero."""
+    from .lowlevel import colfilter, rowfilter
+    if skip_hps:
+        return colfilter(rowfilter(x, h0, mode), h0, mode), x.new_zeros([]), x.new_zeros([])
+    lo = rowfilter(x, h0, mode)
+    hi = rowfilter(x, h1, mode)
+    ba = rowfilter(x, h2, mode)
+    lh = colfilter(lo, h1, mode)
+    hl = colfilter(hi, h0, mode)
+    hh = colfilter(ba, h2, mode)
+    ll = colfilter(lo, h0, mode)
+    highr, highi = highs_to_orientations(lh, hl, hh, o_dim)
+    return ll, highr, highi
+
+
+def inv_j1_rot(ll, highr, highi, g0, g1, g2, o_dim, h_dim, w_dim, mode):
+    """Level-1 inverse with the band-pass diagonal (reference :187-223)."""
+    from .lowlevel import colfilter, rowfilter
+    if _is_empty(highr):
+        return rowfilter(colfilter(ll, g0), g0)
+    lh, hl, hh = orientations_to_highs(highr, highi, o_dim)
+    if _is_empty(ll):
+        lo = colfilter(lh, g1, mode)
+    else:
+        r, c = ll.shape[2:]
+        if r != highr.shape[h_dim] * 2:
+            ll = ll[:, :, 1:-1]
+        if c != highr.shape[w_dim] * 2:
+            ll = ll[:, :, :, 1:-1]
+        lo = colfilter(lh, g1, mode) + colfilter(ll, g0, mode)
+    hi = colfilter(hl, g0, mode)
+    ba = colfilter(hh, g2, mode)
+    return rowfilter(hi, g1, mode) + rowfilter(lo, g0, mode) + rowfilter(ba, g2, mode)
+
+
+def fwd_j2plus_rot(x, h0a, h1a, h0b, h1b, h2a, h2b, skip_hps, o_dim, mode):
+    """Level >= 2 forward with the band-pass diagonal (reference :252-276)."""
+    from .lowlevel import coldfilt, rowdfilt
+    if skip_hps:
+        return coldfilt(rowdfilt(x, h0b, h0a, False, mode), h0b, h0a, False, mode), None, None
+    lo = rowdfilt(x, h0b, h0a, False, mode)
+    hi = rowdfilt(x, h1b, h1a, True, mode)
+    ba = rowdfilt(x, h2b, h2a, True, mode)
+    lh = coldfilt(lo, h1b, h1a, True, mode)
+    hl = coldfilt(hi, h0b, h0a, False, mode)
+    hh = coldfilt(ba, h2b, h2a, True, mode)
+    ll = coldfilt(lo, h0b, h0a, False, mode)
+    highr, highi = highs_to_orientations(lh, hl, hh, o_dim)
+    return ll, highr, highi
+
+
+def inv_j2plus_rot(ll, highr, highi, g0a, g1a, g0b, g1b, g2a, g2b, o_dim, h_dim, w_dim, mode):
+    """Level >= 2 inverse with the band-pass diagonal (reference :310-340)."""
+    from .lowlevel import colifilt, rowifilt
+    if _is_empty(highr):
+        return rowifilt(colifilt(ll, g0b, g0a, False, mode), g0b, g0a, False, mode)
+    lh, hl, hh = orientations_to_highs(highr, highi, o_dim)
+    lo = colifilt(lh, g1b, g1a, True, mode)
+    if not _is_empty(ll):
+        lo = lo + colifilt(ll, g0b, g0a, False, mode)
+    hi = colifilt(hl, g0b, g0a, False, mode)
+    ba = colifilt(hh, g2b, g2a, True, mode)
+    return rowifilt(hi, g1b, g1a, True, mode) + rowifilt(lo, g0b, g0a, False, mode) + rowifilt(ba, g2b, g2a, True, mode)
+
+
+class FWD_J1_ROT(Function):
+    """``FWD_J1_ROT.apply(x, h0, h1, h2, mode_int) -> (ll, reals, imags)``, orientations along dim 1 ((N,6,C,h,w)).
+    Backward = inv_j1_rot with the SAME filters (they are symmetric), as ScatLayerj1_rot_f.backward does upstream
+    (scatternet/lowlevel.py:184-203)."""
+
+    @staticmethod
+    def forward(ctx, x, h0, h1, h2, mode):
+        ctx.mode = int_to_mode(mode)
+        ctx.save_for_backward(h0, h1, h2)
+        return fwd_j1_rot(x, h0, h1, h2, False, 1, ctx.mode)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dll, dre, dim):
+        dx = None
+        if ctx.needs_input_grad[0]:
+            h0, h1, h2 = ctx.saved_tensors
+            dx = inv_j1_rot(dll, dre, dim, h0, h1, h2, 1, 3, 4, ctx.mode)
+        return dx, None, None, None, None
+
+
+class FWD_J2PLUS_ROT(Function):
+    """``FWD_J2PLUS_ROT.apply(x, h0a, h1a, h0b, h1b, h2a, h2b, mode_int) -> (ll, reals, imags)``.  Backward =
+    inv_j2plus_rot with the a / b trees swapped (time reversal; scatternet/lowlevel.py:513-521 upstream)."""
+
+    @staticmethod
+    def forward(ctx, x, h0a, h1a, h0b, h1b, h2a, h2b, mode):
+        ctx.mode = int_to_mode(mode)
+        ctx.save_for_backward(h0a, h1a, h0b, h1b, h2a, h2b)
+        return fwd_j2plus_rot(x, h0a, h1a, h0b, h1b, h2a, h2b, False, 1, ctx.mode)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dll, dre, dim):
+        dx = None
+        if ctx.needs_input_grad[0]:
+            h0a, h1a, h0b, h1b, h2a, h2b = ctx.saved_tensors
+            dx = inv_j2plus_rot(dll, dre, dim, h0b, h1b, h0a, h1a, h2b, h2a, 1, 3, 4, ctx.mode)
+        return (dx,) + (None,) * 7

@@ -4,7 +4,7 @@ import torch.nn as nn
 
 from ..dtcwt.lowlevel import prep_filt
 from ..filters import biort as _biort, qshift as _qshift
-from .lowlevel import ScatLayerj1_f, mode_to_int, scat_layer_j2
+from .lowlevel import ScatLayerj1_f, mode_to_int, scat_layer_j1_rot, scat_layer_j2, scat_layer_j2_rot
 
 
 class ScatLayer(nn.Module):
@@ -20,10 +20,14 @@ class ScatLayer(nn.Module):
         self.magbias = magbias
         self.combine_colour = combine_colour
         if biort == 'near_sym_b_bp':
-            raise NotImplementedError("the rotationally symmetric band-pass variant ('near_sym_b_bp') is not "
-                                      "implemented by the gfx950 engine yet")
-        self.bandpass_diag = False
-        h0o, _, h1o, _ = _biort(biort)[:4]
+            # rotationally symmetric variant: a third (band-pass) pair filters the diagonal sub-band; it runs on the
+            # single-axis kernels (seven filter launches per level), not on the fused ScatLayer kernel
+            self.bandpass_diag = True
+            h0o, _, h1o, _, h2o, _ = _biort(biort)
+            self.h2o = torch.nn.Parameter(prep_filt(h2o, 1), False)
+        else:
+            self.bandpass_diag = False
+            h0o, _, h1o, _ = _biort(biort)[:4]
         self.h0o = torch.nn.Parameter(prep_filt(h0o, 1), False)
         self.h1o = torch.nn.Parameter(prep_filt(h1o, 1), False)
 
@@ -31,8 +35,15 @@ class ScatLayer(nn.Module):
         _, ch, r, c = x.shape
         if self.combine_colour:
             assert ch == 3
-        # odd sizes are extended by edge replication inside the kernel (reference :55-59)
-        Z = ScatLayerj1_f.apply(x, self.h0o, self.h1o, self.mode, self.magbias, self.combine_colour)
+        if self.bandpass_diag:
+            if r % 2 != 0:   # replicate the last row / column (reference layers.py:55-59)
+                x = torch.cat((x, x[:, :, -1:]), dim=2)
+            if c % 2 != 0:
+                x = torch.cat((x, x[:, :, :, -1:]), dim=3)
+            Z = scat_layer_j1_rot(x, self.h0o, self.h1o, self.h2o, self.mode, self.magbias, self.combine_colour)
+        else:
+            # odd sizes are extended by edge replication inside the kernel (reference :55-59)
+            Z = ScatLayerj1_f.apply(x, self.h0o, self.h1o, self.mode, self.magbias, self.combine_colour)
         if not self.combine_colour:
             b, _, c, h, w = Z.shape
             Z = Z.view(b, 7 * c, h, w)
@@ -58,13 +69,19 @@ class ScatLayerj2(nn.Module):
         self.combine_colour = combine_colour
         if biort == 'near_sym_b_bp':
             assert qshift == 'qshift_b_bp'
-            raise NotImplementedError("the rotationally symmetric band-pass variant ('near_sym_b_bp' / 'qshift_b_bp') "
-                                      "is not implemented by the gfx950 engine yet")
-        self.bandpass_diag = False
-        h0o, _, h1o, _ = _biort(biort)[:4]
+            self.bandpass_diag = True
+            h0o, _, h1o, _, h2o, _ = _biort(biort)
+            self.h2o = torch.nn.Parameter(prep_filt(h2o, 1), False)
+            q = _qshift('qshift_b_bp')
+            h0a, h0b, h1a, h1b, h2a, h2b = q[0], q[1], q[4], q[5], q[8], q[9]
+            self.h2a = torch.nn.Parameter(prep_filt(h2a, 1), False)
+            self.h2b = torch.nn.Parameter(prep_filt(h2b, 1), False)
+        else:
+            self.bandpass_diag = False
+            h0o, _, h1o, _ = _biort(biort)[:4]
+            h0a, h0b, _, _, h1a, h1b, _, _ = _qshift(qshift)[:8]
         self.h0o = torch.nn.Parameter(prep_filt(h0o, 1), False)
         self.h1o = torch.nn.Parameter(prep_filt(h1o, 1), False)
-        h0a, h0b, _, _, h1a, h1b, _, _ = _qshift(qshift)[:8]
         self.h0a = torch.nn.Parameter(prep_filt(h0a, 1), False)
         self.h0b = torch.nn.Parameter(prep_filt(h0b, 1), False)
         self.h1a = torch.nn.Parameter(prep_filt(h1a, 1), False)
@@ -84,8 +101,12 @@ class ScatLayerj2(nn.Module):
             x = torch.cat((x[:, :, :, :cols_before], x, x[:, :, :, -cols_after:]), dim=3)
         if self.combine_colour:
             assert ch == 3
-        Z = scat_layer_j2(x, self.h0o, self.h1o, self.h0a, self.h0b, self.h1a, self.h1b, self.mode, self.magbias,
-                          self.combine_colour)
+        if self.bandpass_diag:
+            Z = scat_layer_j2_rot(x, self.h0o, self.h1o, self.h2o, self.h0a, self.h0b, self.h1a, self.h1b, self.h2a,
+                                  self.h2b, self.mode, self.magbias, self.combine_colour)
+        else:
+            Z = scat_layer_j2(x, self.h0o, self.h1o, self.h0a, self.h0b, self.h1a, self.h1b, self.mode, self.magbias,
+                              self.combine_colour)
         if not self.combine_colour:
             b, _, c, h, w = Z.shape
             Z = Z.reshape(b, 49 * c, h, w)

@@ -124,3 +124,41 @@ def scat_layer_j2(x, h0o, h1o, h0a, h0b, h1a, h1b, mode, bias, combine_colour):
     Z2 = ScatLayerj1_f.apply(s1_j1, h0o, h1o, mode, bias, False)                  # (N,7,6C,h,w)
     h, w = Z2.shape[-2:]
     return torch.cat((s0[:, None], Z2[:, 0].reshape(n, 6, c, h, w), s1_j2, Z2[:, 1:].reshape(n, 36, c, h, w)), dim=1)
+
+
+def scat_layer_j1_rot(x, h0o, h1o, h2o, mode, bias, combine_colour):
+    """ScatLayerj1_rot_f (reference scatternet/lowlevel.py:140-203): the ScatLayer with the rotationally symmetric
+    13/19-tap filters (third band-pass pair for the diagonals), as a chain of differentiable pieces."""
+    from ..dtcwt.transform_funcs import FWD_J1_ROT
+    ll, reals, imags = FWD_J1_ROT.apply(x, h0o, h1o, h2o, mode)
+    ll = F.avg_pool2d(ll, 2)
+    if combine_colour:
+        r = _smooth_mag(reals, imags, bias, sum_dim=2)
+        return torch.cat((ll, r[:, :, 0]), dim=1)
+    return torch.cat((ll[:, None], _smooth_mag(reals, imags, bias)), dim=1)
+
+
+def scat_layer_j2_rot(x, h0o, h1o, h2o, h0a, h0b, h1a, h1b, h2a, h2b, mode, bias, combine_colour):
+    """ScatLayerj2_rot_f (reference scatternet/lowlevel.py:401-599), same chain as scat_layer_j2 on the band-pass
+    level functions."""
+    from ..dtcwt.transform_funcs import FWD_J1_ROT, FWD_J2PLUS_ROT
+    if int_to_mode(mode) != 'symmetric':
+        raise NotImplementedError()
+    s0, reals, imags = FWD_J1_ROT.apply(x, h0o, h1o, h2o, mode)
+    n = x.shape[0]
+    if combine_colour:
+        s1_j1 = _smooth_mag(reals, imags, bias, sum_dim=2)[:, :, 0]                 # (N,6,H/2,W/2)
+    else:
+        s1_j1 = _smooth_mag(reals, imags, bias)                                     # (N,6,C,H/2,W/2)
+        c = s1_j1.shape[2]
+        s1_j1 = s1_j1.reshape(n, 6 * c, s1_j1.shape[3], s1_j1.shape[4])
+    s0, reals, imags = FWD_J2PLUS_ROT.apply(s0, h0a, h1a, h0b, h1b, h2a, h2b, mode)
+    s1_j2 = _smooth_mag(reals, imags, bias, sum_dim=2 if combine_colour else None)
+    s0 = F.avg_pool2d(s0, 2)
+    s1_ll, reals, imags = FWD_J1_ROT.apply(s1_j1, h0o, h1o, h2o, mode)
+    s2_j1 = _smooth_mag(reals, imags, bias)                                         # (N,6,6C',h,w)
+    s1p = F.avg_pool2d(s1_ll, 2)
+    h, w = s1p.shape[-2:]
+    if combine_colour:
+        return torch.cat((s0, s1p, s1_j2[:, :, 0], s2_j1.reshape(n, 36, h, w)), dim=1)
+    return torch.cat((s0[:, None], s1p.reshape(n, 6, c, h, w), s1_j2, s2_j1.reshape(n, 36, c, h, w)), dim=1)

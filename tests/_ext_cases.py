@@ -119,6 +119,23 @@ def check_scatj2(name, dev, dtype, tol):
         assert G.relerr(m(x.detach()).cpu().numpy(), g, 'Z') < tol   # no-grad path (nothing saved)
 
 
+def check_rot(name, dev, dtype, tol):
+    meta, g = G.INDEX[name], G.load(name)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        m = getattr(pw, meta['cls'])(**meta['kwargs']).to(dev)
+    finally:
+        torch.set_default_dtype(prev)
+    assert m.bandpass_diag and 'h2o' in dict(m.named_parameters())
+    x = _t(g['x'], dev, dtype).requires_grad_(True)
+    Z = m(x)
+    assert G.relerr(Z.detach().cpu().numpy(), g, 'Z') < tol
+    dx, = torch.autograd.grad((Z * _t(g['gz'], dev, dtype)).sum(), x)
+    assert G.relerr(dx.cpu().numpy(), g, 'dx') < tol
+
+
 DWT1D_CASES = sorted(k for k, v in G.INDEX.items() if v['kind'] == 'dwt1d')
 SWT_CASES = sorted(k for k, v in G.INDEX.items() if v['kind'] == 'swt')
 SCATJ2_CASES = sorted(k for k, v in G.INDEX.items() if v['kind'] == 'scatj2')
+ROT_CASES = sorted(k for k, v in G.INDEX.items() if v['kind'] == 'rot')

@@ -85,8 +85,8 @@ def test_scatlayerj2_refuses_what_upstream_refuses():
     with emu_backend.emulated():
         with pytest.raises(NotImplementedError):
             pw.ScatLayerj2(mode='zero')(torch.randn(1, 1, 16, 16))   # upstream: rowdfilt knows only 'symmetric'
-    with pytest.raises(NotImplementedError):
-        pw.ScatLayerj2(biort='near_sym_b_bp', qshift='qshift_b_bp')
+    with pytest.raises(AssertionError):
+        pw.ScatLayerj2(biort='near_sym_b_bp', qshift='qshift_a')     # upstream asserts the matching q-shift family
 
 
 def test_oracle_scatlayerj2_vs_reference_goldens():
@@ -98,3 +98,12 @@ def test_oracle_scatlayerj2_vs_reference_goldens():
         f = [np.asarray(v, dtype=np.float64).ravel()[::-1] for v in (h0o, h1o, h0a, h0b, h1a, h1b)]
         Z = wo.scat_layer_j2_forward(g['x'].astype(np.float64), *f, combine_colour=meta['combine_colour'])
         assert G.relerr(Z, g, 'Z') < 5e-7
+
+
+@pytest.mark.parametrize('name', E.ROT_CASES)
+def test_rotationally_symmetric_variants(name):
+    """ScatLayer / ScatLayerj2 with biort='near_sym_b_bp' (third band-pass pair for the diagonal orientations):
+    forward and backward against the reference."""
+    with emu_backend.emulated():
+        E.check_rot(name, 'cpu', torch.float64, 5e-7)
+        E.check_rot(name, 'cpu', torch.float32, 2e-5)

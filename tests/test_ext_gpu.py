@@ -54,3 +54,9 @@ def test_dwt1d_long_signals_vs_oracle_and_fp16():
 def test_scatlayerj2_forward_and_backward(name):
     E.check_scatj2(name, DEV, torch.float32, 2e-5)
     E.check_scatj2(name, DEV, torch.float64, 5e-7)
+
+
+@pytest.mark.parametrize('name', E.ROT_CASES)
+def test_rotationally_symmetric_variants(name):
+    E.check_rot(name, DEV, torch.float32, 2e-5)
+    E.check_rot(name, DEV, torch.float64, 5e-7)
