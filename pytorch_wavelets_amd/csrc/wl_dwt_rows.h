@@ -21,7 +21,7 @@
 // FMAs), taps in scalar registers, the schedule as a host-built table instead of per-wave scalar arithmetic (that
 // alone was 57 % of all instructions), and the roles dealt out so that every SIMD carries the same load.
 // Roles are per WAVE (wave-uniform branches, each role has its own lean body): level-1 / level-2 / level-3 compute
-// waves and the loader.  All waves follow the same deterministic schedule: per half-batch level 1 consumes 4
+// waves and the loaders.  All waves follow the same deterministic schedule: per half-batch level 1 consumes 4
 // extended input rows (2 feeds), level j+1 consumes whatever LL_j rows were complete at the barrier.  The launcher
 // simulates it on the host (WlRowsSched), refuses geometries whose rings would be overrun, and hands the result to
 // the kernel as a table.
@@ -38,7 +38,7 @@
 #ifndef WL_ROWS_LOADERS
 #define WL_ROWS_LOADERS 2       // loader waves: each issues the DMA of 4 / WL_ROWS_LOADERS rows of a half-batch (1, 2 or 4)
 #endif
-#define WL_ROWS_MAXHB 1536      // half-batches the schedule table (kernel argument) can hold
+#define WL_ROWS_MAXHB 768       // half-batches one schedule table (kernel argument) can hold
 // WL_ROWS_ABLATE (tools/build_ab.sh builds only, never defined in the product): 1 = no global stores, 2 = no DMA
 // loads, 8 = in-kernel cycle counters written over a few LL samples
 #ifndef WL_ROWS_ABLATE
@@ -90,6 +90,23 @@ struct WlRowsLevel {
     int nwaves;         // 64-column chunks of this level (each chunk is one compute wave)
 };
 
+// One SEGMENT of a plane: the feeds [f0, fend) of every level and the output rows [own_lo, own_hi) it stores.  A plane
+// is either processed whole by one workgroup or cut once (at a row of the coarsest level) into a top and a bottom
+// segment, so that the workgroups of a launch add up to whole rounds of the chip: with 384 planes on 256 CUs and two
+// workgroups per CU, 256 whole planes + 128 planes in halves give every CU one whole and one half plane instead of
+// leaving half the CUs idle for the second half of the launch.  The cut costs a re-computed halo (L-2 rows per level).
+struct WlRowsSeg {
+    int nhb;                        // half-batches (= barriers of the main loop) until every level has finished
+    int f0[WL_ROWS_MAXLEV];         // first feed of each level (= first row it produces)
+    int fend[WL_ROWS_MAXLEV];       // one past its last feed
+    int own_lo[WL_ROWS_MAXLEV];     // rows of each level this segment stores to HBM
+    int own_hi[WL_ROWS_MAXLEV];
+    // the schedule, simulated on the host (WlRowsSched): one byte per half-batch, bits 2j+1:2j = feeds of level j.
+    // Looked up by every wave instead of being recomputed: the scalar instructions of the schedule arithmetic were
+    // 57 % of all instructions issued by the first version of this kernel (rocprofv3 SQ_INSTS_SALU).
+    unsigned sched[WL_ROWS_MAXHB / 4];
+};
+
 template <typename T>
 struct WlRowsArgs {
     const T* x;                    // (NC, H, W) through x_ps / x_rs
@@ -102,7 +119,7 @@ struct WlRowsArgs {
     int64_t NC, x_ps, ll_ps;
     int x_rs, ll_rs;
     int nlev, ext, base;
-    int nhb;            // half-batches (= barriers of the main loop) until every level has finished
+    int nwhole;         // workgroups [0, nwhole) take whole planes; pairs of the remaining ones the two halves of a plane
     int ring_rows;      // rows of the LL rings (power of two)
     int zero_off;       // LDS byte offset of an all-zero row (zero padding above / below the plane)
     int lds_bytes;
@@ -111,28 +128,29 @@ struct WlRowsArgs {
     signed char role_level[WL_ROWS_WAVES];
     short role_col0[WL_ROWS_WAVES];
     WlRowsLevel g[WL_ROWS_MAXLEV];
-    // the schedule, simulated on the host (WlRowsSched): one byte per half-batch, bits 2j+1:2j = feeds of level j.
-    // Looked up by every wave instead of being recomputed: the scalar instructions of the schedule arithmetic were
-    // 57 % of all instructions issued by the first version of this kernel (rocprofv3 SQ_INSTS_SALU).
-    unsigned sched[WL_ROWS_MAXHB / 4];
+    WlRowsSeg seg[3];   // 0: whole plane, 1: top half, 2: bottom half
 };
 
-// The schedule the LAUNCHER steps through to fill WlRowsArgs::sched: fed[j] = feeds level j has consumed.  A feed is
-// one pair of extended source rows (2f+base, 2f+base+1); the first (L-2)/2 feeds of a level only fill its window.
+// The schedule the LAUNCHER steps through to fill WlRowsSeg::sched: fed[j] = next feed of level j.  A feed is one pair
+// of extended source rows (2f+base, 2f+base+1) and completes output row f - (L-2)/2 once the window is full, i.e.
+// from the (L-2)/2-th feed of the segment on.
 struct WlRowsSched {
     int fed[WL_ROWS_MAXLEV];
-    WL_HD void init() { for (int j = 0; j < WL_ROWS_MAXLEV; ++j) fed[j] = 0; }
-    template <typename A> WL_HD int feeds_total(const A& a, int j, int LT) const { return a.g[j].Kh + (LT - 2) / 2; }
-    WL_HD int emitted(int j, int LT) const { const int e = fed[j] - (LT - 2) / 2; return e > 0 ? e : 0; }
+    WL_HD void init(const WlRowsSeg& sg) { for (int j = 0; j < WL_ROWS_MAXLEV; ++j) fed[j] = sg.f0[j]; }
+    // rows [sg.f0[j], avail(j)) of level j are complete
+    WL_HD int avail(const WlRowsSeg& sg, int j, int LT) const {
+        const int warm = (LT - 2) / 2;
+        return fed[j] - sg.f0[j] > warm ? fed[j] - warm : sg.f0[j];
+    }
     // feeds level j runs in the half-batch that starts now; only looks at the state as of the barrier
-    template <typename A> WL_HD int feeds_now(const A& a, int j, int LT) const {
-        const int left = feeds_total(a, j, LT) - fed[j];
+    template <typename A> WL_HD int feeds_now(const A& a, const WlRowsSeg& sg, int j, int LT) const {
+        const int left = sg.fend[j] - fed[j];
         if (j == 0) return left > 2 ? 2 : left;
-        const int avail = emitted(j - 1, LT);
+        const int av = avail(sg, j - 1, LT);
         const int Hs = a.g[j].Hs;
         const int e = a.base + 2 * fed[j];
-        const bool ok0 = left > 0 && wl_ext1(e, Hs, a.ext) < avail && wl_ext1(e + 1, Hs, a.ext) < avail;
-        const bool ok1 = left > 1 && wl_ext1(e + 2, Hs, a.ext) < avail && wl_ext1(e + 3, Hs, a.ext) < avail;
+        const bool ok0 = left > 0 && wl_ext1(e, Hs, a.ext) < av && wl_ext1(e + 1, Hs, a.ext) < av;
+        const bool ok1 = left > 1 && wl_ext1(e + 2, Hs, a.ext) < av && wl_ext1(e + 3, Hs, a.ext) < av;
         return ok0 ? (ok1 ? 2 : 1) : 0;
     }
 };
@@ -150,14 +168,15 @@ struct WlAfbRows {
     static_assert((D - 1) * NL < 64, "prefetch distance exceeds the vmcnt range");
 
     // ---- loader wave ------------------------------------------------------------------------------------------
-    static WL_DEV void loader(const Args& a, const WlCtx& ctx, int64_t plane, int lane, int lidx) {
+    static WL_DEV void loader(const Args& a, const WlRowsSeg& sg, const WlCtx& ctx, int64_t plane, int lane, int lidx) {
         const WlRowsLevel& g = a.g[0];
         const char* xp = reinterpret_cast<const char*>(a.x + (size_t)plane * a.x_ps);
         const int row_bytes = g.Ws * SZ;
         const int row_stride = a.x_rs * SZ;
-        const int nhb0 = (g.Kh + WARM + 1) / 2;                  // half-batches in which level 1 runs
-        const int e_last = a.base + 2 * (g.Kh + WARM) - 1;       // last extended row level 1 consumes
-        const int ring = g.ring_off, pitch = g.ring_pitch, pad = g.pad, Hs = g.Hs, base = a.base, ext = a.ext;
+        const int nhb0 = (sg.fend[0] - sg.f0[0] + 1) / 2;        // half-batches in which level 1 runs
+        const int e_last = a.base + 2 * sg.fend[0] - 1;          // last extended row level 1 consumes
+        const int ring = g.ring_off, pitch = g.ring_pitch, pad = g.pad, Hs = g.Hs, ext = a.ext;
+        const int base = a.base + 2 * sg.f0[0];                  // extended row of the segment's first feed
         const int rfirst = lidx * LROWS;   // this loader's rows of every slot: rfirst .. rfirst + LROWS - 1
         // halo cells of those rows: item = (row r, cell c); a lane handles items lane and lane + 64
         const int NH = g.hl + g.hr;
@@ -196,7 +215,7 @@ struct WlAfbRows {
         };
         for (int h = 0; h < D; ++h) issue(h);
         unsigned long long tw = 0, tb = 0, ti = 0;
-        for (int hb = 0; hb < a.nhb; ++hb) {
+        for (int hb = 0; hb < sg.nhb; ++hb) {
             const unsigned long long c0 = WL_TICK();
             if (hb < nhb0) {
                 if (!(WL_ROWS_ABLATE & 2)) wl_wait_vm<(D - 1) * NL>();   // the rows of this half-batch have landed
@@ -273,7 +292,7 @@ struct WlAfbRows {
     // column filter of the window w[0..L) (oldest first) into one sample of each sub-band, and their stores:
     // (LL, W-lo/H-hi) and (W-hi/H-lo, HH), two chains each (even / odd taps)
     template <bool LAST, bool HALO>
-    static WL_DEV void col_pass(Lane& L, const Role& R, char* smem, const wl_v2* w, int orow) {
+    static WL_DEV void col_pass(Lane& L, const Role& R, char* smem, const wl_v2* w, int orow, bool keep) {
         wl_v2 cl = wl_pk_mul_x(R.th[0], w[0]), ch = wl_pk_mul_y(R.th[0], w[0]);
         wl_v2 cl2 = wl_pk_mul_x(R.th[1], w[1]), ch2 = wl_pk_mul_y(R.th[1], w[1]);
 #pragma unroll
@@ -287,7 +306,8 @@ struct WlAfbRows {
         ch += ch2;
         const unsigned ob = L.ob;
         L.ob = ob + R.rowb;
-        const bool st = !(WL_ROWS_ABLATE & 1) || (cl.x + cl.y + ch.x + ch.y == 12345.f);   // product: always true
+        // keep: the row belongs to this segment (wave-uniform); halo rows of a cut plane are computed, not stored
+        const bool st = keep && (!(WL_ROWS_ABLATE & 1) || (cl.x + cl.y + ch.x + ch.y == 12345.f));
         if (st) {
             *reinterpret_cast<T*>(R.hp0 + ob) = (T)cl.y;    // W-lo / H-hi
             *reinterpret_cast<T*>(R.hp1 + ob) = (T)ch.x;    // W-hi / H-lo
@@ -307,7 +327,7 @@ struct WlAfbRows {
 
     // one feed: row-filter the two new source rows into the window and - once the window is full - emit one output row
     template <bool LAST, bool HALO>
-    static WL_DEV void feed1(Lane& L, const Role& R, char* smem, int row0, int row1, bool emit, int orow) {
+    static WL_DEV void feed1(Lane& L, const Role& R, char* smem, int row0, int row1, bool emit, int orow, bool keep) {
         wl_v2 s0[LT / 2], s1[LT / 2], a0, a1;
         load_rows(L, smem, row0, row1, s0, s1);
         row_pass(R, s0, s1, a0, a1);
@@ -315,12 +335,13 @@ struct WlAfbRows {
         for (int t = 0; t < LT - 2; ++t) L.win[t] = L.win[t + 2];
         L.win[LT - 2] = a0;
         L.win[LT - 1] = a1;
-        if (emit) col_pass<LAST, HALO>(L, R, smem, L.win, orow);
+        if (emit) col_pass<LAST, HALO>(L, R, smem, L.win, orow, keep);
     }
     // two feeds of the steady state (both emit): all four rows are requested from LDS before the first FMA, the
     // window moves once (by four rows) instead of twice
     template <bool LAST, bool HALO>
-    static WL_DEV void feed2(Lane& L, const Role& R, char* smem, int row0, int row1, int row2, int row3, int orow) {
+    static WL_DEV void feed2(Lane& L, const Role& R, char* smem, int row0, int row1, int row2, int row3, int orow,
+                             bool keep0, bool keep1) {
         wl_v2 s0[LT / 2], s1[LT / 2], s2[LT / 2], s3[LT / 2];
         load_rows(L, smem, row0, row1, s0, s1);
         load_rows(L, smem, row2, row3, s2, s3);
@@ -328,15 +349,15 @@ struct WlAfbRows {
 #pragma unroll
         for (int t = 0; t < LT; ++t) w[t] = L.win[t];
         row_pass(R, s0, s1, w[LT], w[LT + 1]);
-        col_pass<LAST, HALO>(L, R, smem, w + 2, orow);
+        col_pass<LAST, HALO>(L, R, smem, w + 2, orow, keep0);
         row_pass(R, s2, s3, w[LT + 2], w[LT + 3]);
-        col_pass<LAST, HALO>(L, R, smem, w + 4, orow + 1);
+        col_pass<LAST, HALO>(L, R, smem, w + 4, orow + 1, keep1);
 #pragma unroll
         for (int t = 0; t < LT; ++t) L.win[t] = w[t + 4];
     }
 
     template <int j>
-    static WL_DEV void compute(const Args& a, const WlCtx& ctx, int64_t plane, int col0, int lane) {
+    static WL_DEV void compute(const Args& a, const WlRowsSeg& sg, const WlCtx& ctx, int64_t plane, int col0, int lane) {
         const WlRowsLevel& g = a.g[j];
         const int k = col0 + lane;
         const bool active = k < g.Kw;
@@ -359,7 +380,7 @@ struct WlAfbRows {
         Lane L;
 #pragma unroll
         for (int t = 0; t < LT; ++t) L.win[t] = wl_v2{0.f, 0.f};
-        L.ob = (unsigned)k * SZ;
+        L.ob = (unsigned)sg.f0[j] * R.rowb + (unsigned)k * SZ;   // the first row this segment produces is row f0
         L.off = g.pad + (2 * (active ? k : 0) + a.base) * SZ;   // halo cells included: always >= 0
         // the halo cells of the NEXT level's ring rows whose source column is k - at most one on either side
         L.ndst = gn.pad + k * SZ; L.hx0 = L.hx1 = -1;
@@ -373,13 +394,14 @@ struct WlAfbRows {
         }
         // does any lane of this wave own a halo cell?  (columns near either edge of the next level's rows)
         R.halo = !R.last && a.ext != WL_EXT_ZERO && (col0 <= gn.hl + 1 || col0 + 63 >= gn.Ws - gn.hr - 2);
-        if (R.last) main_loop<j, true, false>(a, ctx, plane, L, R, active, k);
-        else if (R.halo) main_loop<j, false, true>(a, ctx, plane, L, R, active, k);
-        else main_loop<j, false, false>(a, ctx, plane, L, R, active, k);
+        if (R.last) main_loop<j, true, false>(a, sg, ctx, plane, L, R, active, k);
+        else if (R.halo) main_loop<j, false, true>(a, sg, ctx, plane, L, R, active, k);
+        else main_loop<j, false, false>(a, sg, ctx, plane, L, R, active, k);
     }
 
     template <int j, bool LAST, bool HALO>
-    static WL_DEV void main_loop(const Args& a, const WlCtx& ctx, int64_t plane, Lane& L, const Role& R, bool active, int k) {
+    static WL_DEV void main_loop(const Args& a, const WlRowsSeg& sg, const WlCtx& ctx, int64_t plane, Lane& L, const Role& R,
+                                 bool active, int k) {
         const WlRowsLevel& g = a.g[j];
         char* const smem = ctx.smem;
         const int rmask = R.rmask, zrow = a.zero_off, ring = g.ring_off, pitch = g.ring_pitch, Hs = g.Hs;
@@ -404,26 +426,31 @@ struct WlAfbRows {
             r0 = wl_uniform(r0); r1 = wl_uniform(r1);
         };
 
-        int fed = 0;            // feeds this level has consumed (wave-uniform)
+        const int f0 = sg.f0[j], own_lo = sg.own_lo[j], own_hi = sg.own_hi[j];
+        int fed = f0;           // next feed of this level (wave-uniform)
         unsigned long long tb = 0, tf = 0, ts = 0, c3 = WL_TICK();
-        for (int hb = 0; hb < a.nhb; ++hb) {
+        for (int hb = 0; hb < sg.nhb; ++hb) {
             const unsigned long long c0 = WL_TICK();
             ts += c0 - c3;
-            const int n = wl_uniform((int)(a.sched[hb >> 2] >> (8 * (hb & 3) + 2 * j)) & 3);   // read before the barrier
+            const int n = wl_uniform((int)(sg.sched[hb >> 2] >> (8 * (hb & 3) + 2 * j)) & 3);   // read before the barrier
             ctx.sync();
             const unsigned long long c1 = WL_TICK();
             tb += c1 - c0;
-            if (n == 2 && fed >= WARM) {            // the steady state of level 1
+            const int orow = fed - WARM;   // the output row the next feed completes (once the window is full)
+            if (n == 2 && fed - f0 >= WARM) {       // the steady state of level 1
                 int r0, r1, r2, r3;
                 rows_of(fed, hb, 0, r0, r1);
                 rows_of(fed + 1, hb, 1, r2, r3);
-                if (active) feed2<LAST, HALO>(L, R, smem, r0, r1, r2, r3, fed - WARM);
+                if (active)
+                    feed2<LAST, HALO>(L, R, smem, r0, r1, r2, r3, orow, orow >= own_lo && orow < own_hi,
+                                      orow + 1 >= own_lo && orow + 1 < own_hi);
                 fed += 2;
             } else {
                 for (int i = 0; i < n; ++i) {
                     int r0, r1;
                     rows_of(fed, hb, i, r0, r1);
-                    if (active) feed1<LAST, HALO>(L, R, smem, r0, r1, fed >= WARM, fed - WARM);
+                    const int o = fed - WARM;
+                    if (active) feed1<LAST, HALO>(L, R, smem, r0, r1, fed - f0 >= WARM, o, o >= own_lo && o < own_hi);
                     ++fed;
                 }
             }
@@ -439,7 +466,10 @@ struct WlAfbRows {
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
         const int tid = ctx.tid;
         const int wave = wl_uniform(tid >> 6), lane = tid & 63;
-        const int64_t plane = ctx.bid;
+        // workgroup -> (plane, segment)
+        const int64_t bid = ctx.bid;
+        const int64_t plane = bid < a.nwhole ? bid : a.nwhole + (bid - a.nwhole) / 2;
+        const WlRowsSeg& sg = a.seg[bid < a.nwhole ? 0 : 1 + (int)((bid - a.nwhole) & 1)];
         // all of LDS starts as zeros: the zero row, and halo cells that stay zero in zero-padding mode
         for (int i = tid * 16; i < a.lds_bytes; i += kThreads * 16) {
             wl_f4 z; z.x = z.y = z.z = z.w = 0.f;
@@ -447,11 +477,11 @@ struct WlAfbRows {
         }
         ctx.sync();
         const int lev = wl_uniform(a.role_level[wave]), col0 = wl_uniform(a.role_col0[wave]);
-        if (lev == -1) loader(a, ctx, plane, lane, col0);
-        else if (lev == 0) compute<0>(a, ctx, plane, col0, lane);
-        else if (lev == 1) compute<1>(a, ctx, plane, col0, lane);
-        else if (lev == 2) compute<2>(a, ctx, plane, col0, lane);
+        if (lev == -1) loader(a, sg, ctx, plane, lane, col0);
+        else if (lev == 0) compute<0>(a, sg, ctx, plane, col0, lane);
+        else if (lev == 1) compute<1>(a, sg, ctx, plane, col0, lane);
+        else if (lev == 2) compute<2>(a, sg, ctx, plane, col0, lane);
         else
-            for (int hb = 0; hb < a.nhb; ++hb) ctx.sync();   // spare wave: keeps the barrier count
+            for (int hb = 0; hb < sg.nhb; ++hb) ctx.sync();   // spare wave: keeps the barrier count
     }
 };

@@ -144,7 +144,8 @@ def _num_cus(device):
 def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=0):
     """`nlev` (1..3) analysis levels in ONE launch of the streaming kernel (one workgroup per plane, LL_j stay in LDS,
     HBM traffic = the algorithmic minimum).  Returns (yl, [yh_0..]) or None when the kernel does not cover the
-    configuration (caller goes level by level).  strips: 0 = only when the planes alone fill the chip, 1 = force."""
+    configuration (caller goes level by level).  strips: 0 = only when the planes alone fill the chip (the engine cuts
+    some planes in two to fill whole rounds), 1 = force, whole planes only, 2 = force, every plane cut in two."""
     import ctypes
     _check_tensor(x, 'x')
     N, C, H, W = x.shape
@@ -152,7 +153,7 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=0):
     # the launcher's envelope, checked here first so that a decline costs no allocation
     if (x.dtype == torch.float64 or nlev < 1 or nlev > 3 or h_h_lo.numel() != L or L % 2 or L > 12
             or (W * x.element_size()) % 16 or (nlev > 1 and mode not in (0, 1, 4)) or x.numel() == 0
-            or (strips == 0 and N * C < _num_cus(x.device)) or strips > 1):
+            or (strips == 0 and N * C < _num_cus(x.device)) or strips > 2):
         return None
     x = x.contiguous()
     hwl, hwh, hhl, hhh = (_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi))

@@ -87,22 +87,24 @@ def test_mode_errors():
                 pw.DWTForward(mode=bad)(torch.randn(1, 1, 8, 8))
 
 
-def _fused(x, wave, mode, J):
+def _fused(x, wave, mode, J, strips=1):
+    """strips = 1: one workgroup per plane; 2: every plane cut into a top and a bottom segment (halo rows re-computed)."""
     from pytorch_wavelets_amd import ops, filters
     from pytorch_wavelets_amd.dwt import lowlevel
     h0, h1 = filters.dwt_analysis_taps(wave)
     th = [torch.tensor(v, dtype=torch.float32) for v in (h0, h1, h0, h1)]
     with emu_backend.emulated():
-        return ops.afb2d_fused(x, *th, lowlevel.mode_to_int(mode), J, strips=1)
+        return ops.afb2d_fused(x, *th, lowlevel.mode_to_int(mode), J, strips=strips)
 
 
+@pytest.mark.parametrize('strips', [1, 2])
 @pytest.mark.parametrize('name', ['dwt_00', 'dwt_01', 'dwt_02', 'dwt_04', 'dwt_09'])
-def test_streaming_kernel_fp32_goldens_on_emulator(name):
+def test_streaming_kernel_fp32_goldens_on_emulator(name, strips):
     """The streaming multi-level analysis kernel (wl_dwt2d_analysis_fused: one workgroup per plane, LL_j in LDS
     rings, LDS-DMA row loads released by counted waits) against the reference goldens - incl. the benchmark geometry
     512x512 J=3 db4 symmetric (dwt_02)."""
     meta, g = G.INDEX[name], G.load(name)
-    res = _fused(torch.tensor(g['x']), meta['wave'], meta['mode'], meta['J'])
+    res = _fused(torch.tensor(g['x']), meta['wave'], meta['mode'], meta['J'], strips)
     assert res is not None, 'the streaming kernel was expected to cover this case'
     yl, yh = res
     assert G.relerr(yl.numpy(), g, 'yl') < 1e-5
@@ -126,7 +128,10 @@ def test_streaming_kernel_vs_oracle_random_shapes(seed):
         W = 4 * int(rng.randint(max(2, (L + 3) // 4), [20, 40, 90, 150][seed % 4]))
         x = torch.tensor(rng.randn(1, 2, H, W), dtype=torch.float32)
         oyl, oyh = wo.dwt_forward(x.double().numpy(), J, h0, h1, h0, h1, mode)
-        res = _fused(x, wave, mode, J)
+        strips = 1 + int(rng.randint(0, 2))
+        res = _fused(x, wave, mode, J, strips)
+        if res is None and strips == 2:   # planes too short to be cut: whole planes
+            res = _fused(x, wave, mode, J, 1)
         if res is None:   # the launcher may decline (a level shorter than the filter, or periodization with
             # L % 4 == 0 whose samples sit on odd addresses); never silently wrong
             assert min(H, W) < 2 ** (J - 1) * (2 * L) or (mode == 'periodization' and L % 4 == 0), (wave, mode, H, W, J)

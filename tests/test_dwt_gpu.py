@@ -237,12 +237,13 @@ def test_streaming_kernel_vs_oracle(wave, mode, J, shape):
     h0, h1 = F.dwt_analysis_taps(wave)
     th = [torch.tensor(v, dtype=torch.float32, device=DEV) for v in (h0, h1, h0, h1)]
     oyl, oyh = wo.dwt_forward(x.double().numpy(), J, h0, h1, h0, h1, mode)
-    res = ops.afb2d_fused(x.to(DEV), *th, lowlevel.mode_to_int(mode), J, strips=1)
-    assert res is not None
-    yl, yh = res
-    assert rel(yl, oyl) < TOL
-    for a, b in zip(yh, oyh):
-        assert rel(a, b) < TOL
+    for strips in (1, 2):   # whole planes; every plane cut into a top and a bottom segment
+        res = ops.afb2d_fused(x.to(DEV), *th, lowlevel.mode_to_int(mode), J, strips=strips)
+        assert res is not None
+        yl, yh = res
+        assert rel(yl, oyl) < TOL
+        for a, b in zip(yh, oyh):
+            assert rel(a, b) < TOL
     # float16 storage, fp32 accumulate (rows in multiples of eight halfs)
     if shape[-1] % 8 == 0:
         xh = x.half()
@@ -309,3 +310,26 @@ def test_tile_equals_generic_random_shapes_gpu(seed, monkeypatch):
         xh = x.half()
         yl, yh = pw.DWTForward(J=J, wave=wave, mode=mode).to(DEV).half()(xh)
         assert float((yl.float() - out['1'][0]).abs().max()) <= 1e-2 * float(out['1'][0].abs().max())
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs')
+def test_tensors_on_a_non_current_device():
+    """Single-process multi-GPU use: module and input on cuda:1 while cuda:0 is current - the C ABI launches on the
+    current device with the stream it is handed, so ops.py switches devices around every call (as ATen does)."""
+    torch.manual_seed(1)
+    x = torch.randn(2, 3, 64, 64)
+    h0, h1 = F.dwt_analysis_taps('db4')
+    oyl, oyh = wo.dwt_forward(x.double().numpy(), 2, h0, h1, h0, h1, 'symmetric')
+    assert torch.cuda.current_device() == 0
+    xfm = pw.DWTForward(J=2, wave='db4', mode='symmetric').to('cuda:1')
+    yl, yh = xfm(x.to('cuda:1'))
+    assert yl.device.index == 1 and rel(yl, oyl) < TOL and rel(yh[0], oyh[0]) < TOL
+    assert torch.cuda.current_device() == 0
+
+
+def test_mixed_device_inputs_are_rejected():
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    ifm = pw.DWTInverse(wave='db1').to('cuda:0')
+    with pytest.raises(RuntimeError, match='different devices'):
+        ifm((torch.randn(1, 1, 4, 4, device='cuda:0'), [torch.randn(1, 1, 3, 4, 4, device='cuda:1')]))
