@@ -93,6 +93,23 @@ int wl_dwt2d_analysis_fused(const void* x, void* yl, void* const* yh, int dtype,
                             int W, int nlev, const void* h_w_lo, const void* h_w_hi, const void* h_h_lo,
                             const void* h_h_hi, int L, int mode, int strips, void* stream);
 
+/* All `nlev` (1..3) synthesis levels in ONE launch = the body of DWTInverse.forward's level loop
+ * (dwt/transform2d.py:131-148) = nlev x SFB2D.forward (dwt/lowlevel.py:671-680): yl (planes, Kh[nlev-1],
+ * Kw[nlev-1]) with dense rows, planes `yl_plane_stride` elements apart (yl_h / yl_w = its logical size, which must
+ * equal the coarsest high-pass size: the caller crops the reference's 'unpad' surplus row / column first);
+ * yh[j] (planes,3,Kh[j],Kw[j]) dense, j = 0 finest (`yh`, `Kh`, `Kw` are HOST arrays of nlev entries) ->
+ * y (planes, 2*Kh[0]-L+2, 2*Kw[0]-L+2) dense.  Between levels the low-pass of level j+1 is cropped to yh[j]'s size
+ * exactly as the reference does.  One workgroup streams one plane (or half of one) coarsest level first; the
+ * intermediate low-passes stay in LDS rings, every coefficient is read from HBM once (LDS-DMA in whole 1024-byte
+ * chunks of the contiguous band planes) and x is written once.  Same even tap count L <= 12 on both axes of every
+ * level, F32/F16 data, float taps; zero / symmetric / reflect / periodic (not periodization); row bytes and plane
+ * bytes multiples of four.  `strips` as for wl_dwt2d_analysis_fused.  Returns WL_ERR_UNSUPPORTED outside the
+ * kernel's envelope: the caller then uses wl_dwt2d_synthesis level by level. */
+int wl_dwt2d_synthesis_fused(const void* yl, int64_t yl_plane_stride, int yl_row_stride, int yl_h, int yl_w,
+                             const void* const* yh, const int* Kh, const int* Kw, void* y, int dtype,
+                             int64_t planes, int nlev, const void* g_w_lo, const void* g_w_hi,
+                             const void* g_h_lo, const void* g_h_hi, int L, int mode, int strips, void* stream);
+
 /* ---- DTCWT (filters = the reference's stored buffers: reversed columns, dtcwt/lowlevel.py:58-67) ------------ */
 
 /* Level-1 forward = FWD_J1.forward -> fwd_j1 (dtcwt/transform_funcs.py:98-121, :346-358): 2 rowfilter +

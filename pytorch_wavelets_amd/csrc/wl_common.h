@@ -74,6 +74,7 @@ struct WlCtx {
 //                least one lane of the wave must be on (the wait counts are per wave-instruction).  The data
 //                is visible to the issuing wave after wl_wait_vm<N>() (at most N younger DMA / vector-memory
 //                operations of that wave still outstanding) and to other waves after a barrier behind that wait;
+//   wl_dma4    : the same with 4 bytes per lane (global_load_lds_dword) at LDS bytes [lds_off + 4*lane, +4);
 //   The instruction is emitted through inline assembly on purpose: the compiler would otherwise order every later
 //   LDS read behind ALL outstanding DMA loads (s_waitcnt vmcnt(0)), i.e. no prefetch distance.
 // The host emulation defers each copy until the lane's wl_wait_vm releases it, so a missing or too permissive wait
@@ -88,6 +89,22 @@ WL_DEV void wl_dma16(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool 
     if (lane_on)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0), "v"(gsrc) : "memory", "m0");
 }
+// the same with the global address split into a wave-uniform base (scalar registers) and a 32-bit per-lane byte offset
+WL_DEV void wl_dma16_s(const WlCtx& ctx, unsigned lds_off, const void* sbase, unsigned voff, bool lane_on) {
+    const unsigned m0 = __builtin_amdgcn_readfirstlane(ctx.lds_base + lds_off);
+    if (lane_on)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(m0), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+WL_DEV void wl_dma4_s(const WlCtx& ctx, unsigned lds_off, const void* sbase, unsigned voff, bool lane_on) {
+    const unsigned m0 = __builtin_amdgcn_readfirstlane(ctx.lds_base + lds_off);
+    if (lane_on)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" : : "s"(m0), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+WL_DEV void wl_dma4(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on) {   // 4 bytes per lane
+    const unsigned m0 = __builtin_amdgcn_readfirstlane(ctx.lds_base + lds_off);
+    if (lane_on)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(m0), "v"(gsrc) : "memory", "m0");
+}
 template <int N> WL_DEV void wl_wait_vm() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
     __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));   // vmcnt(N), others untouched
@@ -96,6 +113,9 @@ template <int N> WL_DEV void wl_wait_vm() {
 inline int wl_uniform(int v) { return v; }
 inline float wl_uniform_f(float v) { return v; }
 void wl_dma16(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on);
+void wl_dma4(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on);
+inline void wl_dma16_s(const WlCtx& ctx, unsigned lds_off, const void* sbase, unsigned voff, bool lane_on) { wl_dma16(ctx, lds_off, (const char*)sbase + voff, lane_on); }
+inline void wl_dma4_s(const WlCtx& ctx, unsigned lds_off, const void* sbase, unsigned voff, bool lane_on) { wl_dma4(ctx, lds_off, (const char*)sbase + voff, lane_on); }
 void wl_emu_wait_vm(int n);
 template <int N> inline void wl_wait_vm() { wl_emu_wait_vm(N); }
 #endif

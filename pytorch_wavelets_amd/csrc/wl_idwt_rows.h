@@ -1,0 +1,452 @@
+// Streaming multi-level 2-D DWT synthesis: the mirror image of wl_dwt_rows.h.  One workgroup owns one (n,c) plane (or
+// the top / bottom half of one) and marches down it, coarsest level first:
+//   * every coefficient row of yl / yh[j] is read from HBM exactly once by LDS-DMA (global_load_lds: one 16-byte piece
+//     per lane plus a dword tail, band rows are only 4-byte aligned) into small per-band LDS rings, D feeds ahead;
+//   * a lane owns one PAIR of output columns (2c, 2c+1) of its level.  Per new coefficient row k ("feed") it runs the
+//     polyphase row synthesis  (a,b)[n..n+1] = sum_t (ll|hl, lh|hh)[c + L/2-1 - t] * (g[2t], g[2t+1])  straight from the
+//     rings, pushes the result into an L/2-row window in registers and - once the window is full - the polyphase
+//     column synthesis of output rows 2(k - (L-2)/2) and the one below: v_pk_fma_f32 on (even,odd) tap pairs with the
+//     broadcast sample picked by op_sel.  No zero stuffing, no transposed convolution, no boundary handling at all
+//     (every sample a valid lane reads exists; the window starts as zeros = the coefficients above the plane);
+//   * the output rows of level j+1 (= LL_j) go to an LDS ring that the waves of level j consume; LL_1 .. LL_{J-1}
+//     never touch HBM.  HBM traffic = yl, yh[j] in + x out = the algorithmic minimum of SURVEY.md 8(d);
+//   * x leaves as 8 contiguous bytes per lane, whole rows written by consecutive lanes of consecutive waves.
+// Roles are per wave: compute waves of every level and loader waves (one per band at the finest level, one per coarser
+// level); the schedule (who runs how many feeds in which half-batch, with the rings as back-pressure) is simulated by
+// the launcher and handed over as a table, exactly as for the analysis kernel.
+//
+// Restates DWTInverse.forward's level loop (reference dwt/transform2d.py:131-148) = J x SFB2D.forward
+// (dwt/lowlevel.py:671-680) = 3J x sfb1d (:226-271) incl. the 'unpad' crop of an LL that is one row / column larger
+// than the next finer high-pass; zero / symmetric / reflect / periodic (synthesis is the same for all of them).
+#pragma once
+#include "wl_common.h"
+#include "wl_dwt_rows.h"   // wl_pk_fma_x / _y, wl_pk_mul_x / _y, wl_uniform_v2
+
+#define WL_IROWS_MAXLEV 3
+#define WL_IROWS_WAVES 14
+#define WL_IROWS_MAXHB 640
+#ifndef WL_IROWS_ABLATE
+#define WL_IROWS_ABLATE 0       // measurement builds only (tools/build_ab.sh): 1 no global stores, 2 no DMA, 4 no arithmetic,
+#endif                          // 8 per-wave cycle counters into row 0 of x, 16 / 32 no loads of level 0 / levels > 0
+#if (WL_IROWS_ABLATE & 8) && defined(__HIPCC__)
+#define WL_ITICK() __builtin_readcyclecounter()
+#else
+#define WL_ITICK() 0ull
+#endif
+#define WL_IROWS_MAX_VM 48      // DMA instructions a loader wave may have outstanding
+#define WL_IROWS_CHUNK 1024     // bytes one LDS-DMA instruction moves: 64 lanes x 16 bytes
+
+struct WlIRowsLevel {
+    int Kh, Kw;         // coefficient rows / cols (size of yh[j]; the LL source is cropped to it)
+    int OH, OW;         // output rows / cols = 2K - L + 2
+    int src_off[4];     // LDS byte offsets of the four source rings: [0] = LL, [1..3] = lh, hl, hh
+    int ll_rows;        // rows of the low-pass ring (power of two, row k in k & (rows - 1)): chosen by the launcher when
+    int ll_pitch;       // level j+1 writes it (pitch padded to 16 bytes), = dma_rows / rbytes when it arrives by DMA
+    // DMA rings are flat images of dma_rows consecutive coefficient rows (row k at (k & (dma_rows - 1)) * rbytes, no
+    // padding): a band plane is contiguous in HBM, so the loader copies it in whole 1024-byte chunks that ignore the
+    // row boundaries - an LDS-DMA instruction costs the CU the same ~64 cycles whether it moves 4 bytes or 1024
+    int rbytes;         // bytes of a coefficient row = Kw * sizeof(T)
+    int dma_rows;       // power of two >= 1024 / rbytes + 4; dma_rows * rbytes is a multiple of 16
+    int dma_shift;      // log2(dma_rows)
+    int cpr;            // chunks per revolution of the ring = ceil(dma_rows * rbytes / 1024)
+    int nwaves;         // compute waves: 64 column pairs each
+};
+
+struct WlIRowsSeg {
+    int nhb;
+    int f0[WL_IROWS_MAXLEV], fend[WL_IROWS_MAXLEV];   // feeds [f0, fend) of each level
+    int own_lo, own_hi;                               // rows of x this segment stores
+    unsigned sched[WL_IROWS_MAXHB / 4];               // per half-batch: bits 2j+1:2j = feeds of level j
+};
+
+template <typename T>
+struct WlIRowsArgs {
+    const T* yl;                   // coarsest low-pass, (NC, Kh, Kw) planes ll_ps apart, rows dense
+    const T* yh[WL_IROWS_MAXLEV];  // (NC, 3, Kh_j, Kw_j) dense, j = 0 finest
+    T* y;                          // (NC, OH_0, OW_0) dense
+    const float* g_w_lo;
+    const float* g_w_hi;
+    const float* g_h_lo;
+    const float* g_h_hi;
+    int64_t NC, ll_ps;
+    int nlev, nwhole, lds_bytes;
+    // role of every wave: role_level >= 0: compute wave of that level, role_arg = first column pair;
+    //                     role_level == -1: loader, role_arg = level * 16 + first_source * 4 + nsources;  -2: spare
+    signed char role_level[WL_IROWS_WAVES];
+    short role_arg[WL_IROWS_WAVES];
+    WlIRowsLevel g[WL_IROWS_MAXLEV];
+    WlIRowsSeg seg[3];             // 0: whole plane, 1: top half, 2: bottom half
+};
+
+// Host-side schedule of one segment (also documents the rules the table encodes).
+struct WlIRowsSched {
+    int fed[WL_IROWS_MAXLEV];
+    WL_HD void init(const WlIRowsSeg& sg) { for (int j = 0; j < WL_IROWS_MAXLEV; ++j) fed[j] = sg.f0[j]; }
+    // output rows [2 f0, made(j)) of level j have been produced
+    WL_HD int made(const WlIRowsSeg& sg, int j, int LT) const {
+        const int warm = (LT - 2) / 2;
+        return fed[j] - sg.f0[j] > warm ? 2 * (fed[j] - warm) : 2 * sg.f0[j];
+    }
+    template <typename A> WL_HD int feeds_now(const A& a, const WlIRowsSeg& sg, int j, int LT) const {
+        const int warm = (LT - 2) / 2;
+        int n = 0;
+        while (n < 2 && fed[j] + n < sg.fend[j]) {
+            const int k = fed[j] + n;
+            // its LL row must exist (the coarsest level's arrives by DMA like the bands) ...
+            if (j + 1 < a.nlev && k >= made(sg, j + 1, LT)) break;
+            // ... and its two output rows must fit into the ring of the level below without evicting an unread row
+            if (j > 0 && k - sg.f0[j] >= warm && 2 * (k - warm) + 1 - a.g[j - 1].ll_rows >= fed[j - 1]) break;
+            ++n;
+        }
+        return n;
+    }
+};
+
+#if defined(__HIPCC__)
+WL_DEV void wl_fail() { __builtin_trap(); }
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n in [0, 48].  The count is an immediate, and both a switch and a
+// hand-written decision tree come out of the compiler as a chain through every case (hundreds of cycles per
+// half-batch in the loader waves, which every other wave then waits for at the barrier): a computed jump into a table
+// of (s_waitcnt, s_branch) pairs instead - 8 bytes per entry, the table starts 20 bytes behind the s_getpc.
+WL_DEV void wl_wait_vm_dyn(int n) {
+    static_assert(WL_IROWS_MAX_VM == 48, "the table below has 49 entries");
+    int t = n < WL_IROWS_MAX_VM ? n : WL_IROWS_MAX_VM;
+    asm volatile(
+        "s_getpc_b64 vcc\n\t"
+        "s_lshl_b32 %0, %0, 3\n\t"
+        "s_add_u32 %0, %0, 20\n\t"
+        "s_add_u32 vcc_lo, vcc_lo, %0\n\t"
+        "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+        "s_setpc_b64 vcc\n\t"
+        "s_waitcnt vmcnt(0)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(1)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(2)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(3)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(4)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(5)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(6)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(7)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(8)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(9)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(10)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(11)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(12)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(13)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(14)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(15)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(16)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(17)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(18)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(19)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(20)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(21)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(22)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(23)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(24)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(25)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(26)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(27)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(28)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(29)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(30)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(31)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(32)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(33)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(34)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(35)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(36)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(37)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(38)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(39)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(40)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(41)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(42)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(43)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(44)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(45)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(46)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(47)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(48)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        ".Lwl_vm_end_%=:"
+        : "+s"(t) : : "memory", "vcc", "scc");
+}
+#else
+inline void wl_fail() { abort(); }
+inline void wl_wait_vm_dyn(int n) { wl_emu_wait_vm(n < WL_IROWS_MAX_VM ? n : WL_IROWS_MAX_VM); }
+#endif
+
+template <typename T, int LT>
+struct WlSfbRows {
+    typedef WlIRowsArgs<T> Args;
+    static const int kThreads = 64 * WL_IROWS_WAVES;
+    static const int kMinWaves = 7;        // two workgroups per CU: 28 waves on 4 SIMDs
+    static const int HL = LT / 2;          // taps per polyphase component = rows of the window
+    static const int WARM = HL - 1;        // feeds that only fill the window
+    static const int SZ = (int)sizeof(T);
+
+    // ---- loader wave: sources [s0, s0+ns) of level j ---------------------------------------------------------------
+    // A "step" = the next 1024-byte chunk of every source (one DMA instruction each, plus dword pieces where a plane ends
+    // off a 16-byte boundary).  A step may go out once the rows it overwrites (the previous revolution's rows under the
+    // same ring bytes) were consumed at least one half-batch ago; before a half-batch the wave waits until the steps
+    // under the rows about to be consumed have landed.
+    static WL_DEV void loader(const Args& a, const WlIRowsSeg& sg, const WlCtx& ctx, int64_t plane, int lane, int j, int s0, int ns) {
+        const WlIRowsLevel& g = a.g[j];
+        const int rb = g.rbytes, R = g.dma_rows, cpr = g.cpr;
+        const int plane_bytes = g.Kh * rb, ring_bytes = R * rb;
+        const int f0 = sg.f0[j], fend = sg.fend[j];
+        const int r0 = f0 >> g.dma_shift;                // the segment starts with the revolution that holds its first row
+        // everything a step needs sits in scalar registers: a load from the argument block per chunk would stall the wave
+        // for longer than the chunk takes
+        const char* src[4];
+        int dst[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int s = s0 + (i < ns ? i : 0);
+            src[i] = s == 0 ? reinterpret_cast<const char*>(a.yl + (size_t)plane * a.ll_ps)
+                            : reinterpret_cast<const char*>(a.yh[j] + ((size_t)plane * 3 + (s - 1)) * ((size_t)g.Kh * g.Kw));
+            dst[i] = g.src_off[s];
+        }
+        // steps (counted from the segment's first) under rows [.., k]
+        auto need = [&](int k) { return ((k >> g.dma_shift) - r0) * cpr + (((k & (R - 1)) + 1) * rb - 1) / WL_IROWS_CHUNK + 1; };
+        const int total = fend > f0 ? need(fend - 1) : 0;
+        const int max_steps = WL_IROWS_MAX_VM / ns - 1;  // in flight at once
+        const int p16 = plane_bytes & ~15, ptail = (plane_bytes & 15) / 4;   // whole 16-byte pieces; dwords behind them
+        int issued = 0, landed = 0;                      // steps issued / known to have landed
+        int r = r0, c = 0;                               // next step: revolution r, chunk c ...
+        int rbyte = 0, pbyte = r0 * ring_bytes;          // ... = ring bytes [rbyte, +1024), plane bytes [pbyte, +1024)
+        int fed = f0;
+        auto try_issue = [&]() {
+            if (issued >= total || issued - landed >= max_steps) return false;
+            const int cend = rbyte + WL_IROWS_CHUNK < ring_bytes ? rbyte + WL_IROWS_CHUNK : ring_bytes;
+            // the ring bytes it overwrites held rows of the previous revolution: all of them consumed, and not in the
+            // half-batch that is running now (rows >= fed - 2)
+            if (r != r0 && cend > (fed - 2 - (r - 1) * R) * rb) return false;
+            if (!(WL_IROWS_ABLATE & 2)) {
+                const bool whole = pbyte + 16 <= plane_bytes;                 // at least lane 0 has a whole piece
+                const bool on = rbyte + lane * 16 < ring_bytes && pbyte + lane * 16 + 16 <= plane_bytes;
+                const bool tail = ptail && p16 >= pbyte && p16 < pbyte + (cend - rbyte);   // the plane's last dwords are in this step
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i >= ns) break;
+                    if (whole) wl_dma16_s(ctx, (unsigned)(dst[i] + rbyte), src[i], (unsigned)(pbyte + lane * 16), on);
+                    if (tail) wl_dma4_s(ctx, (unsigned)(dst[i] + rbyte + (p16 - pbyte)), src[i], (unsigned)(p16 + lane * 4), lane < ptail);
+                }
+            }
+            ++issued;
+            rbyte += WL_IROWS_CHUNK; pbyte += WL_IROWS_CHUNK;
+            if (++c == cpr) { c = 0; ++r; rbyte = 0; pbyte = r * ring_bytes; }
+            return true;
+        };
+        while (try_issue()) {}
+        unsigned long long tw = 0, tb = 0, ti = 0;
+        unsigned word = sg.sched[0];
+        for (int hb = 0; hb < sg.nhb; ++hb) {
+            const unsigned long long c0 = WL_ITICK();
+            const int n = (int)(word >> (8 * (hb & 3) + 2 * j)) & 3;
+            if ((hb & 3) == 3) word = sg.sched[(hb >> 2) + 1 < WL_IROWS_MAXHB / 4 ? (hb >> 2) + 1 : 0];
+            if (n) {   // the steps under rows fed .. fed+n-1 have landed
+                const int nd = need(fed + n - 1);
+                if (issued < nd) wl_fail();   // the launcher's geometry checks rule this out
+                if (!(WL_IROWS_ABLATE & 2)) wl_wait_vm_dyn((issued - nd) * ns);
+                landed = nd;
+            }
+            const unsigned long long c1 = WL_ITICK();
+            ctx.sync();
+            const unsigned long long c2 = WL_ITICK();
+            fed += n;
+            while (try_issue()) {}
+            tw += c1 - c0; tb += c2 - c1; ti += WL_ITICK() - c2;
+        }
+        wl_wait_vm<0>();   // nothing may land after the workgroup has released its LDS
+        if ((WL_IROWS_ABLATE & 8) && lane == 0) {
+            T* o = a.y + (size_t)plane * a.g[0].OH * a.g[0].OW + 4 * (ctx.tid >> 6);
+            o[0] = (T)(float)(tw >> 6); o[1] = (T)(float)(tb >> 6); o[2] = (T)(float)(ti >> 6);
+        }
+    }
+
+    // ---- compute waves of level j -------------------------------------------------------------------------------------
+    struct __attribute__((packed, aligned(sizeof(T)), may_alias)) WlPairT { T a, b; };
+    static const int NP = (HL + 1) / 2;        // coefficient pairs a lane reads per band row
+    static const int NW = HL > 1 ? HL - 1 : 1; // rows of history in the window
+    struct Wave {                              // per-wave / per-lane constants of a compute wave
+        wl_v2 gw0[HL], gw1[HL], gh0[HL], gh1[HL];   // (g[2t], g[2t+1]) tap pairs, wave-uniform
+        int coff;                              // byte offset of this lane's first coefficient in a ring row
+        int llmask;                            // row mask of this level's low-pass source ring
+        bool two;                              // the second column of the pair exists (odd widths: not for the last pair)
+        bool odd_wave;                         // wave-uniform: some lane of this wave has !two
+        char* yp; unsigned yrowb, ycol;        // level 0: x
+        int lring, lpitch, lmask, lrows, lcol; // levels > 0: the low-pass ring of the level below
+    };
+
+    // the HL coefficients c .. c+HL-1 of one ring row as (even, odd) pairs: one ds_read2 / ds_read_b64 per pair, and the
+    // packed FMAs pick the half they need (op_sel) - no register shuffling
+    static WL_DEV void load_coeffs(const char* p, wl_v2 (&v)[NP]) {
+#pragma unroll
+        for (int i = 0; i < HL / 2; ++i)
+            v[i] = wl_v2{(float)*reinterpret_cast<const T*>(p + 2 * i * SZ), (float)*reinterpret_cast<const T*>(p + (2 * i + 1) * SZ)};
+        if (HL & 1) v[NP - 1] = wl_v2{(float)*reinterpret_cast<const T*>(p + (HL - 1) * SZ), 0.f};
+    }
+    // polyphase row synthesis of coefficient row k for this lane's column pair: a = (ll, hl) along W (the H-low
+    // intermediate), b = (lh, hh) (the H-high one); tap pair t meets coefficient c + HL-1 - t
+    static WL_DEV void row_syn(const WlIRowsLevel& g, const Wave& R, const char* smem, int k, wl_v2& na, wl_v2& nb) {
+        // (all scalar already: no readfirstlane here - it would drag the producers of its operand into vector registers)
+        const int rll = g.src_off[0] + (k & R.llmask) * g.ll_pitch;
+        const int rb = (k & (g.dma_rows - 1)) * g.rbytes;
+        wl_v2 vll[NP], vlh[NP], vhl[NP], vhh[NP];
+        load_coeffs(smem + (rll + R.coff), vll);
+        load_coeffs(smem + (g.src_off[1] + rb + R.coff), vlh);
+        load_coeffs(smem + (g.src_off[2] + rb + R.coff), vhl);
+        load_coeffs(smem + (g.src_off[3] + rb + R.coff), vhh);
+        na = wl_pk_mul_x(R.gw0[HL - 1], vll[0]);
+        nb = wl_pk_mul_x(R.gw0[HL - 1], vlh[0]);
+        wl_pk_fma_x(na, R.gw1[HL - 1], vhl[0]);
+        wl_pk_fma_x(nb, R.gw1[HL - 1], vhh[0]);
+#pragma unroll
+        for (int u = 1; u < HL; ++u) {
+            const int t = HL - 1 - u;
+            if (u & 1) {
+                wl_pk_fma_y(na, R.gw0[t], vll[u / 2]); wl_pk_fma_y(nb, R.gw0[t], vlh[u / 2]);
+                wl_pk_fma_y(na, R.gw1[t], vhl[u / 2]); wl_pk_fma_y(nb, R.gw1[t], vhh[u / 2]);
+            } else {
+                wl_pk_fma_x(na, R.gw0[t], vll[u / 2]); wl_pk_fma_x(nb, R.gw0[t], vlh[u / 2]);
+                wl_pk_fma_x(na, R.gw1[t], vhl[u / 2]); wl_pk_fma_x(nb, R.gw1[t], vhh[u / 2]);
+            }
+        }
+    }
+    // polyphase column synthesis from HL consecutive window rows e[OFF .. OFF+HL-1] (oldest first): y0 = (row m, row m+1)
+    // of column n (.x of the window pairs), y1 of column n+1 (.y)
+    template <int OFF, int NE>
+    static WL_DEV void col_syn(const Wave& R, const wl_v2 (&ea)[NE], const wl_v2 (&eb)[NE], wl_v2& y0, wl_v2& y1) {
+        y0 = wl_pk_mul_x(R.gh0[0], ea[OFF + HL - 1]); y1 = wl_pk_mul_y(R.gh0[0], ea[OFF + HL - 1]);
+        wl_pk_fma_x(y0, R.gh1[0], eb[OFF + HL - 1]);
+        wl_pk_fma_y(y1, R.gh1[0], eb[OFF + HL - 1]);
+#pragma unroll
+        for (int t = 1; t < HL; ++t) {
+            wl_pk_fma_x(y0, R.gh0[t], ea[OFF + HL - 1 - t]);
+            wl_pk_fma_y(y1, R.gh0[t], ea[OFF + HL - 1 - t]);
+            wl_pk_fma_x(y0, R.gh1[t], eb[OFF + HL - 1 - t]);
+            wl_pk_fma_y(y1, R.gh1[t], eb[OFF + HL - 1 - t]);
+        }
+    }
+    // output rows m, m+1: to x (8 contiguous bytes per lane and row), or into the low-pass ring of the level below
+    template <int j>
+    static WL_DEV void emit(const Wave& R, char* smem, int m, wl_v2 y0, wl_v2 y1) {
+        if (j == 0) {
+            // every row a level-0 feed produces is one this segment owns: its feeds start at own_lo / 2 and end with the
+            // feed that makes row own_hi - 1
+            if ((WL_IROWS_ABLATE & 1) && y0.x + y0.y + y1.x + y1.y != 1.2345e30f) return;   // keeps the arithmetic alive
+            char* r0 = R.yp + ((unsigned)m * R.yrowb + R.ycol);
+            char* r1 = r0 + R.yrowb;
+            if (!R.odd_wave) {
+                T v[2] = {(T)y0.x, (T)y1.x}, w[2] = {(T)y0.y, (T)y1.y};
+                *reinterpret_cast<WlPairT*>(r0) = *reinterpret_cast<WlPairT*>(v);
+                *reinterpret_cast<WlPairT*>(r1) = *reinterpret_cast<WlPairT*>(w);
+            } else {   // the wave that holds the last pair of an odd-width row: that lane has one column only
+                *reinterpret_cast<T*>(r0) = (T)y0.x;
+                *reinterpret_cast<T*>(r1) = (T)y0.y;
+                if (R.two) { *reinterpret_cast<T*>(r0 + SZ) = (T)y1.x; *reinterpret_cast<T*>(r1 + SZ) = (T)y1.y; }
+            }
+        } else {
+            if (m < R.lrows) {
+                T v[2] = {(T)y0.x, (T)y1.x};
+                *reinterpret_cast<WlPairT*>(smem + (R.lring + (m & R.lmask) * R.lpitch + R.lcol)) = *reinterpret_cast<WlPairT*>(v);
+            }
+            if (m + 1 < R.lrows) {
+                T v[2] = {(T)y0.y, (T)y1.y};
+                *reinterpret_cast<WlPairT*>(smem + (R.lring + ((m + 1) & R.lmask) * R.lpitch + R.lcol)) = *reinterpret_cast<WlPairT*>(v);
+            }
+        }
+    }
+
+    template <int j>
+    static WL_DEV void compute(const Args& a, const WlIRowsSeg& sg, const WlCtx& ctx, int64_t plane, int c0, int lane) {
+        const WlIRowsLevel& g = a.g[j];
+        char* const smem = ctx.smem;
+        const int c = c0 + lane;                         // column pair: output columns 2c, 2c+1
+        const bool active = 2 * c < g.OW;
+        Wave R;
+#pragma unroll
+        for (int t = 0; t < HL; ++t) {
+            R.gw0[t] = wl_uniform_v2(wl_v2{a.g_w_lo[2 * t], a.g_w_lo[2 * t + 1]});
+            R.gw1[t] = wl_uniform_v2(wl_v2{a.g_w_hi[2 * t], a.g_w_hi[2 * t + 1]});
+            R.gh0[t] = wl_uniform_v2(wl_v2{a.g_h_lo[2 * t], a.g_h_lo[2 * t + 1]});
+            R.gh1[t] = wl_uniform_v2(wl_v2{a.g_h_hi[2 * t], a.g_h_hi[2 * t + 1]});
+        }
+        R.coff = (active ? c : 0) * SZ;
+        R.llmask = g.ll_rows - 1;
+        R.two = 2 * c + 1 < g.OW;
+        R.odd_wave = wl_uniform((g.OW & 1) && 2 * (c0 + 63) + 1 >= g.OW) != 0;
+        R.yp = reinterpret_cast<char*>(a.y + (size_t)plane * g.OH * g.OW);
+        R.yrowb = (unsigned)g.OW * SZ; R.ycol = (unsigned)(2 * c) * SZ;
+        R.lmask = j > 0 ? a.g[j > 0 ? j - 1 : 0].ll_rows - 1 : 0;
+        R.lring = j > 0 ? a.g[j > 0 ? j - 1 : 0].src_off[0] : 0;
+        R.lpitch = j > 0 ? a.g[j > 0 ? j - 1 : 0].ll_pitch : 0;
+        R.lrows = j > 0 ? a.g[j > 0 ? j - 1 : 0].Kh : 0;   // rows the level below reads ('unpad': it may drop the last one)
+        R.lcol = 2 * c * SZ;
+        // window: the row-synthesised (a, b) of the previous HL-1 coefficient rows as (col n, col n+1) pairs, oldest first
+        wl_v2 wa[NW], wb[NW];
+#pragma unroll
+        for (int t = 0; t < NW; ++t) wa[t] = wb[t] = wl_v2{0.f, 0.f};
+        const int f0 = sg.f0[j];
+        int fed = f0;
+        unsigned long long tb = 0, tf = 0, c2 = WL_ITICK();
+        unsigned word = sg.sched[0];                     // the schedule of four half-batches; the next one is fetched early
+        for (int hb = 0; hb < sg.nhb; ++hb) {
+            const int n = (int)(word >> (8 * (hb & 3) + 2 * j)) & 3;
+            if ((hb & 3) == 3) word = sg.sched[(hb >> 2) + 1 < WL_IROWS_MAXHB / 4 ? (hb >> 2) + 1 : 0];
+            const unsigned long long c0 = WL_ITICK();
+            ctx.sync();
+            const unsigned long long c1 = WL_ITICK();
+            tf += c0 - c2; tb += c1 - c0; c2 = c1;
+            if (n == 0) continue;
+            const int k = fed;
+            fed += n;
+            if (!active || (WL_IROWS_ABLATE & 4)) continue;
+            const int m = 2 * (k - WARM);
+            wl_v2 y0, y1;
+            if (n == 2) {                                // two coefficient rows: one window move for both
+                wl_v2 ea[HL + 1], eb[HL + 1];
+                row_syn(g, R, smem, k, ea[HL - 1], eb[HL - 1]);
+                row_syn(g, R, smem, k + 1, ea[HL], eb[HL]);
+#pragma unroll
+                for (int t = 0; t < HL - 1; ++t) { ea[t] = wa[t]; eb[t] = wb[t]; }
+                if (k - f0 >= WARM) { col_syn<0>(R, ea, eb, y0, y1); emit<j>(R, smem, m, y0, y1); }
+                if (k + 1 - f0 >= WARM) { col_syn<1>(R, ea, eb, y0, y1); emit<j>(R, smem, m + 2, y0, y1); }
+#pragma unroll
+                for (int t = 0; t < HL - 1; ++t) { wa[t] = ea[t + 2]; wb[t] = eb[t + 2]; }
+            } else {
+                wl_v2 ea[HL], eb[HL];
+                row_syn(g, R, smem, k, ea[HL - 1], eb[HL - 1]);
+#pragma unroll
+                for (int t = 0; t < HL - 1; ++t) { ea[t] = wa[t]; eb[t] = wb[t]; }
+                if (k - f0 >= WARM) { col_syn<0>(R, ea, eb, y0, y1); emit<j>(R, smem, m, y0, y1); }
+#pragma unroll
+                for (int t = 0; t < HL - 1; ++t) { wa[t] = ea[t + 1]; wb[t] = eb[t + 1]; }
+            }
+        }
+        if ((WL_IROWS_ABLATE & 8) && lane == 0) {
+            T* o = a.y + (size_t)plane * a.g[0].OH * a.g[0].OW + 4 * (ctx.tid >> 6);
+            o[0] = (T)(float)(tb >> 6); o[1] = (T)(float)(tf >> 6); o[2] = (T)0;
+        }
+    }
+
+    static WL_DEV void run(const Args& a, const WlCtx& ctx) {
+        const int tid = ctx.tid;
+        const int wave = wl_uniform(tid >> 6), lane = tid & 63;
+        const int64_t bid = ctx.bid;
+        const int64_t plane = bid < a.nwhole ? bid : a.nwhole + (bid - a.nwhole) / 2;
+        const WlIRowsSeg& sg = a.seg[bid < a.nwhole ? 0 : 1 + (int)((bid - a.nwhole) & 1)];
+        const int lev = wl_uniform(a.role_level[wave]), arg = wl_uniform(a.role_arg[wave]);
+        if (lev == -1) {
+#if defined(__HIPCC__)
+            __builtin_amdgcn_s_setprio(3);   // its few instructions go first: every other wave waits for it at the barrier
+#endif
+            loader(a, sg, ctx, plane, lane, arg >> 4, (arg >> 2) & 3, (arg & 3) + 1);
+        }
+        else if (lev == 0) compute<0>(a, sg, ctx, plane, arg, lane);
+        else if (lev == 1) compute<1>(a, sg, ctx, plane, arg, lane);
+        else if (lev == 2) compute<2>(a, sg, ctx, plane, arg, lane);
+        else
+            for (int hb = 0; hb < sg.nhb; ++hb) ctx.sync();   // spare wave: keeps the barrier count
+    }
+};

@@ -89,6 +89,75 @@ class SFB2D(Function):
         return dlow, dhigh, None, None, None, None, None
 
 
+class SFB2DMulti(Function):
+    """All synthesis levels as ONE autograd node: ``SFB2DMulti.apply(yl, g0_row, g1_row, g0_col, g1_col, mode_int,
+    *yh) -> x`` with yh finest first, ``None`` entries = zeros (the level loop of DWTInverse.forward, reference
+    dwt/transform2d.py:131-148, incl. the 'unpad' of a low-pass one row / column larger than the next high-pass).
+
+    Forward: up to three levels at a time in ONE launch of the streaming kernel (wl_dwt2d_synthesis_fused: the
+    intermediate low-passes stay in LDS) whenever the engine takes the configuration, otherwise one tile-kernel launch
+    per level.  Backward = the chain of SFB2D.backward steps of the reference (analysis with the stored synthesis
+    taps, dwt/lowlevel.py:683-694), finest level first; a dropped row / column gets a zero gradient."""
+
+    @staticmethod
+    def forward(ctx, yl, g0_row, g1_row, g0_col, g1_col, mode, *yh):
+        _check_bank_mode(mode)
+        ctx.save_for_backward(g0_row, g1_row, g0_col, g1_col)
+        ctx.mode = mode
+        ctx.has_highs = [h is not None for h in yh]
+        J = len(yh)
+        ll_shapes = [None] * J          # the low-pass handed to level j, before the 'unpad'
+        ll, j = yl, J - 1
+        while j >= 0:
+            n = 0                       # levels j, j-1, .. that the streaming kernel can take together
+            while n < 3 and j - n >= 0 and yh[j - n] is not None:
+                n += 1
+            res = None
+            while FUSED_LEVELS and n >= 1 and res is None:
+                res = ops.sfb2d_fused(ll, list(yh[j - n + 1:j + 1]), g0_row, g1_row, g0_col, g1_col, mode)
+                if res is None:
+                    n -= 1
+            if res is not None:
+                L = g0_row.numel()
+                sh = tuple(ll.shape[-2:])
+                for i in range(j, j - n, -1):
+                    ll_shapes[i] = sh
+                    sh = (2 * yh[i].shape[-2] - L + 2, 2 * yh[i].shape[-1] - L + 2)
+                ll, j = res, j - n
+                continue
+            h = yh[j]
+            ll_shapes[j] = tuple(ll.shape[-2:])
+            if h is not None:
+                if ll.shape[-2] > h.shape[-2]:
+                    ll = ll[..., :-1, :]
+                if ll.shape[-1] > h.shape[-1]:
+                    ll = ll[..., :-1]
+            ll = ops.sfb2d(ll, h, g0_row, g1_row, g0_col, g1_col, mode)
+            j -= 1
+        ctx.ll_shapes = ll_shapes
+        return ll
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        J = len(ctx.has_highs)
+        grads = [None] * J
+        d = None
+        if any(ctx.needs_input_grad[:1]) or any(ctx.needs_input_grad[6 + j] for j in range(J)):
+            g0_row, g1_row, g0_col, g1_col = ctx.saved_tensors
+            d = dy
+            for j in range(J):
+                d, dhigh = ops.afb2d(d, g0_row, g1_row, g0_col, g1_col, ctx.mode)
+                if ctx.has_highs[j] and ctx.needs_input_grad[6 + j]:
+                    grads[j] = dhigh
+                full = ctx.ll_shapes[j]
+                if tuple(d.shape[-2:]) != full:      # the forward dropped a row / column of this low-pass
+                    d = torch.nn.functional.pad(d, (0, full[1] - d.shape[-1], 0, full[0] - d.shape[-2]))
+            if not ctx.needs_input_grad[0]:
+                d = None
+        return (d, None, None, None, None, None) + tuple(grads)
+
+
 _PAD_LL = False   # inner-level LL_j at a cache-line-aligned row pitch for the per-level path (measured neutral: off)
 
 

@@ -62,17 +62,8 @@ class DWTInverse(nn.Module):
 
     def forward(self, coeffs):
         yl, yh = coeffs
-        ll = yl
         mode = lowlevel.mode_to_int(self.mode)
-        for h in yh[::-1]:
-            if h is not None:
-                # 'unpad': drop the extra row/col an odd-sized finer level produced
-                if ll.shape[-2] > h.shape[-2]:
-                    ll = ll[..., :-1, :]
-                if ll.shape[-1] > h.shape[-1]:
-                    ll = ll[..., :-1]
-            ll = lowlevel.SFB2D.apply(ll, h, self.g0_col, self.g1_col, self.g0_row, self.g1_row, mode)
-        return ll
+        return lowlevel.SFB2DMulti.apply(yl, self.g0_col, self.g1_col, self.g0_row, self.g1_row, mode, *yh)
 
 
 class SWTForward(nn.Module):

@@ -172,6 +172,51 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=0):
     return yl, yh
 
 
+def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=0):
+    """All len(yh) (1..3) synthesis levels in ONE launch of the streaming kernel: yl (N,C,h,w) [may be a strided crop],
+    yh = [finest .. coarsest] of (N,C,3,Kh_j,Kw_j) -> x (N,C,OH,OW).  The intermediate low-passes never leave the
+    chip.  Returns None when the kernel does not cover the configuration (caller goes level by level)."""
+    import ctypes
+    _check_tensor(yl, 'yl')
+    nlev = len(yh)
+    N, C, h, w = yl.shape
+    L = g_w_lo.numel()
+    es = yl.element_size()
+    if (yl.dtype == torch.float64 or nlev < 1 or nlev > 3 or g_h_lo.numel() != L or L % 2 or L > 12 or mode == 2
+            or yl.numel() == 0 or (strips == 0 and N * C < _num_cus(yl.device)) or strips > 2
+            or any(t is None or t.dim() != 5 or t.dtype != yl.dtype or t.shape[:3] != (N, C, 3) or t.numel() == 0
+                   or (t.shape[4] * es) % 4 or (t.shape[3] * t.shape[4] * es) % 4 for t in yh)):
+        return None
+    # the low-pass source of every level is its high-pass size or one larger (then the surplus row / column is dropped)
+    sh, sw = h, w
+    for t in reversed(yh):
+        kh, kw = t.shape[3], t.shape[4]
+        if not (kh <= sh <= kh + 1 and kw <= sw <= kw + 1) or kh < L // 2 or kw < L // 2:
+            return None
+        sh, sw = 2 * kh - L + 2, 2 * kw - L + 2
+    # the kernel copies the coarsest low-pass like a band plane: dense rows of the coarsest high-pass width
+    kh, kw = yh[-1].shape[3], yh[-1].shape[4]
+    if (h, w) != (kh, kw):
+        yl = yl[..., :kh, :kw]
+    if yl.stride(3) != 1 or yl.stride(2) != kw or yl.stride(0) != C * yl.stride(1) or (yl.stride(1) * es) % 4:
+        yl = yl.contiguous()
+    yh = [t.contiguous() for t in yh]
+    for t in yh:
+        _same_device(yl, t)
+    gwl, gwh, ghl, ghh = (_taps(g, yl) for g in (g_w_lo, g_w_hi, g_h_lo, g_h_hi))
+    y = torch.empty((N, C, sh, sw), dtype=yl.dtype, device=yl.device)
+    ptrs = (ctypes.c_void_p * nlev)(*[t.data_ptr() for t in yh])
+    khs = (ctypes.c_int * nlev)(*[t.shape[3] for t in yh])
+    kws = (ctypes.c_int * nlev)(*[t.shape[4] for t in yh])
+    rc = _call('wl_dwt2d_synthesis_fused', yl, yl.data_ptr(), yl.stride(1), yl.stride(2), kh, kw, ptrs, khs, kws,
+               y.data_ptr(), _DTYPES[yl.dtype], N * C, nlev, gwl.data_ptr(), gwh.data_ptr(), ghl.data_ptr(),
+               ghh.data_ptr(), L, mode, strips, _stream(yl))
+    if rc == -3:
+        return None
+    _lib.check(rc, 'wl_dwt2d_synthesis_fused')
+    return y
+
+
 # ---------------------------------------------------------------------------------------------- single axis
 EXT_ZERO, EXT_SYM, EXT_REFL, EXT_PERIODIC, EXT_PER, EXT_REPLICATE = 0, 1, 2, 3, 4, 5
 _MODE_TO_EXT = {0: EXT_ZERO, 1: EXT_SYM, 2: EXT_PER, 4: EXT_REFL, 6: EXT_PERIODIC}

@@ -26,7 +26,7 @@ struct WlEmuBlock {
     std::vector<char> state;        // 0 ready, 1 at barrier, 2 at shuffle, 3 done
     std::vector<float> shfl_in, shfl_out;
     std::vector<int> shfl_src;      // source lane (0..63) of a pending shuffle, -1 = the lane below (wl_shfl_up1)
-    struct Dma { char* dst; const char* src; };
+    struct Dma { char* dst; const char* src; int len; };
     std::vector<std::vector<Dma> > dma;   // per lane: asynchronous global->LDS copies not yet released by wl_wait_vm
     int cur;
     WlEmuBlock() : cur(0) {}
@@ -54,13 +54,16 @@ float wl_shfl_up1(float v) { return wl_emu_shuffle(v, -1); }
 float wl_shfl(float v, int src_lane) { return wl_emu_shuffle(v, src_lane & 63); }
 
 // LDS-DMA: the copy lands only when the issuing lane's wl_wait_vm<N> releases it (oldest first)
-void wl_dma16(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on) {
+static void wl_emu_dma(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on, int len) {
     WlEmuBlock* b = wl_emu_cur_block;
     WlEmuBlock::Dma d;
-    d.dst = lane_on ? ctx.smem + lds_off + 16 * (ctx.tid & 63) : nullptr;   // off lanes keep the per-wave count
+    d.dst = lane_on ? ctx.smem + lds_off + len * (ctx.tid & 63) : nullptr;   // off lanes keep the per-wave count
     d.src = (const char*)gsrc;
+    d.len = len;
     b->dma[b->cur].push_back(d);
 }
+void wl_dma16(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on) { wl_emu_dma(ctx, lds_off, gsrc, lane_on, 16); }
+void wl_dma4(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on) { wl_emu_dma(ctx, lds_off, gsrc, lane_on, 4); }
 // The counter is per WAVE: the wait is a wave-level rendezvous (all lanes have issued the same loads; all their
 // copies have landed before any lane goes on), like the lockstep execution of the hardware.
 void wl_emu_wait_vm(int n) {
@@ -68,7 +71,7 @@ void wl_emu_wait_vm(int n) {
     wl_emu_shuffle(0.f, b->cur & 63);
     std::vector<WlEmuBlock::Dma>& q = b->dma[b->cur];
     while ((int)q.size() > n) {
-        if (q.front().dst) memcpy(q.front().dst, q.front().src, 16);
+        if (q.front().dst) memcpy(q.front().dst, q.front().src, q.front().len);
         q.erase(q.begin());
     }
     wl_emu_shuffle(0.f, b->cur & 63);

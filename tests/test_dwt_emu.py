@@ -149,6 +149,99 @@ def test_streaming_kernel_vs_oracle_random_shapes(seed):
         assert np.abs(got.float().numpy() - want).max() <= 3e-3 * np.abs(want).max()
 
 
+def _fused_inv(yl, yh, wave, mode, strips=1):
+    from pytorch_wavelets_amd import ops, filters
+    from pytorch_wavelets_amd.dwt import lowlevel
+    g0, g1 = filters.dwt_synthesis_taps(wave)
+    tg = [torch.tensor(v, dtype=torch.float32) for v in (g0, g1, g0, g1)]
+    with emu_backend.emulated():
+        return ops.sfb2d_fused(yl, yh, *tg, lowlevel.mode_to_int(mode), strips=strips)
+
+
+@pytest.mark.parametrize('strips', [1, 2])
+@pytest.mark.parametrize('name', ['dwt_00', 'dwt_01', 'dwt_02', 'dwt_04', 'dwt_05', 'dwt_06', 'dwt_08', 'dwt_09', 'dwt_10',
+                                  'dwt_12', 'dwt_13', 'dwt_14'])
+def test_streaming_synthesis_fp32_goldens_on_emulator(name, strips):
+    """The streaming multi-level synthesis kernel (wl_dwt2d_synthesis_fused: coarsest level first, the intermediate
+    low-passes in LDS rings, coefficient rows by LDS-DMA incl. dword tails of 4-byte-aligned rows, 'unpad' of odd
+    sizes) against the reference's reconstructions - incl. the benchmark geometry (dwt_02) and biorthogonal taps."""
+    meta, g = G.INDEX[name], G.load(name)
+    J = meta['J']
+    if 'yh0' in g:
+        yl, yh = g['yl'], [g['yh%d' % j] for j in range(J)]
+    else:   # the big fixture stores samples of yh0 only: coefficients from the oracle (pinned to the same fixture)
+        from oracle import wavelet_oracle as wo
+        from pytorch_wavelets_amd import filters
+        h0, h1 = filters.dwt_analysis_taps(meta['wave'])
+        yl, yh = wo.dwt_forward(g['x'].astype(np.float64), J, h0, h1, h0, h1, meta['mode'])
+    res = _fused_inv(torch.tensor(yl, dtype=torch.float32), [torch.tensor(v, dtype=torch.float32) for v in yh],
+                     meta['wave'], meta['mode'], strips)
+    assert res is not None, 'the streaming kernel was expected to cover this case'
+    assert G.relerr(res.numpy(), g, 'rec') < 1e-5
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_streaming_synthesis_vs_oracle_random_shapes(seed):
+    """Random (odd too) heights and widths, every supported tap count, fp32 and fp16, whole planes and cut planes."""
+    from oracle import wavelet_oracle as wo
+    from pytorch_wavelets_amd import filters
+    rng = np.random.RandomState(900 + seed)
+    wave = ['haar', 'db2', 'db3', 'db4', 'db5', 'db6'][seed]
+    h0, h1 = filters.dwt_analysis_taps(wave)
+    g0, g1 = filters.dwt_synthesis_taps(wave)
+    L = len(h0)
+    for mode in ('zero', 'symmetric', 'reflect', 'periodic'):
+        J = int(rng.randint(1, 4))
+        H = int(rng.randint(8 * L, 140))
+        W = int(rng.randint(8 * L, [90, 160, 300, 500][seed % 4]))
+        x = rng.randn(1, 2, H, W)
+        oyl, oyh = wo.dwt_forward(x, J, h0, h1, h0, h1, mode)
+        want = wo.dwt_inverse(oyl, oyh, g0, g1, g0, g1, mode)
+        strips = 1 + int(rng.randint(0, 2))
+        res = _fused_inv(torch.tensor(oyl, dtype=torch.float32), [torch.tensor(v, dtype=torch.float32) for v in oyh], wave, mode, strips)
+        assert res is not None, (wave, mode, H, W, J, strips)
+        assert res.shape == want.shape
+        assert np.abs(res.numpy() - want).max() <= 1e-5 * np.abs(want).max(), (wave, mode, H, W, J, strips)
+    x = rng.randn(1, 2, 64, 2 * int(rng.randint(4 * L, 100)))
+    oyl, oyh = wo.dwt_forward(x, 2, h0, h1, h0, h1, 'symmetric')
+    if all(v.shape[-1] % 2 == 0 for v in oyh):
+        want = wo.dwt_inverse(oyl, oyh, g0, g1, g0, g1, 'symmetric')
+        res = _fused_inv(torch.tensor(oyl).half(), [torch.tensor(v).half() for v in oyh], wave, 'symmetric')
+        assert res is not None
+        assert np.abs(res.float().numpy() - want).max() <= 4e-3 * np.abs(want).max()
+
+
+def test_inverse_module_takes_streaming_kernel_and_matches_per_level(monkeypatch):
+    """DWTInverse (fp32, different row / column filter banks, odd sizes -> 'unpad' between levels, J = 4 -> a fused
+    group of three + one more level): the streaming path and the per-level tile path agree, forward and gradients."""
+    from pytorch_wavelets_amd.dwt import lowlevel
+    from pytorch_wavelets_amd import filters
+    torch.set_default_dtype(torch.float32)
+    rng = np.random.RandomState(77)
+    (ch0, ch1), (rh0, rh1) = filters.dwt_analysis_taps('db3'), filters.dwt_analysis_taps('sym3')
+    (cg0, cg1), (rg0, rg1) = filters.dwt_synthesis_taps('db3'), filters.dwt_synthesis_taps('sym3')
+    xfm = pw.DWTForward(J=4, wave=tuple(v[::-1].copy() for v in (ch0, ch1, rh0, rh1)), mode='symmetric')   # dec_* as pywt stores them
+    ifm = pw.DWTInverse(wave=(cg0, cg1, rg0, rg1), mode='symmetric')
+    x = torch.tensor(rng.randn(1, 2, 150, 171), dtype=torch.float32)
+    gy = torch.tensor(rng.randn(1, 2, 150, 172), dtype=torch.float32)
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(lowlevel, 'FUSED_LEVELS', fused)
+        with emu_backend.emulated():
+            yl, yh = xfm(x)
+            leaves = [yl.detach().requires_grad_(True)] + [h.detach().requires_grad_(True) for h in yh]
+            rec = ifm((leaves[0], leaves[1:]))
+            kernel = emu_backend.handle().wl_last_kernel().decode()
+            grads = torch.autograd.grad((rec * gy[..., :rec.shape[-2], :rec.shape[-1]]).sum(), leaves)
+        out[fused] = (rec.detach(), grads, kernel)
+    assert 'WlSfbRows' in out[True][2] and 'WlSfbRows' not in out[False][2]
+    assert out[True][0].shape == out[False][0].shape
+    assert (out[True][0][..., :150, :171] - x).abs().max() < 1e-4
+    assert (out[True][0] - out[False][0]).abs().max() < 1e-5 * out[False][0].abs().max()
+    for a, b in zip(out[True][1], out[False][1]):
+        assert a.shape == b.shape and (a - b).abs().max() <= 1e-5 * b.abs().max()
+
+
 @pytest.mark.parametrize('name', ['dwt_01', 'dwt_03', 'dwt_06', 'dwt_07', 'dwt_08', 'dwt_14', 'dwt_15'])
 def test_tile_kernels_fp32_on_emulator(name):
     """float32 modules take the specialised tile kernels (float64 above takes the generic ones)."""

@@ -273,6 +273,61 @@ def test_fused_levels_equal_per_level_launches_full_size(monkeypatch):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
 
 
+@pytest.mark.parametrize('wave,mode,J,shape', [
+    ('db4', 'symmetric', 3, (2, 2, 200, 136)), ('db2', 'zero', 3, (1, 3, 97, 203)), ('db3', 'reflect', 2, (1, 2, 131, 80)),
+    ('db4', 'periodic', 1, (1, 2, 112, 66)), ('haar', 'zero', 3, (1, 2, 64, 512)), ('db5', 'symmetric', 3, (3, 1, 301, 512)),
+    ('db6', 'symmetric', 1, (1, 2, 90, 1000)),
+])
+def test_streaming_synthesis_vs_oracle(wave, mode, J, shape):
+    """The streaming multi-level synthesis kernel through its C-ABI entry point (forced: strips = 1 / 2): chunked
+    LDS-DMA of whole band planes incl. the dword tail of planes that end off a 16-byte boundary, counted waits through
+    the jump table, the low-pass rings between the levels, the 'unpad' of odd sizes."""
+    from pytorch_wavelets_amd import ops
+    rng = np.random.RandomState(11)
+    x = rng.randn(*shape)
+    h0, h1 = F.dwt_analysis_taps(wave)
+    g0, g1 = F.dwt_synthesis_taps(wave)
+    tg = [torch.tensor(v, dtype=torch.float32, device=DEV) for v in (g0, g1, g0, g1)]
+    oyl, oyh = wo.dwt_forward(x, J, h0, h1, h0, h1, mode)
+    want = wo.dwt_inverse(oyl, oyh, g0, g1, g0, g1, mode)
+    yl = torch.tensor(oyl, dtype=torch.float32, device=DEV)
+    yh = [torch.tensor(v, dtype=torch.float32, device=DEV) for v in oyh]
+    for strips in (1, 2):
+        got = ops.sfb2d_fused(yl, yh, *tg, lowlevel.mode_to_int(mode), strips=strips)
+        assert got is not None
+        assert got.shape == want.shape and rel(got, want) < TOL
+    if all(v.shape[-1] % 2 == 0 for v in oyh):   # float16 storage, fp32 accumulate
+        got = ops.sfb2d_fused(yl.half(), [v.half() for v in yh], *tg, lowlevel.mode_to_int(mode), strips=1)
+        assert got is not None
+        wanth = wo.dwt_inverse(yl.half().double().cpu().numpy(), [v.half().double().cpu().numpy() for v in yh], g0, g1, g0, g1, mode)
+        assert rel(got.float(), wanth) < 3e-3
+
+
+def test_fused_inverse_equals_per_level_launches_full_size(monkeypatch):
+    """BASELINE configs[1] shape, inverse: the module's default path (one streaming launch for the three levels)
+    against one tile-kernel launch per level, the kernel the engine reports for each, perfect reconstruction, and
+    the gradients of both paths."""
+    from pytorch_wavelets_amd import _lib
+    torch.manual_seed(7)
+    x = torch.randn(128, 3, 512, 512, device=DEV)
+    xfm = pw.DWTForward(J=3, wave='db4', mode='symmetric').to(DEV)
+    ifm = pw.DWTInverse(wave='db4', mode='symmetric').to(DEV)
+    yl, yh = xfm(x)
+    leaves = [yl.detach().requires_grad_(True)] + [h.detach().requires_grad_(True) for h in yh]
+    rec = ifm((leaves[0], leaves[1:]))
+    assert 'WlSfbRows' in _lib.get().wl_last_kernel().decode()
+    assert float((rec - x).abs().max()) < 1e-4
+    gy = torch.randn_like(rec)
+    g1 = torch.autograd.grad((rec * gy).sum(), leaves)
+    monkeypatch.setattr(lowlevel, 'FUSED_LEVELS', False)
+    rec2 = ifm((leaves[0], leaves[1:]))
+    assert 'WlSfbTile' in _lib.get().wl_last_kernel().decode()
+    assert float((rec - rec2).abs().max()) <= 2e-6 * float(rec2.abs().max())
+    g2 = torch.autograd.grad((rec2 * gy).sum(), leaves)
+    for a, b in zip(g1, g2):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+
+
 def test_function_level_api():
     """afb2d / sfb2d function forms (reference dwt/lowlevel.py:427-472, :600-644)."""
     torch.manual_seed(4)
