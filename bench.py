@@ -233,11 +233,14 @@ def main():
     fwd_bytes = algorithmic_bytes_fwd(N, C, H, W, J, 8, 4)
     fwd_gbs = fwd_bytes / (fwd_ms * 1e-3) / 1e9
     inv_gbs = fwd_bytes / (inv_ms * 1e-3) / 1e9
-    # the same forward as one tile-kernel launch per level (the round-1 path), for the record
+    inv_fused = 'WlSfbRows' in inv_kernel
+    # the same transforms as one tile-kernel launch per level (the round-1 path), for the record
     with torch.no_grad():
         _ll.FUSED_LEVELS = False
         tile_ms = timer.run(lambda: xfm(x), args.steps)
         tile_kernel = _kernel_name(lib)
+        inv_tile_ms = timer.run(lambda: ifm((yl, yh)), args.steps)
+        inv_tile_kernel = _kernel_name(lib)
         _ll.FUSED_LEVELS = True
     # what a plain device copy of the same footprint achieves on this box (read + write bytes / time)
     with torch.no_grad():
@@ -306,7 +309,8 @@ def main():
                        'global_batch': world * N, 'parallelism': 'batch-sharded x%d, no data-path collective' % world,
                        'fwd_path': ('one launch of the streaming kernel for all %d levels (LL_j in LDS)' % J) if fused
                                    else 'one tile-kernel launch per level',
-                       'inv_path': 'one polyphase tile-kernel launch per level'},
+                       'inv_path': ('one launch of the streaming kernel for all %d levels (low-passes in LDS)' % J) if inv_fused
+                                   else 'one polyphase tile-kernel launch per level'},
             'roofline': {'bound': 'hbm', 'kernel': fwd_kernel + (' (all %d levels, one launch)' % J if fused else ' (last level)'),
                          'achieved': round(fwd_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(fwd_gbs / HBM_PEAK_GBS, 4), 'traffic': traffic,
@@ -315,9 +319,14 @@ def main():
                          'device_copy_gbs': round(copy_gbs, 1), 'frac_of_device_copy': round(fwd_gbs / copy_gbs, 4),
                          'forward_per_level_tile_kernels': {'kernel': tile_kernel, 'avg_ms': round(tile_ms, 4),
                                                             'frac': round(fwd_bytes / (tile_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                         'inverse': {'kernel': inv_kernel, 'achieved': round(inv_gbs, 1),
+                         'inverse': {'kernel': inv_kernel + (' (all %d levels, one launch)' % J if inv_fused else ' (last level)'),
+                                     'achieved': round(inv_gbs, 1),
                                      'frac': round(inv_gbs / HBM_PEAK_GBS, 4), 'avg_ms': round(inv_ms, 4),
-                                     'launches_per_inverse': J}},
+                                     'frac_of_device_copy': round(inv_gbs / copy_gbs, 4),
+                                     'launches_per_inverse': 1 if inv_fused else J,
+                                     'inverse_per_level_tile_kernels': {
+                                         'kernel': inv_tile_kernel, 'avg_ms': round(inv_tile_ms, 4),
+                                         'frac': round(fwd_bytes / (inv_tile_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}},
             'fwd_mpix_s': round(N * C * H * W / (fwd_ms * 1e-3) / 1e6, 1),
             'inv_mpix_s': round(N * C * H * W / (inv_ms * 1e-3) / 1e6, 1),
             'roundtrip_rel_err': err,
