@@ -282,7 +282,7 @@ def main():
                 'last_fwd_kernel': hk}
             del xh, hyl, hyh
     # HBM traffic of the dominant kernel: only from a PMC summary measured on THIS build of the sources
-    traffic = None
+    traffic = inv_traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'r02_hbm_traffic.json')
     if os.path.exists(tpath) and not emu:
         try:
@@ -291,8 +291,10 @@ def main():
                 for k, v in tj.get('kernels', {}).items():   # rocprof prints defaulted template arguments too
                     if k.strip().startswith(fwd_kernel.rstrip('>')):
                         traffic = v.get('hbm_bytes_corrected')
+                    if k.strip().startswith(inv_kernel.rstrip('>')):
+                        inv_traffic = v.get('hbm_bytes_corrected')
         except Exception:
-            traffic = None
+            traffic = inv_traffic = None
 
     if rank == 0:
         pixels = world * N * C * H * W
@@ -322,7 +324,7 @@ def main():
                          'inverse': {'kernel': inv_kernel + (' (all %d levels, one launch)' % J if inv_fused else ' (last level)'),
                                      'achieved': round(inv_gbs, 1),
                                      'frac': round(inv_gbs / HBM_PEAK_GBS, 4), 'avg_ms': round(inv_ms, 4),
-                                     'frac_of_device_copy': round(inv_gbs / copy_gbs, 4),
+                                     'frac_of_device_copy': round(inv_gbs / copy_gbs, 4), 'traffic': inv_traffic,
                                      'launches_per_inverse': 1 if inv_fused else J,
                                      'inverse_per_level_tile_kernels': {
                                          'kernel': inv_tile_kernel, 'avg_ms': round(inv_tile_ms, 4),
