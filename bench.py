@@ -86,7 +86,7 @@ def cpu_baseline(args):
            'host_cores': ncores, 'mpix_s_by_torch_threads': tried,
            'sample': 'oracle/torch_cpu.py (the reference\'s conv2d / conv_transpose2d formulation on PyTorch-CPU, fp32), '
                      'fwd+inv J=3 db4 symmetric on %dx3x512x512, %d reps at the best thread count; the real reference '
-                     'measured 16.2 Mpixels/s on 8 vCPU in the authoring container (BASELINE.md)' % (n, best[2])}
+                     'measured 23.0 Mpixels/s on the 8 vCPU of the authoring container with this torch build (profiles/r02_reference_cpu_timing.json; BASELINE.md quotes 16.2 for an older torch)' % (n, best[2])}
     try:
         from oracle import dwt_port
         rng = np.random.RandomState(0)
