@@ -110,6 +110,17 @@ int wl_dwt2d_synthesis_fused(const void* yl, int64_t yl_plane_stride, int yl_row
                              int64_t planes, int nlev, const void* g_w_lo, const void* g_w_hi,
                              const void* g_h_lo, const void* g_h_hi, int L, int mode, int strips, void* stream);
 
+/* Non-separable one-level analysis / synthesis with four Ly x Lx point-spread functions = afb2d_nonsep
+ * (dwt/lowlevel.py:524-597) / sfb2d_nonsep (:746-798).  `f` / `g`: (4, Ly, Lx) device taps in the accumulate dtype,
+ * exactly what prep_filt_afb2d_nonsep (already mirrored) / prep_filt_sfb2d_nonsep return.  Analysis: x (planes,H,W)
+ * -> y (planes,4,Kh,Kw), K = wl_dwt_coeff_len; modes zero / symmetric / reflect / periodization (WL_ERR_MODE for
+ * 'periodic', as upstream).  Synthesis: coeffs (planes,4,Kh,Kw) -> y (planes,OH,OW), OH/OW <= the natural size (a
+ * crop).  Direct evaluation, one thread per output sample: completes the function-level API, not a tuned path. */
+int wl_dwt2d_analysis_nonsep(const void* x, void* y, int dtype, int64_t planes, int H, int W, const void* f,
+                             int Ly, int Lx, int mode, void* stream);
+int wl_dwt2d_synthesis_nonsep(const void* coeffs, void* y, int dtype, int64_t planes, int Kh, int Kw, int OH,
+                              int OW, const void* g, int Ly, int Lx, int mode, void* stream);
+
 /* ---- DTCWT (filters = the reference's stored buffers: reversed columns, dtcwt/lowlevel.py:58-67) ------------ */
 
 /* Level-1 forward = FWD_J1.forward -> fwd_j1 (dtcwt/transform_funcs.py:98-121, :346-358): 2 rowfilter +

@@ -682,3 +682,66 @@ def scat_layer_j2_forward(x, h0o, h1o, h0a, h0b, h1a, h1b, magbias=1e-2, combine
         return np.concatenate([s0, s1p, s1_j2[:, :, 0], s2_j1.reshape(n, 36, h, w)], axis=1)
     Z = np.concatenate([s0[:, None], s1p.reshape(n, 6, p[2], h, w), s1_j2, s2_j1.reshape(n, 36, p[2], h, w)], axis=1)
     return Z.reshape(n, 49 * p[2], h, w)
+
+
+# ----------------------------------------------------------------------------------------------
+# non-separable one-level banks (dwt/lowlevel.py:524-597, :746-798)
+# ----------------------------------------------------------------------------------------------
+def afb2d_nonsep(x, filts, mode='zero'):
+    """x (N,C,H,W), filts (4,Ly,Lx) = the mirrored point-spread functions of prep_filt_afb2d_nonsep (:801-833) ->
+    (N, 4C, H', W'), channel 4c+b.  The strided conv2d of :558-591 as a direct sum:
+    zero / symmetric / reflect: y[b][i][j] = sum f[b][u][v] ext(x)[2i-(Ly-2)+u][2j-(Lx-2)+v] (p//2 = L-2 for every N, L);
+    periodization: xe = x with the last row / column repeated for odd sizes (:559-564), rolled by ceil(L/2) (:567),
+    zero-padded conv with padding L-1 and ONE fold of the first L//2 outputs (:568-570)."""
+    x = np.asarray(x, dtype=np.float64)
+    f = np.asarray(filts, dtype=np.float64).reshape(4, filts.shape[-2], filts.shape[-1])
+    N, C, H, W = x.shape
+    Ly, Lx = f.shape[1], f.shape[2]
+    if mode in ('per', 'periodization'):
+        if H % 2:
+            x = np.concatenate((x, x[:, :, -1:]), axis=2)
+        if W % 2:
+            x = np.concatenate((x, x[:, :, :, -1:]), axis=3)
+        He, We = x.shape[2], x.shape[3]
+        xr = np.roll(np.roll(x, -((Ly + 1) // 2), axis=2), -((Lx + 1) // 2), axis=3)
+        Ky, Kx = (He + Ly - 2) // 2 + 1, (We + Lx - 2) // 2 + 1
+        xp = np.zeros((N, C, He + 2 * (Ly - 1), We + 2 * (Lx - 1)))
+        xp[:, :, Ly - 1:Ly - 1 + He, Lx - 1:Lx - 1 + We] = xr
+        y = np.zeros((N, C, 4, Ky, Kx))
+        for u in range(Ly):
+            for v in range(Lx):
+                y += f[None, None, :, u, v, None, None] * xp[:, :, None, u:u + 2 * Ky:2, v:v + 2 * Kx:2]
+        y[:, :, :, :Ly // 2] += y[:, :, :, He // 2:He // 2 + Ly // 2]
+        y[:, :, :, :, :Lx // 2] += y[:, :, :, :, We // 2:We // 2 + Lx // 2]
+        y = y[:, :, :, :He // 2, :We // 2]
+    elif mode in ('zero', 'symmetric', 'reflect'):
+        Ky, Kx = dwt_coeff_len(H, Ly, mode), dwt_coeff_len(W, Lx, mode)
+        y = np.zeros((N, C, 4, Ky, Kx))
+        for u in range(Ly):
+            rows = _take_ext(x, 2 * np.arange(Ky) - (Ly - 2) + u, mode, 2)
+            for v in range(Lx):
+                y += f[None, None, :, u, v, None, None] * _take_ext(rows, 2 * np.arange(Kx) - (Lx - 2) + v, mode, 3)[:, :, None]
+    else:
+        raise ValueError("Unkown pad type: {}".format(mode))
+    return y.reshape(N, 4 * C, y.shape[-2], y.shape[-1])
+
+
+def sfb2d_nonsep(coeffs, filts, mode='zero'):
+    """coeffs (N,C,4,H,W), filts (4,Ly,Lx) = prep_filt_sfb2d_nonsep (:836-867) -> (N,C,2H-Ly+2,2W-Lx+2), periodization
+    (N,C,2H,2W): the conv_transpose2d of :784-796 as a direct sum (full[P][Q] = sum c[i][j] g[P-2i][Q-2j])."""
+    c = np.asarray(coeffs, dtype=np.float64)
+    g = np.asarray(filts, dtype=np.float64).reshape(4, filts.shape[-2], filts.shape[-1])
+    N, C, _, Ny, Nx = c.shape
+    Ly, Lx = g.shape[1], g.shape[2]
+    full = np.zeros((N, C, 2 * Ny + Ly - 2, 2 * Nx + Lx - 2))
+    for u in range(Ly):
+        for v in range(Lx):
+            full[:, :, u:u + 2 * Ny:2, v:v + 2 * Nx:2] += np.einsum('b,ncbij->ncij', g[:, u, v], c)
+    if mode in ('per', 'periodization'):
+        full[:, :, :Ly - 2] += full[:, :, 2 * Ny:2 * Ny + Ly - 2]
+        full[:, :, :, :Lx - 2] += full[:, :, :, 2 * Nx:2 * Nx + Lx - 2]
+        full = full[:, :, :2 * Ny, :2 * Nx]
+        return np.roll(np.roll(full, 1 - Ly // 2, axis=2), 1 - Lx // 2, axis=3)
+    if mode in ('zero', 'symmetric', 'reflect', 'periodic'):
+        return full[:, :, Ly - 2:2 * Ny, Lx - 2:2 * Nx]
+    raise ValueError("Unkown pad type: {}".format(mode))

@@ -320,6 +320,105 @@ def afb2d_atrous(x, filts, mode='periodization', dilation=1):
     return afb1d_atrous(lohi, h0_col, h1_col, mode=mode, dim=2, dilation=dilation)
 
 
+def prep_filt_afb2d_nonsep(h0_col, h1_col, h0_row=None, h1_row=None, device=None):
+    """The four 2-D point-spread functions (ll, lh, hl, hh) of an analysis bank as a (4, 1, Ly, Lx) tensor, mirrored for
+    cross-correlation (reference dwt/lowlevel.py:801-833)."""
+    h0_col = np.array(h0_col).ravel()
+    h1_col = np.array(h1_col).ravel()
+    h0_row = h0_col if h0_row is None else np.array(h0_row).ravel()
+    h1_row = h1_col if h1_row is None else np.array(h1_row).ravel()
+    psf = [np.outer(c, r)[::-1, ::-1] for c, r in ((h0_col, h0_row), (h1_col, h0_row), (h0_col, h1_row), (h1_col, h1_row))]
+    return torch.tensor(np.stack(psf)[:, None].copy(), dtype=torch.get_default_dtype(), device=device)
+
+
+def prep_filt_sfb2d_nonsep(g0_col, g1_col, g0_row=None, g1_row=None, device=None):
+    """The four 2-D point-spread functions of a synthesis bank as a (4, 1, Ly, Lx) tensor, not mirrored (reference
+    dwt/lowlevel.py:836-867)."""
+    g0_col = np.array(g0_col).ravel()
+    g1_col = np.array(g1_col).ravel()
+    g0_row = g0_col if g0_row is None else np.array(g0_row).ravel()
+    g1_row = g1_col if g1_row is None else np.array(g1_row).ravel()
+    psf = [np.outer(c, r) for c, r in ((g0_col, g0_row), (g1_col, g0_row), (g0_col, g1_row), (g1_col, g1_row))]
+    return torch.tensor(np.stack(psf)[:, None], dtype=torch.get_default_dtype(), device=device)
+
+
+class _AFB2DNonsep(Function):
+    """afb2d_nonsep as an autograd node.  Backward = the adjoint, evaluated by the synthesis kernel with the same
+    (mirrored) point-spread functions: exact where the forward has no mirrored samples (zero, periodization)."""
+
+    @staticmethod
+    def forward(ctx, x, filts, mode):
+        ctx.save_for_backward(filts)
+        ctx.mode, ctx.shape = mode, tuple(x.shape)
+        return ops.afb2d_nonsep(x, filts, mode)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.mode not in (0, 2):
+                raise NotImplementedError('gradient of afb2d_nonsep: zero and periodization modes only')
+            filts, = ctx.saved_tensors
+            N, C, H, W = ctx.shape
+            dx = ops.sfb2d_nonsep(dy, filts, ctx.mode, out_hw=(H + (H & 1), W + (W & 1)) if ctx.mode == 2 else (H, W))
+            if ctx.mode == 2 and (H & 1 or W & 1):   # the repeated last row / column of an odd size
+                if H & 1:
+                    dx = torch.cat((dx[:, :, :H - 1], dx[:, :, H - 1:H] + dx[:, :, H:H + 1]), dim=2)
+                if W & 1:
+                    dx = torch.cat((dx[..., :W - 1], dx[..., W - 1:W] + dx[..., W:W + 1]), dim=3)
+        return dx, None, None
+
+
+class _SFB2DNonsep(Function):
+    """sfb2d_nonsep as an autograd node.  Backward = analysis with the same point-spread functions (the synthesis has
+    no boundary extension, so this is the exact adjoint for the non-periodization modes; periodization: circular)."""
+
+    @staticmethod
+    def forward(ctx, coeffs, filts, mode):
+        ctx.save_for_backward(filts)
+        ctx.mode, ctx.shape = mode, tuple(coeffs.shape)
+        return ops.sfb2d_nonsep(coeffs, filts, mode)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dc = None
+        if ctx.needs_input_grad[0]:
+            filts, = ctx.saved_tensors
+            # dc[b][i][j] = sum_{p,q} dy[p][q] g[b][p + s - 2i][q + s - 2j]: a correlation of dy with g at offset -s
+            # = afb2d_nonsep(dy, g) with zero (non-periodization) / periodic extension; for periodization the analysis
+            # kernel's offset is that of the mirrored bank, so mirror g and shift by one period where needed
+            if ctx.mode == 2:
+                raise NotImplementedError('gradient of sfb2d_nonsep: not for periodization')
+            dc = ops.afb2d_nonsep(dy, filts, 0).reshape(ctx.shape)
+        return dc, None, None
+
+
+def afb2d_nonsep(x, filts, mode='zero'):
+    """One analysis level WITHOUT separate row and column filtering (reference dwt/lowlevel.py:524-597): ``filts`` =
+    the (4,1,Ly,Lx) tensor of prep_filt_afb2d_nonsep, or a 2- / 4-tuple of 1-D banks.  Returns (N, 4C, H', W').
+    'zero', 'symmetric', 'reflect', 'periodization' ('periodic' raises, as upstream)."""
+    if isinstance(filts, (tuple, list)):
+        filts = prep_filt_afb2d_nonsep(*filts, device=x.device)
+    if mode not in ('zero', 'symmetric', 'reflect', 'periodization', 'per'):
+        raise ValueError("Unkown pad type: {}".format(mode))
+    return _AFB2DNonsep.apply(x, filts, mode_to_int(mode))
+
+
+def sfb2d_nonsep(coeffs, filts, mode='zero'):
+    """One synthesis level without separable filtering (reference dwt/lowlevel.py:746-798): coeffs (N,C,4,H,W) ->
+    (N,C,2H-Ly+2,2W-Lx+2) (periodization: (N,C,2H,2W)); ``filts`` = the tensor of prep_filt_sfb2d_nonsep or a 2- /
+    4-tuple of 1-D banks."""
+    if isinstance(filts, (tuple, list)):
+        if len(filts) not in (2, 4):
+            raise ValueError("Unkown form for input filts")
+        filts = prep_filt_sfb2d_nonsep(*filts, device=coeffs.device)
+    if mode not in ('zero', 'symmetric', 'reflect', 'periodic', 'periodization', 'per'):
+        raise ValueError("Unkown pad type: {}".format(mode))
+    return _SFB2DNonsep.apply(coeffs, filts, mode_to_int(mode))
+
+
 def afb2d(x, filts, mode='zero'):
     """Function-level analysis (reference dwt/lowlevel.py:427-472): ``filts`` is a 2- or 4-tuple
     of arrays / tensors (h0_col, h1_col[, h0_row, h1_row]); here the *col* pair really filters

@@ -217,6 +217,53 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=0):
     return y
 
 
+def afb2d_nonsep(x, filts, mode):
+    """One non-separable analysis level: x (N,C,H,W), filts (4,1,Ly,Lx) point-spread functions as
+    prep_filt_afb2d_nonsep builds them -> y (N,4C,Kh,Kw), channel 4c+b (reference dwt/lowlevel.py:524-597)."""
+    _check_tensor(x, 'x')
+    if filts.dim() != 4 or filts.shape[0] != 4 or filts.shape[1] != 1:
+        raise ValueError('filts must be a (4, 1, Ly, Lx) tensor, got %s' % (tuple(filts.shape),))
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    Ly, Lx = filts.shape[2], filts.shape[3]
+    f = _taps(filts, x)
+    y = torch.empty((N, 4 * C, coeff_len(H, Ly, mode), coeff_len(W, Lx, mode)), dtype=x.dtype, device=x.device)
+    if x.numel():
+        rc = _call('wl_dwt2d_analysis_nonsep', x, x.data_ptr(), y.data_ptr(), _DTYPES[x.dtype], N * C, H, W,
+                   f.data_ptr(), Ly, Lx, mode, _stream(x))
+        _lib.check(rc, 'wl_dwt2d_analysis_nonsep')
+    return y
+
+
+def sfb2d_nonsep(coeffs, filts, mode, out_hw=None):
+    """One non-separable synthesis level: coeffs (N,C,4,Kh,Kw) [or (N,4C,Kh,Kw)], filts (4,1,Ly,Lx) as
+    prep_filt_sfb2d_nonsep builds them -> y (N,C,OH,OW) (reference dwt/lowlevel.py:746-798); out_hw crops."""
+    _check_tensor(coeffs, 'coeffs')
+    if filts.dim() != 4 or filts.shape[0] != 4 or filts.shape[1] != 1:
+        raise ValueError('filts must be a (4, 1, Ly, Lx) tensor, got %s' % (tuple(filts.shape),))
+    if coeffs.dim() == 5:
+        if coeffs.shape[2] != 4:
+            raise ValueError('coeffs must be (N, C, 4, H, W), got %s' % (tuple(coeffs.shape),))
+        N, C, _, Kh, Kw = coeffs.shape
+    else:
+        if coeffs.dim() != 4 or coeffs.shape[1] % 4:
+            raise ValueError('coeffs must be (N, C, 4, H, W) or (N, 4C, H, W), got %s' % (tuple(coeffs.shape),))
+        N, C, Kh, Kw = coeffs.shape[0], coeffs.shape[1] // 4, coeffs.shape[2], coeffs.shape[3]
+    coeffs = coeffs.contiguous()
+    Ly, Lx = filts.shape[2], filts.shape[3]
+    g = _taps(filts, coeffs)
+    OH = 2 * Kh if mode == 2 else 2 * Kh - Ly + 2
+    OW = 2 * Kw if mode == 2 else 2 * Kw - Lx + 2
+    if out_hw is not None:
+        OH, OW = min(OH, out_hw[0]), min(OW, out_hw[1])
+    y = torch.empty((N, C, OH, OW), dtype=coeffs.dtype, device=coeffs.device)
+    if coeffs.numel():
+        rc = _call('wl_dwt2d_synthesis_nonsep', coeffs, coeffs.data_ptr(), y.data_ptr(), _DTYPES[coeffs.dtype], N * C,
+                   Kh, Kw, OH, OW, g.data_ptr(), Ly, Lx, mode, _stream(coeffs))
+        _lib.check(rc, 'wl_dwt2d_synthesis_nonsep')
+    return y
+
+
 # ---------------------------------------------------------------------------------------------- single axis
 EXT_ZERO, EXT_SYM, EXT_REFL, EXT_PERIODIC, EXT_PER, EXT_REPLICATE = 0, 1, 2, 3, 4, 5
 _MODE_TO_EXT = {0: EXT_ZERO, 1: EXT_SYM, 2: EXT_PER, 4: EXT_REFL, 6: EXT_PERIODIC}

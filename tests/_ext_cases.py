@@ -139,3 +139,49 @@ DWT1D_CASES = sorted(k for k, v in G.INDEX.items() if v['kind'] == 'dwt1d')
 SWT_CASES = sorted(k for k, v in G.INDEX.items() if v['kind'] == 'swt')
 SCATJ2_CASES = sorted(k for k, v in G.INDEX.items() if v['kind'] == 'scatj2')
 ROT_CASES = sorted(k for k, v in G.INDEX.items() if v['kind'] == 'rot')
+
+
+NONSEP_CASES = sorted(k for k, v in G.INDEX.items() if v['kind'] == 'nonsep')
+
+
+def check_nonsep(name, dev, dtype, tol):
+    """afb2d_nonsep / sfb2d_nonsep (+ their prep_filt functions) against the reference's outputs and against the
+    gradients autograd gives upstream (zero / periodization for the analysis, all non-periodization modes for the
+    synthesis; the other gradients raise)."""
+    import pytest
+    meta, g = G.INDEX[name], G.load(name)
+    mode = meta['mode']
+    fa, fs = _t(g['fa'], dev, dtype), _t(g['fs'], dev, dtype)
+    wcol, wrow = meta['wave']
+    if wcol != 'random':   # the prep functions build the same point-spread functions as upstream
+        wc = filters.Wavelet(wcol)
+        wr = filters.Wavelet(wrow) if wrow else wc
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float64)
+        try:
+            pa = dwl.prep_filt_afb2d_nonsep(wc.dec_lo, wc.dec_hi, wr.dec_lo, wr.dec_hi)
+            ps = dwl.prep_filt_sfb2d_nonsep(wc.rec_lo, wc.rec_hi, wr.rec_lo, wr.rec_hi)
+        finally:
+            torch.set_default_dtype(prev)
+        assert pa.shape == fa.shape and np.abs(pa.numpy() - g['fa']).max() < 1e-6
+        assert ps.shape == fs.shape and np.abs(ps.numpy() - g['fs']).max() < 1e-6
+    if mode == 'periodic':
+        with pytest.raises(ValueError, match='Unkown pad type'):
+            dwl.afb2d_nonsep(_t(g['x'], dev, dtype), fa, mode)
+    else:
+        x = _t(g['x'], dev, dtype).requires_grad_(True)
+        y = dwl.afb2d_nonsep(x, fa, mode)
+        assert G.relerr(y.detach().cpu().numpy(), g, 'y') < tol
+        loss = (y * _t(g['gy'], dev, dtype)).sum()
+        if mode in ('zero', 'periodization'):
+            dx, = torch.autograd.grad(loss, x)
+            assert G.relerr(dx.cpu().numpy(), g, 'dx') < tol
+        else:
+            with pytest.raises(NotImplementedError):
+                torch.autograd.grad(loss, x)
+    c = _t(g['c'], dev, dtype).requires_grad_(True)
+    rec = dwl.sfb2d_nonsep(c, fs, mode)
+    assert G.relerr(rec.detach().cpu().numpy(), g, 'rec') < tol
+    if mode != 'periodization':
+        dc, = torch.autograd.grad((rec * _t(g['gr'], dev, dtype)).sum(), c)
+        assert G.relerr(dc.cpu().numpy(), g, 'dc') < tol

@@ -44,6 +44,21 @@ def test_swt_second_level_is_the_dilated_bank_on_ll_and_bad_modes_raise():
     assert np.abs(y[0].numpy() - o1).max() < 1e-12 and np.abs(y[1].numpy() - o2).max() < 1e-12
 
 
+@pytest.mark.parametrize('name', E.NONSEP_CASES)
+def test_nonseparable_banks(name):
+    with emu_backend.emulated():
+        E.check_nonsep(name, 'cpu', torch.float64, 5e-7)
+        E.check_nonsep(name, 'cpu', torch.float32, 1e-5)
+
+
+def test_oracle_nonseparable_vs_reference_goldens():
+    for name in E.NONSEP_CASES:
+        meta, g = G.INDEX[name], G.load(name)
+        if meta['mode'] != 'periodic':
+            assert G.relerr(wo.afb2d_nonsep(g['x'].astype(np.float64), g['fa'].astype(np.float64), meta['mode']), g, 'y') < 5e-6
+        assert G.relerr(wo.sfb2d_nonsep(g['c'].astype(np.float64), g['fs'].astype(np.float64), meta['mode']), g, 'rec') < 5e-6
+
+
 def test_dtcwt_primitives():
     with emu_backend.emulated():
         E.check_prims('cpu', torch.float64, 5e-7)

@@ -22,6 +22,29 @@ def test_swt_level_and_dilated_bank(name):
     E.check_swt(name, DEV, torch.float32, 1e-5)
 
 
+@pytest.mark.parametrize('name', E.NONSEP_CASES)
+def test_nonseparable_banks(name):
+    E.check_nonsep(name, DEV, torch.float32, 1e-5)
+    E.check_nonsep(name, DEV, torch.float64, 5e-7)
+
+
+def test_nonseparable_equals_separable_at_size():
+    """afb2d_nonsep with the outer-product point-spread functions of db4 == the separable analysis kernel, and
+    sfb2d_nonsep inverts it, on a 2x3x256x320 batch (symmetric)."""
+    import pytorch_wavelets_amd as pw
+    from pytorch_wavelets_amd import filters
+    from pytorch_wavelets_amd.dwt import lowlevel as dwl
+    w = filters.Wavelet('db4')
+    x = torch.randn(2, 3, 256, 320, device=DEV)
+    y = dwl.afb2d_nonsep(x, (w.dec_lo, w.dec_hi), 'symmetric')
+    yl, yh = pw.DWTForward(J=1, wave='db4', mode='symmetric').to(DEV)(x)
+    y5 = y.reshape(2, 3, 4, y.shape[-2], y.shape[-1])
+    assert float((y5[:, :, 0] - yl).abs().max()) < 1e-5 * float(yl.abs().max())
+    assert float((y5[:, :, 1:] - yh[0]).abs().max()) < 1e-5 * float(yh[0].abs().max())
+    rec = dwl.sfb2d_nonsep(y5, (w.rec_lo, w.rec_hi), 'symmetric')
+    assert float((rec[..., :256, :320] - x).abs().max()) < 1e-4
+
+
 def test_dtcwt_primitives():
     E.check_prims(DEV, torch.float32, 1e-5)
     E.check_prims(DEV, torch.float64, 5e-7)
