@@ -251,7 +251,7 @@ struct WlSfbRows {
                 landed = nd;
             }
             const unsigned long long c1 = WL_ITICK();
-            ctx.sync();
+            if (!(WL_IROWS_ABLATE & 64) || !(hb & 1)) ctx.sync();
             const unsigned long long c2 = WL_ITICK();
             fed += n;
             while (try_issue()) {}
@@ -395,7 +395,7 @@ struct WlSfbRows {
             const int n = (int)(word >> (8 * (hb & 3) + 2 * j)) & 3;
             if ((hb & 3) == 3) word = sg.sched[(hb >> 2) + 1 < WL_IROWS_MAXHB / 4 ? (hb >> 2) + 1 : 0];
             const unsigned long long c0 = WL_ITICK();
-            ctx.sync();
+            if (!(WL_IROWS_ABLATE & 64) || !(hb & 1)) ctx.sync();
             const unsigned long long c1 = WL_ITICK();
             tf += c0 - c2; tb += c1 - c0; c2 = c1;
             if (n == 0) continue;
@@ -447,6 +447,6 @@ struct WlSfbRows {
         else if (lev == 1) compute<1>(a, sg, ctx, plane, arg, lane);
         else if (lev == 2) compute<2>(a, sg, ctx, plane, arg, lane);
         else
-            for (int hb = 0; hb < sg.nhb; ++hb) ctx.sync();   // spare wave: keeps the barrier count
+            for (int hb = 0; hb < sg.nhb; ++hb) if (!(WL_IROWS_ABLATE & 64) || !(hb & 1)) ctx.sync();   // spare wave: keeps the barrier count
     }
 };

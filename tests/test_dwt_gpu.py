@@ -316,7 +316,7 @@ def test_fused_inverse_equals_per_level_launches_full_size(monkeypatch):
     leaves = [yl.detach().requires_grad_(True)] + [h.detach().requires_grad_(True) for h in yh]
     rec = ifm((leaves[0], leaves[1:]))
     assert 'WlSfbRows' in _lib.get().wl_last_kernel().decode()
-    assert float((rec - x).abs().max()) < 1e-4
+    assert float((rec.detach() - x).abs().max()) < 1e-4
     gy = torch.randn_like(rec)
     g1 = torch.autograd.grad((rec * gy).sum(), leaves)
     monkeypatch.setattr(lowlevel, 'FUSED_LEVELS', False)
@@ -326,6 +326,62 @@ def test_fused_inverse_equals_per_level_launches_full_size(monkeypatch):
     g2 = torch.autograd.grad((rec2 * gy).sum(), leaves)
     for a, b in zip(g1, g2):
         assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+
+
+@pytest.mark.parametrize('wave,mode,J,shape', [('db2', 'zero', 5, (64, 4, 256, 192)), ('db3', 'reflect', 4, (86, 3, 200, 136)),
+                                               ('db5', 'symmetric', 4, (32, 8, 333, 160))])
+def test_modules_deep_pyramids_streaming_vs_per_level(wave, mode, J, shape, monkeypatch):
+    """J > 3 with enough planes for the streaming kernels: the forward runs levels 1-3 in one launch and the rest in
+    another, the inverse the coarsest three first; both must equal the per-level tile path (odd sizes: 'unpad' between
+    the launches and inside them), values and gradients."""
+    from pytorch_wavelets_amd import _lib
+    torch.manual_seed(8)
+    x = torch.randn(*shape, device=DEV, requires_grad=True)
+    xfm = pw.DWTForward(J=J, wave=wave, mode=mode).to(DEV)
+    ifm = pw.DWTInverse(wave=wave, mode=mode).to(DEV)
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(lowlevel, 'FUSED_LEVELS', fused)
+        yl, yh = xfm(x)
+        kf = _lib.get().wl_last_kernel().decode()
+        rec = ifm((yl, yh))
+        ki = _lib.get().wl_last_kernel().decode()
+        gx, = torch.autograd.grad((rec * torch.cos(rec)).sum(), x)
+        out[fused] = ([yl] + list(yh) + [rec, gx], kf, ki)
+    # (the forward's last launch is its coarsest group, which may be too small for the streaming kernel; the inverse's
+    # last launch is the finest group)
+    assert 'WlSfbRows' in out[True][2]
+    assert 'Rows' not in out[False][1] and 'Rows' not in out[False][2]
+    for a, b in zip(out[True][0], out[False][0]):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    rec = out[True][0][-2]
+    assert float((rec[..., :shape[2], :shape[3]] - x).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize('shape,wave,J', [((2, 2, 1200, 96), 'db4', 2), ((1, 3, 64, 1200), 'db2', 1), ((3, 1, 24, 40), 'haar', 2),
+                                         ((1, 2, 2300, 64), 'db3', 3)])
+def test_streaming_kernels_at_the_edges_of_their_envelope(shape, wave, J):
+    """Tall planes (long schedules), rows near the width limit, tiny planes (deep DMA rings): either the engine takes the
+    case and it matches the oracle, or it declines (None) and the caller falls back - never a wrong answer."""
+    from pytorch_wavelets_amd import ops
+    rng = np.random.RandomState(12)
+    x = rng.randn(*shape)
+    h0, h1 = F.dwt_analysis_taps(wave)
+    g0, g1 = F.dwt_synthesis_taps(wave)
+    th = [torch.tensor(v, dtype=torch.float32, device=DEV) for v in (h0, h1, h0, h1)]
+    tg = [torch.tensor(v, dtype=torch.float32, device=DEV) for v in (g0, g1, g0, g1)]
+    oyl, oyh = wo.dwt_forward(x, J, h0, h1, h0, h1, 'symmetric')
+    want = wo.dwt_inverse(oyl, oyh, g0, g1, g0, g1, 'symmetric')
+    if shape[-1] % 4 == 0:
+        res = ops.afb2d_fused(torch.tensor(x, dtype=torch.float32, device=DEV), *th, 1, J, strips=1)
+        if res is not None:
+            assert rel(res[0], oyl) < TOL and all(rel(a, b) < TOL for a, b in zip(res[1], oyh))
+    yl = torch.tensor(oyl, dtype=torch.float32, device=DEV)
+    yh = [torch.tensor(v, dtype=torch.float32, device=DEV) for v in oyh]
+    for strips in (1, 2):
+        got = ops.sfb2d_fused(yl, yh, *tg, 1, strips=strips)
+        if got is not None:
+            assert got.shape == want.shape and rel(got, want) < TOL
 
 
 def test_function_level_api():
