@@ -46,7 +46,7 @@ template <typename T, int LT, int TH_ = 16, int TW_ = 64, int SH_ = 0, int V4_ =
 struct WlAfbTile {
     typedef WlAfbTileArgs<T> Args;
     static const int kThreads = 256;
-    static const int kMinWaves = 3;
+    static const int kMinWaves = LT >= 20 ? 2 : 3;   // 20-tap windows need more than 168 registers (spilled at 3 waves)
     static const int TH = TH_, TW = TW_;
     static const int NROWS = 2 * TH + LT - 2;            // staged input rows
     static const int NCOLS = 2 * TW + LT - 2;            // staged input cols actually needed
