@@ -169,7 +169,8 @@ class AFB2DMulti(Function):
     in LDS) whenever the engine takes the configuration - enough planes to fill the chip, even tap count <= 12,
     16-byte rows - otherwise one specialised tile-kernel launch per level (generic kernel for unusual tap counts /
     float64).  Backward = the chain of J AFB2D.backward steps of the reference (synthesis with the stored analysis
-    taps + crop, dwt/lowlevel.py:350-365), coarsest level first."""
+    taps + crop, dwt/lowlevel.py:350-365), coarsest level first - which is an inverse transform with the analysis taps,
+    so it runs on the streaming synthesis kernel too (the crops are its 'unpad')."""
 
     @staticmethod
     def forward(ctx, x, h0_row, h1_row, h0_col, h1_col, mode, J):
@@ -200,9 +201,27 @@ class AFB2DMulti(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             h0_row, h1_row, h0_col, h1_col = ctx.saved_tensors
-            dx = dyl
-            for j in range(len(dyh) - 1, -1, -1):
+            dx, j = dyl, len(dyh) - 1
+            while j >= 0:
+                # the crop to the input size of each level is the 'unpad' of the inverse transform: up to three levels
+                # in one launch of the streaming synthesis kernel, the last crop as a view
+                n = min(3, j + 1)
+                res = None
+                while FUSED_LEVELS and n >= 1 and res is None:
+                    grp = list(dyh[j - n + 1:j + 1])
+                    ok = all(g is not None for g in grp)
+                    res = ops.sfb2d_fused(dx, grp, h0_row, h1_row, h0_col, h1_col, ctx.mode) if ok else None
+                    if res is None:
+                        n -= 1
+                if res is not None:
+                    j -= n
+                    H, W = ctx.shapes[j + 1]
+                    dx = res[..., :H, :W]
+                    continue
                 dx = ops.sfb2d(dx, dyh[j], h0_row, h1_row, h0_col, h1_col, ctx.mode, out_hw=ctx.shapes[j])
+                j -= 1
+            if not dx.is_contiguous():
+                dx = dx.contiguous()
         return dx, None, None, None, None, None, None
 
 

@@ -228,13 +228,18 @@ def test_inverse_module_takes_streaming_kernel_and_matches_per_level(monkeypatch
     for fused in (True, False):
         monkeypatch.setattr(lowlevel, 'FUSED_LEVELS', fused)
         with emu_backend.emulated():
-            yl, yh = xfm(x)
+            xg = x.clone().requires_grad_(True)
+            yl, yh = xfm(xg)
+            # the forward transform's backward = an inverse transform with the analysis taps (streaming kernel too)
+            dxf, = torch.autograd.grad(sum((t * torch.sin(t)).sum() for t in [yl] + list(yh)), xg)
+            kbwd = emu_backend.handle().wl_last_kernel().decode()
             leaves = [yl.detach().requires_grad_(True)] + [h.detach().requires_grad_(True) for h in yh]
             rec = ifm((leaves[0], leaves[1:]))
             kernel = emu_backend.handle().wl_last_kernel().decode()
             grads = torch.autograd.grad((rec * gy[..., :rec.shape[-2], :rec.shape[-1]]).sum(), leaves)
-        out[fused] = (rec.detach(), grads, kernel)
+        out[fused] = (rec.detach(), list(grads) + [dxf], kernel, kbwd)
     assert 'WlSfbRows' in out[True][2] and 'WlSfbRows' not in out[False][2]
+    assert 'WlSfbRows' in out[True][3] and 'WlSfbRows' not in out[False][3]
     assert out[True][0].shape == out[False][0].shape
     assert (out[True][0][..., :150, :171] - x).abs().max() < 1e-4
     assert (out[True][0] - out[False][0]).abs().max() < 1e-5 * out[False][0].abs().max()
