@@ -167,7 +167,7 @@ def main():
                 self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
         def run(self, fn, n):
-            for _ in range(1 if emu else 10):
+            for _ in range(1 if emu else 60):   # long enough for the clocks to settle on the new load pattern
                 fn()
             sync()
             if emu:
@@ -230,10 +230,34 @@ def main():
     with torch.no_grad():
         yl, yh = xfm(x)
         fwd_launches = 0
-        fwd_ms = timer.run(lambda: xfm(x), args.steps)
-        fwd_kernel = _kernel_name(lib)
-        inv_ms = timer.run(lambda: ifm((yl, yh)), args.steps)
-        inv_kernel = _kernel_name(lib)
+        # Per-kernel durations are taken LIVE in the step loop (the same alternating forward / inverse stream as the timed
+        # region, K more steps right behind it), HIP events around each transform on the launch stream: a loop of one
+        # kernel alone measures the power-management transient of a changed load pattern, not the kernel (rocprofv3
+        # trace of this command: the same launch takes 170 us in the step loop and 205-213 us in the first 30 launches
+        # of a forward-only loop).  The launch is asynchronous and far shorter on the host than on the GPU, so the
+        # stream never runs dry between the events.
+        if emu:
+            fwd_ms = timer.run(lambda: xfm(x), args.steps)
+            fwd_kernel = _kernel_name(lib)
+            inv_ms = timer.run(lambda: ifm((yl, yh)), args.steps)
+            inv_kernel = _kernel_name(lib)
+        else:
+            for _ in range(10):
+                step()
+            ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+            for k in range(args.steps):
+                ev[k][0].record()
+                a_, b_ = xfm(x)
+                if k == 0:
+                    fwd_kernel = _kernel_name(lib)
+                ev[k][1].record()
+                ifm((a_, b_))
+                if k == 0:
+                    inv_kernel = _kernel_name(lib)
+                ev[k][2].record()
+            torch.cuda.synchronize()
+            fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
+            inv_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
     from pytorch_wavelets_amd.dwt import lowlevel as _ll
     fused = 'WlAfbRows' in fwd_kernel
     fwd_launches = 1 if fused else J
@@ -321,6 +345,9 @@ def main():
                        'inv_path': ('one launch of the streaming kernel for all %d levels (low-passes in LDS)' % J) if inv_fused
                                    else 'one polyphase tile-kernel launch per level'},
             'roofline': {'bound': 'hbm', 'kernel': fwd_kernel + (' (all %d levels, one launch)' % J if fused else ' (last level)'),
+                         'how_timed': 'HIP events around each transform inside %d further steps of the same forward/inverse '
+                                      'stream (launches serialised by the events; in the free-running timed region consecutive '
+                                      'launches overlap their tails, so ms_per_step < forward + inverse)' % args.steps,
                          'achieved': round(fwd_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(fwd_gbs / HBM_PEAK_GBS, 4), 'traffic': traffic,
                          'algorithmic_bytes_per_launch': fwd_bytes, 'avg_launch_ms': round(fwd_ms, 4),
