@@ -49,6 +49,7 @@ float wl_shfl(float v, int src_lane);
 
 struct __attribute__((may_alias)) alignas(16) wl_f4 { float x, y, z, w; };
 struct __attribute__((may_alias)) alignas(8) wl_f2 { float x, y; };
+typedef float wl_vf4 __attribute__((ext_vector_type(4), may_alias));   // one 16-byte LDS / global access, never split
 typedef float wl_v2 __attribute__((ext_vector_type(2)));   // (low-band, high-band) pair: one v_pk_fma_f32 per tap
 
 struct WlCtx {

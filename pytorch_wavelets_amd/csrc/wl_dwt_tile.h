@@ -46,7 +46,8 @@ template <typename T, int LT, int TH_ = 16, int TW_ = 64, int SH_ = 0, int V4_ =
 struct WlAfbTile {
     typedef WlAfbTileArgs<T> Args;
     static const int kThreads = 256;
-    static const int kMinWaves = LT >= 20 ? 2 : 3;   // 20-tap windows need more than 168 registers (spilled at 3 waves)
+    // long windows need more than the 168 registers of three waves per SIMD (they spilled)
+    static const int kMinWaves = (LT >= 20 || (LT >= 16 && sizeof(T) == 4)) ? 2 : 3;
     static const int TH = TH_, TW = TW_;
     static const int NROWS = 2 * TH + LT - 2;            // staged input rows
     static const int NCOLS = 2 * TW + LT - 2;            // staged input cols actually needed
@@ -216,10 +217,10 @@ struct WlAfbTile {
             for (int j = 0; j < LT; ++j) { tw[j].x = tl[2 * j]; tw[j].y = tl[2 * j + 1]; }
             auto row_item = [&](int i, int q) {
                 float v[NV * 4];
-                const wl_f4* s4 = reinterpret_cast<const wl_f4*>(S + i * SP) + q;
+                const wl_vf4* s4 = reinterpret_cast<const wl_vf4*>(S + i * SP) + q;
 #pragma unroll
                 for (int u = 0; u < NV; ++u) {
-                    const wl_f4 t = s4[u];
+                    const wl_vf4 t = s4[u];
                     v[4 * u] = t.x; v[4 * u + 1] = t.y; v[4 * u + 2] = t.z; v[4 * u + 3] = t.w;
                 }
                 wl_v2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
@@ -263,7 +264,8 @@ struct WlAfbTile {
                 const float* col = Tm + (2 * kh) * TP + 4 * q;
 #pragma unroll
                 for (int j = 0; j < LT; ++j) {
-                    const wl_f4 p = *reinterpret_cast<const wl_f4*>(col + j * TP);
+                    const wl_vf4 p = *reinterpret_cast<const wl_vf4*>(col + j * TP);   // one 128-bit load (a struct of four floats is
+                                                                                       // split and re-paired into 8-byte reads with a 2-way bank conflict)
                     cl0 += th[j] * p.x; ch0 += th[j] * p.y;
                     cl1 += th[j] * p.z; ch1 += th[j] * p.w;
                 }

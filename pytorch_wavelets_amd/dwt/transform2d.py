@@ -63,6 +63,8 @@ class DWTInverse(nn.Module):
     def forward(self, coeffs):
         yl, yh = coeffs
         mode = lowlevel.mode_to_int(self.mode)
+        if len(yh) == 0:
+            return yl
         return lowlevel.SFB2DMulti.apply(yl, self.g0_col, self.g1_col, self.g0_row, self.g1_row, mode, *yh)
 
 

@@ -19,7 +19,7 @@ res = {'lib': os.environ.get('WL_LIB')}
 with torch.no_grad():
     for dt, name in ((torch.float32, 'f32'), (torch.float16, 'f16')):
         x = torch.randn(64, 3, 512, 512, device=dev).to(dt)
-        for wave in ('db8', 'db10'):
+        for wave in ('db4', 'db8', 'db10'):
             for mode in ('symmetric', 'periodization'):
                 fx = pw.DWTForward(J=1, wave=wave, mode=mode).to(dev).to(dt)
                 ix = pw.DWTInverse(wave=wave, mode=mode).to(dev).to(dt)
