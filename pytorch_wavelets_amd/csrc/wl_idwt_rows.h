@@ -1,13 +1,14 @@
 // Streaming multi-level 2-D DWT synthesis: the mirror image of wl_dwt_rows.h.  One workgroup owns one (n,c) plane (or
 // the top / bottom half of one) and marches down it, coarsest level first:
-//   * every coefficient row of yl / yh[j] is read from HBM exactly once by LDS-DMA (global_load_lds: one 16-byte piece
-//     per lane plus a dword tail, band rows are only 4-byte aligned) into small per-band LDS rings, D feeds ahead;
+//   * every coefficient of yl / yh[j] is read from HBM exactly once by LDS-DMA (global_load_lds) into small per-band
+//     LDS rings: a band plane is contiguous, so it is copied in whole 1024-byte chunks that ignore the row boundaries
+//     (band rows are only 4-byte aligned and 1036 bytes long at the benchmark size), a few rows ahead of their use;
 //   * a lane owns one PAIR of output columns (2c, 2c+1) of its level.  Per new coefficient row k ("feed") it runs the
 //     polyphase row synthesis  (a,b)[n..n+1] = sum_t (ll|hl, lh|hh)[c + L/2-1 - t] * (g[2t], g[2t+1])  straight from the
 //     rings, pushes the result into an L/2-row window in registers and - once the window is full - the polyphase
 //     column synthesis of output rows 2(k - (L-2)/2) and the one below: v_pk_fma_f32 on (even,odd) tap pairs with the
 //     broadcast sample picked by op_sel.  No zero stuffing, no transposed convolution, no boundary handling at all
-//     (every sample a valid lane reads exists; the window starts as zeros = the coefficients above the plane);
+//     (every sample a valid lane reads exists);
 //   * the output rows of level j+1 (= LL_j) go to an LDS ring that the waves of level j consume; LL_1 .. LL_{J-1}
 //     never touch HBM.  HBM traffic = yl, yh[j] in + x out = the algorithmic minimum of SURVEY.md 8(d);
 //   * x leaves as 8 contiguous bytes per lane, whole rows written by consecutive lanes of consecutive waves.
@@ -27,7 +28,7 @@
 #define WL_IROWS_MAXHB 640
 #ifndef WL_IROWS_ABLATE
 #define WL_IROWS_ABLATE 0       // measurement builds only (tools/build_ab.sh): 1 no global stores, 2 no DMA, 4 no arithmetic,
-#endif                          // 8 per-wave cycle counters into row 0 of x, 16 / 32 no loads of level 0 / levels > 0
+#endif                          // 8 per-wave cycle counters into row 0 of x, 64 a barrier in every other half-batch only
 #if (WL_IROWS_ABLATE & 8) && defined(__HIPCC__)
 #define WL_ITICK() __builtin_readcyclecounter()
 #else
@@ -41,7 +42,7 @@ struct WlIRowsLevel {
     int OH, OW;         // output rows / cols = 2K - L + 2
     int src_off[4];     // LDS byte offsets of the four source rings: [0] = LL, [1..3] = lh, hl, hh
     int ll_rows;        // rows of the low-pass ring (power of two, row k in k & (rows - 1)): chosen by the launcher when
-    int ll_pitch;       // level j+1 writes it (pitch padded to 16 bytes), = dma_rows / rbytes when it arrives by DMA
+    int ll_pitch;       // level j+1 writes it (pitch padded to 16 bytes); = dma_rows and rbytes when it arrives by DMA
     // DMA rings are flat images of dma_rows consecutive coefficient rows (row k at (k & (dma_rows - 1)) * rbytes, no
     // padding): a band plane is contiguous in HBM, so the loader copies it in whole 1024-byte chunks that ignore the
     // row boundaries - an LDS-DMA instruction costs the CU the same ~64 cycles whether it moves 4 bytes or 1024
