@@ -87,7 +87,9 @@ int wl_dwt2d_synthesis(const void* ll, int64_t ll_plane_stride, int ll_row_strid
  * HBM traffic is the algorithmic minimum.  `yh` is a HOST array of nlev device pointers.  Same taps (even length
  * L <= 12) on both axes of every level, F32/F16 data, float taps; rows of 16-byte multiples up to ~630 outputs wide;
  * zero / symmetric / reflect for nlev > 1, any mode for nlev == 1.  `strips`: 0 = let the engine decide (it declines
- * when there are fewer planes than compute units), 1 = force this kernel.  Returns WL_ERR_UNSUPPORTED outside the
+ * below about 3/8 as many planes as compute units, where the tile kernels win; with fewer planes than compute units it
+ * cuts planes in two so that every workgroup has a compute unit of its own), 1 = force this kernel, whole planes,
+ * 2 = force, every plane cut in two.  Returns WL_ERR_UNSUPPORTED outside the
  * kernel's envelope: the caller then uses wl_dwt2d_analysis level by level. */
 int wl_dwt2d_analysis_fused(const void* x, void* yl, void* const* yh, int dtype, int64_t planes, int H,
                             int W, int nlev, const void* h_w_lo, const void* h_w_hi, const void* h_h_lo,

@@ -153,7 +153,7 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=0):
     # the launcher's envelope, checked here first so that a decline costs no allocation
     if (x.dtype == torch.float64 or nlev < 1 or nlev > 3 or h_h_lo.numel() != L or L % 2 or L > 12
             or (W * x.element_size()) % 16 or (nlev > 1 and mode not in (0, 1, 4)) or x.numel() == 0
-            or (strips == 0 and N * C < _num_cus(x.device)) or strips > 2):
+            or (strips == 0 and 8 * N * C < 3 * _num_cus(x.device)) or strips > 2):
         return None
     x = x.contiguous()
     hwl, hwh, hhl, hhh = (_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi))
@@ -183,7 +183,7 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=0):
     L = g_w_lo.numel()
     es = yl.element_size()
     if (yl.dtype == torch.float64 or nlev < 1 or nlev > 3 or g_h_lo.numel() != L or L % 2 or L > 12 or mode == 2
-            or yl.numel() == 0 or (strips == 0 and N * C < _num_cus(yl.device)) or strips > 2
+            or yl.numel() == 0 or (strips == 0 and 8 * N * C < 3 * _num_cus(yl.device)) or strips > 2
             or any(t is None or t.dim() != 5 or t.dtype != yl.dtype or t.shape[:3] != (N, C, 3) or t.numel() == 0
                    or (t.shape[4] * es) % 4 or (t.shape[3] * t.shape[4] * es) % 4 for t in yh)):
         return None

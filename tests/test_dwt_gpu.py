@@ -384,6 +384,26 @@ def test_streaming_kernels_at_the_edges_of_their_envelope(shape, wave, J):
             assert got.shape == want.shape and rel(got, want) < TOL
 
 
+@pytest.mark.parametrize('planes', [100, 150, 250])
+def test_fewer_planes_than_compute_units_take_the_streaming_kernels(planes):
+    """Between 96 and 256 planes the engine gives every workgroup a compute unit of its own: all planes cut in two (<= 128
+    planes), a mix of whole and cut planes (the plane -> workgroup map with nwhole > 0 and ncut > 0), or whole planes."""
+    from pytorch_wavelets_amd import _lib
+    rng = np.random.RandomState(planes)
+    x = rng.randn(planes, 1, 96, 128)
+    h0, h1 = F.dwt_analysis_taps('db3')
+    g0, g1 = F.dwt_synthesis_taps('db3')
+    oyl, oyh = wo.dwt_forward(x, 2, h0, h1, h0, h1, 'symmetric')
+    orec = wo.dwt_inverse(oyl, oyh, g0, g1, g0, g1, 'symmetric')
+    xfm = pw.DWTForward(J=2, wave='db3', mode='symmetric').to(DEV)
+    ifm = pw.DWTInverse(wave='db3', mode='symmetric').to(DEV)
+    yl, yh = xfm(torch.tensor(x, dtype=torch.float32, device=DEV))
+    assert 'WlAfbRows' in _lib.get().wl_last_kernel().decode()
+    rec = ifm((yl, yh))
+    assert 'WlSfbRows' in _lib.get().wl_last_kernel().decode()
+    assert rel(yl, oyl) < TOL and all(rel(a, b) < TOL for a, b in zip(yh, oyh)) and rel(rec, orec) < TOL
+
+
 def test_function_level_api():
     """afb2d / sfb2d function forms (reference dwt/lowlevel.py:427-472, :600-644)."""
     torch.manual_seed(4)
