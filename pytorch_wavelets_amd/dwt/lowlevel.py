@@ -180,7 +180,11 @@ class AFB2DMulti(Function):
         shapes, yh, ll, done = [], [], x, 0
         while done < J:
             n = min(3, J - done)
-            res = ops.afb2d_fused(ll, h0_row, h1_row, h0_col, h1_col, mode, n) if FUSED_LEVELS else None
+            res = None
+            while FUSED_LEVELS and n >= 1 and res is None:   # e.g. periodization: one level per streaming launch
+                res = ops.afb2d_fused(ll, h0_row, h1_row, h0_col, h1_col, mode, n)
+                if res is None:
+                    n -= 1
             if res is None:
                 n = 1
                 shapes.append(tuple(ll.shape[-2:]))

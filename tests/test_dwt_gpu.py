@@ -404,6 +404,25 @@ def test_fewer_planes_than_compute_units_take_the_streaming_kernels(planes):
     assert rel(yl, oyl) < TOL and all(rel(a, b) < TOL for a, b in zip(yh, oyh)) and rel(rec, orec) < TOL
 
 
+@pytest.mark.parametrize('wave,mode', [('db3', 'periodization'), ('db5', 'periodization'), ('haar', 'periodization'),
+                                       ('db4', 'periodization'), ('db3', 'periodic'), ('db4', 'periodic')])
+def test_periodic_modes_level_by_level_on_the_streaming_kernel(wave, mode):
+    """periodization / periodic with many planes: the streaming analysis kernel takes one level per launch (its rings
+    cannot wrap a plane around), or declines (db4 periodization: odd filter-bank offset) and the tile kernels run; the
+    inverse goes level by level on the tile kernels (periodization) or fused (periodic).  Values against the oracle."""
+    rng = np.random.RandomState(31)
+    x = rng.randn(130, 1, 80, 96)
+    h0, h1 = F.dwt_analysis_taps(wave)
+    g0, g1 = F.dwt_synthesis_taps(wave)
+    oyl, oyh = wo.dwt_forward(x, 3, h0, h1, h0, h1, mode)
+    orec = wo.dwt_inverse(oyl, oyh, g0, g1, g0, g1, mode)
+    xfm = pw.DWTForward(J=3, wave=wave, mode=mode).to(DEV)
+    ifm = pw.DWTInverse(wave=wave, mode=mode).to(DEV)
+    yl, yh = xfm(torch.tensor(x, dtype=torch.float32, device=DEV))
+    rec = ifm((yl, yh))
+    assert rel(yl, oyl) < TOL and all(rel(a, b) < TOL for a, b in zip(yh, oyh)) and rel(rec, orec) < TOL
+
+
 def test_function_level_api():
     """afb2d / sfb2d function forms (reference dwt/lowlevel.py:427-472, :600-644)."""
     torch.manual_seed(4)
