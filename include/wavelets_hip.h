@@ -174,11 +174,23 @@ int wl_scat_bwd_level1(const void* dz, const void* drdx, const void* drdy, void*
                        int H, int W, const void* h0, int L0, const void* h1, int L1, int mode, int combine_colour,
                        void* stream);
 
+/* Gradients of the two non-separable banks, as autograd gives them upstream (where afb2d_nonsep / sfb2d_nonsep are
+ * plain differentiable ATen chains, dwt/lowlevel.py:524-597, :746-798):
+ *   wl_dwt2d_analysis_nonsep_bwd : dy (planes,4,Kh,Kw) -> dx (planes,H,W), the adjoint of the boundary gather + strided
+ *       correlation in every mode (mirrored / wrapped / repeated samples fold their gradient back onto their source);
+ *   wl_dwt2d_synthesis_nonsep_bwd: dy (planes,OH,OW) [OH = 2Kh-Ly+2, periodization 2Kh] -> dc (planes,4,Kh,Kw). */
+int wl_dwt2d_analysis_nonsep_bwd(const void* dy, void* dx, int dtype, int64_t planes, int H, int W, const void* f,
+                                 int Ly, int Lx, int mode, void* stream);
+int wl_dwt2d_synthesis_nonsep_bwd(const void* dy, void* dc, int dtype, int64_t planes, int Kh, int Kw, const void* g,
+                                  int Ly, int Lx, int mode, void* stream);
+
 /* ---- single-axis building blocks -------------------------------------------------------------------------------
  * One strided / dilated correlation with boundary extension along the middle axis of a dense (outer, n, inner) tensor:
  *   y[o, out_offset + out_stride*k, i] = sum_{t<ntaps} h[tap_offset + tap_stride*t] * ext(x[o,:,i], start + step*k + tap_step*t)
  * for k in [0,K); y index = o*y_outer_stride + q*inner + i.  h1/y1 (nullable) = a second tap set / output on the same
- * samples.  `ext`: 0 zero, 1 symmetric (half-sample), 2 reflect (whole-sample), 3 periodic, 4 periodization, 5 replicate.
+ * samples.  `ext`: 0 zero, 1 symmetric (half-sample), 2 reflect (whole-sample), 3 periodic, 4 periodization, 5 replicate,
+ * 6 periodization exactly as the reference evaluates it (roll, zero-padded strided convolution, ONE fold of the wrapped tail,
+ * dwt/lowlevel.py:134-150; differs from 4 when the signal is shorter than the filter; step 2, tap_step 1, start 1-ntaps).
  * Replaces the ATen bodies of afb1d on one axis (AFB1D.forward, dwt/lowlevel.py:368-407 -> :91-172), afb1d_atrous
  * (:175-223) and the DTCWT primitives colfilter / rowfilter / coldfilt / rowdfilt / colifilt / rowifilt
  * (dtcwt/lowlevel.py:70-239), each of which is one to four such correlations. */

@@ -106,7 +106,8 @@ def afb1d(x, h0, h1, mode='zero', axis=-1):
       non-periodization (:151-170):  K=(N+L-1)//2, p=2(K-1)-N+L,
           y_b[k] = sum_m u_b[m] * ext_mode(x, 2k + (L-1-p//2) - m),     k in [0,K)
       periodization (:134-150):      xe = x (+ last sample repeated if N odd), Ne=len(xe),
-          xr[i] = xe[(i+L//2) mod Ne]  (roll by -L//2),  xr0 = xr zero-extended,
+          xr[i] = xe[(i+S) mod Ne], S = L//2 (roll by -L//2; the reference's roll(), :9-25, is two slices and
+          degenerates into the identity once L//2 >= 2 Ne: S = 0 there),  xr0 = xr zero-extended,
           f[k]  = sum_m u_b[m] * xr0[2k-m],  k in [0, Ne/2+L//2)
           y_b[k] = f[k] + (f[k+Ne/2] if k < L//2 else 0),                k in [0,Ne/2)
     """
@@ -125,7 +126,7 @@ def afb1d(x, h0, h1, mode='zero', axis=-1):
             N += 1
         L2 = L // 2
         N2 = N // 2
-        xr = np.take(x, np.mod(np.arange(N) + L2, N), axis=axis)
+        xr = np.take(x, np.mod(np.arange(N) + (L2 if L2 < 2 * N else 0), N), axis=axis)
         nfull = N2 + L2
         k = np.arange(nfull)
         for u in (u0, u1):
@@ -160,7 +161,7 @@ def sfb1d(lo, hi, g0, g1, mode='zero', axis=-1):
       full[n] = sum_k lo[k] g0[n-2k] + hi[k] g1[n-2k],  n in [0, 2K+L-2)
       non-periodization (:262-269): y[n] = full[n+L-2],  n in [0, 2K-L+2)
       periodization (:252-261):     N=2K; full[:L-2] += full[N:N+L-2]; z = full[:N];
-                                    y[i] = z[(i + L//2 - 1) mod N]
+                                    y[i] = z[(i + S) mod N], S = L//2 - 1 (0 once L//2 - 1 >= 2N: roll() again)
     """
     if mode not in ('zero', 'symmetric', 'reflect', 'periodic', 'per', 'periodization'):
         raise ValueError("Unkown pad type: {}".format(mode))
@@ -191,7 +192,7 @@ def sfb1d(lo, hi, g0, g1, mode='zero', axis=-1):
             # also when L-2 > N), then truncate to N
             full[tuple(sl_h)] = full[tuple(sl_h)] + full[tuple(sl_t)]
         z = np.take(full, np.arange(N), axis=axis)
-        return np.take(z, np.mod(np.arange(N) + L // 2 - 1, N), axis=axis)
+        return np.take(z, np.mod(np.arange(N) + (L // 2 - 1 if L // 2 - 1 < 2 * N else 0), N), axis=axis)
     return np.take(full, np.arange(L - 2, L - 2 + 2 * K - L + 2), axis=axis)
 
 

@@ -14,10 +14,12 @@ from .scatternet import ScatLayer, ScatLayerj2   # noqa: E402,F401
 from . import parallel                                  # noqa: E402,F401
 
 
-def engine_info(module, x=None):
-    """Which kernels a module's forward will launch (used by bench.py to label the roofline)."""
-    from .dwt import transform2d
-    return transform2d.describe_path(module, x)
+def last_kernel():
+    """Name of the kernel functor the engine dispatched last on this thread (wl_last_kernel of the C ABI): what actually
+    ran for the last forward / inverse / backward, after every dispatch decision - bench.py and the tests quote it."""
+    from . import _lib
+    raw = _lib.get().wl_last_kernel().decode()
+    return raw.split('K = ')[-1].rstrip(']') if 'K = ' in raw else raw
 
 
 DTCWT = DTCWTForward
@@ -29,5 +31,5 @@ IDWT2D = IDWT
 DWT1D = DWT1DForward
 IDWT1D = DWT1DInverse
 
-__all__ = ['__version__', 'DTCWTForward', 'DTCWTInverse', 'DWTForward', 'DWTInverse', 'DTCWT', 'IDTCWT',
+__all__ = ['__version__', 'last_kernel', 'DTCWTForward', 'DTCWTInverse', 'DWTForward', 'DWTInverse', 'DTCWT', 'IDTCWT',
            'DWT', 'IDWT', 'DWT2D', 'IDWT2D', 'DWT1DForward', 'DWT1DInverse', 'DWT1D', 'IDWT1D', 'ScatLayer', 'ScatLayerj2']

@@ -18,6 +18,8 @@ PROTOTYPES = {
     'wl_dwt2d_synthesis_fused': (I, [P, L, I, I, I, C.POINTER(P), C.POINTER(I), C.POINTER(I), P, I, L, I, P, P, P, P, I, I, I, P]),
     'wl_dwt2d_analysis_nonsep': (I, [P, P, I, L, I, I, P, I, I, I, P]),
     'wl_dwt2d_synthesis_nonsep': (I, [P, P, I, L, I, I, I, I, P, I, I, I, P]),
+    'wl_dwt2d_analysis_nonsep_bwd': (I, [P, P, I, L, I, I, P, I, I, I, P]),
+    'wl_dwt2d_synthesis_nonsep_bwd': (I, [P, P, I, L, I, I, P, I, I, I, P]),
     'wl_dtcwt_fwd_level1': (I, [P, P, P, I, L, I, I, P, I, P, I, I, P]),
     'wl_dtcwt_fwd_level2': (I, [P, P, P, I, L, I, I, P, P, P, P, I, P]),
     'wl_dtcwt_inv_level1': (I, [P, L, I, P, P, I, L, I, I, P, I, P, I, I, P]),

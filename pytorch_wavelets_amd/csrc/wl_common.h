@@ -164,6 +164,17 @@ WL_HD int wl_ext1(int i, int n, int ext) {
     return (unsigned)i < (unsigned)n ? i : out;
 }
 
+// The reference's periodization analysis evaluated literally (dwt/lowlevel.py:134-150): the signal (its last sample
+// repeated when n is odd: ne samples) is rolled by L2 = L/2 and zero padded by the convolution; Z(i) = source position of
+// position i of that rolled signal, or -1 for a zero.  The reference's roll() (:9-25) is built from two slices and
+// degenerates into the identity once the shift reaches twice the length (signals of 1-4 samples under 10-20 taps).
+WL_HD int wl_per_rolled_src(int i, int n, int L2) {
+    const int ne = n + (n & 1);
+    if ((unsigned)i >= (unsigned)ne) return -1;
+    const int t = (i + (L2 < 2 * ne ? L2 : 0)) % ne;
+    return t < n ? t : n - 1;
+}
+
 // Replicate-padded view used by the DTCWT modules (dtcwt/transform2d.py:116-120, :131-135):
 // a virtual signal of length n + pad_lo + pad_hi whose first pad_lo / last pad_hi samples
 // replicate the edge.  Returns the source position of virtual position v (after extension).

@@ -6,10 +6,12 @@
 // irrelevant.  (They are valid for every periodization size - for long signals both forms coincide.)
 //
 //   analysis, one axis:  xe = x (+ its last sample again when N is odd), Ne = len(xe), N2 = Ne/2, L2 = L/2,
-//       Z(i) = xe[(i + L2) mod Ne] for 0 <= i < Ne, else 0          (the rolled signal, zero padded by conv2d)
+//       Z(i) = xe[(i + S) mod Ne] for 0 <= i < Ne, else 0           (the rolled signal, zero padded by conv2d)
+//       S = L2 mod Ne while L2 < 2 Ne, else 0: the reference's roll() (dwt/lowlevel.py:9-25) is built from two slices and
+//       degenerates into the identity once the shift reaches twice the length (signals of 1-4 samples under 10-20 taps)
 //       y[k] = sum_m h[L-1-m] * ( Z(2k-m) + [k < min(L2,N2)] * Z(2k+Ne-m) )
 //   synthesis, one axis: full[n] = sum_k lo[k] g0[n-2k] + hi[k] g1[n-2k], n in [0, 2K+L-2), N = 2K,
-//       z[n] = full[n] + [n < L-2] * full[n+N]   (n < N),   y[i] = z[(i + L/2 - 1) mod N]
+//       z[n] = full[n] + [n < L-2] * full[n+N]   (n < N),   y[i] = z[(i + S) mod N],  S = L/2-1 (0 once L/2-1 >= 2N: roll() again)
 #pragma once
 #include "wl_common.h"
 
@@ -32,13 +34,7 @@ struct WlAfbDirect {
     typedef typename WlAcc<T>::type A;
     static const int kThreads = 256;
     static const int kMinWaves = 1;
-    // Z(i) of the header: source position in the original length-n signal, or -1 for a zero
-    static WL_DEV int zsrc(int i, int n, int L2) {
-        const int ne = n + (n & 1);
-        if ((unsigned)i >= (unsigned)ne) return -1;
-        const int t = (i + L2) % ne;
-        return t < n ? t : n - 1;
-    }
+    static WL_DEV int zsrc(int i, int n, int L2) { return wl_per_rolled_src(i, n, L2); }   // Z(i) of the header
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
         const int64_t per = (int64_t)a.Kh * a.Kw;
         const int64_t idx = ctx.bid * kThreads + ctx.tid;
@@ -84,7 +80,7 @@ struct WlSfbDirect {
     // coefficient of coefficient k in output sample i of one synthesis axis (taps g, length L, K coefficients)
     static WL_DEV A coef(const A* g, int L, int K, int i, int k) {
         const int N = 2 * K;
-        const int n = (i + L / 2 - 1) % N;
+        const int n = (i + (L / 2 - 1 < 2 * N ? L / 2 - 1 : 0)) % N;
         A c = 0;
         int t = n - 2 * k;
         if (t >= 0 && t < L) c += g[t];

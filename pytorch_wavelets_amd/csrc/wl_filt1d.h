@@ -16,6 +16,9 @@
 #include "wl_common.h"
 
 #define WL_EXT_REPLICATE 5   // edge replication (only the stationary transform's 'replicate' padding uses it)
+#define WL_EXT_PER_FOLD1 6   // periodization as the reference evaluates it (roll, zero-padded convolution, ONE fold of the
+                             // wrapped tail: dwt/lowlevel.py:134-150) - differs from the circular form (WL_EXT_PER) when the
+                             // signal is shorter than the filter.  step 2, tap_step 1, start = 1 - ntaps.
 
 WL_HD int wl_ext_any(int i, int n, int ext) {
     if (ext == WL_EXT_REPLICATE) return i < 0 ? 0 : (i >= n ? n - 1 : i);
@@ -48,6 +51,18 @@ struct WlCorr1d {
         const T* xp = a.x + o * a.n * a.inner + i;
         A acc0 = 0, acc1 = 0;
         const int p0 = a.start + a.step * k;
+        if (a.ext == WL_EXT_PER_FOLD1) {
+            const int ne = a.n + (a.n & 1), L2 = a.nt / 2;
+            const int nfold = k < (L2 < ne / 2 ? L2 : ne / 2) ? 2 : 1;
+            for (int f = 0; f < nfold; ++f)
+                for (int t = 0; t < a.nt; ++t) {
+                    const int s = wl_per_rolled_src(p0 + t + f * ne, a.n, L2);
+                    if (s < 0) continue;
+                    const A v = (A)xp[(int64_t)s * a.inner];
+                    acc0 += a.h0[a.t0 + a.ts * t] * v;
+                    if (a.y1) acc1 += a.h1[a.t0 + a.ts * t] * v;
+                }
+        } else
         for (int t = 0; t < a.nt; ++t) {
             const int s = wl_ext_any(p0 + a.dstep * t, a.n, a.ext);
             if (s < 0) continue;
@@ -103,7 +118,7 @@ struct WlSynth1d {
         A v;
         if (a.circ) {
             const int N = 2 * a.K;
-            const int m = (p + a.L / 2 - 1) % N;
+            const int m = (p + (a.L / 2 - 1 < 2 * N ? a.L / 2 - 1 : 0)) % N;   // the reference's roll(): identity from 2N on
             v = full(a, lp, hp, m);
             if (m < a.L - 2) v += full(a, lp, hp, m + N);
         } else {

@@ -11,6 +11,12 @@
 //   synthesis: y[p][q] = sum_b sum_{u,v} g[b][u][v] * c[b][(p + sy - u) / 2][(q + sx - v) / 2]  over the even numerators;
 //              zero / symmetric / reflect / periodic: s = L - 2, indices outside the coefficient plane dropped (:793-796);
 //              periodization: s = L / 2 - 1 and the numerator taken modulo 2K (:787-791: fold + roll).
+//   gradients (what autograd gives upstream, where both banks are plain differentiable ATen chains):
+//     analysis:  dx[r][c] = sum over the extended positions (er, ec) that the boundary rule maps onto (r, c) of
+//                sum_b sum_{u,v} f[b][u][v] * dy[b][(er - oy - u) / 2][(ec - ox - v) / 2]   (even numerators, in range)
+//                - the position itself plus the mirrored / wrapped / repeated ones in the two pads (WlAfbNonsepAdj);
+//     synthesis: dc[b][i][j] = sum_{u,v} g[b][u][v] * DY(2i + u - sy, 2j + v - sx), DY = dy outside its support zero
+//                (periodization: periodic) - which IS the analysis kernel with other offsets (WlAfbNonsep).
 #pragma once
 #include "wl_common.h"
 
@@ -87,5 +93,65 @@ struct WlSfbNonsep {
             }
         }
         a.y[(size_t)plane * per + rem] = (T)acc;
+    }
+};
+
+// Adjoint of WlAfbNonsep: x = dy (planes, 4, Kh, Kw), y = dx (planes, H, W); one thread per input sample.
+template <typename T>
+struct WlAfbNonsepAdj {
+    typedef WlNonsepArgs<T> Args;
+    typedef typename WlAcc<T>::type A;
+    static const int kThreads = 256;
+    static const int kMinWaves = 1;
+    // contribution of extended position (er, ec)
+    static WL_DEV A at(const Args& a, const T* dp, int er, int ec) {
+        const size_t per = (size_t)a.Kh * a.Kw;
+        const int taps = a.Ly * a.Lx;
+        A acc = 0;
+        for (int u = 0; u < a.Ly; ++u) {
+            const int P = er - a.oy - u;
+            if (P < 0 || (P & 1) || P / 2 >= a.Kh) continue;
+            for (int v = 0; v < a.Lx; ++v) {
+                const int Q = ec - a.ox - v;
+                if (Q < 0 || (Q & 1) || Q / 2 >= a.Kw) continue;
+                const T* s = dp + (size_t)(P / 2) * a.Kw + Q / 2;
+                const A* fp = a.f + u * a.Lx + v;
+                acc += fp[0] * (A)s[0] + fp[taps] * (A)s[per] + fp[2 * taps] * (A)s[2 * per] + fp[3 * taps] * (A)s[3 * per];
+            }
+        }
+        return acc;
+    }
+    // k-th extended position mapped onto r: k = 0 is r itself, then the positions of the two pads that the rule folds
+    // onto r, in order; -1000000 when there are no more.  lo / hi = first / last extended position the bank reads.
+    static WL_DEV int cand(int k, int r, int n, int lo, int hi, int ext) {
+        if (k == 0) return r;
+        for (int e = lo; e <= hi; ++e) {
+            if (e == 0) e = n;                       // skip the interior
+            if (e > hi) break;
+            if (wl_ext(e, n, ext) == r && --k == 0) return e;
+        }
+        return -1000000;
+    }
+    static WL_DEV void run(const Args& a, const WlCtx& ctx) {
+        const int64_t per = (int64_t)a.H * a.W;
+        const int64_t idx = ctx.bid * kThreads + ctx.tid;
+        if (idx >= a.planes * per) return;
+        const int64_t plane = idx / per;
+        const int rem = (int)(idx - plane * per);
+        const int r = rem / a.W, c = rem - r * a.W;
+        const T* dp = a.x + (size_t)plane * 4 * a.Kh * a.Kw;
+        const int rlo = a.oy < 0 ? a.oy : 0, rhi = 2 * (a.Kh - 1) + a.oy + a.Ly - 1;
+        const int clo = a.ox < 0 ? a.ox : 0, chi = 2 * (a.Kw - 1) + a.ox + a.Lx - 1;
+        A acc = 0;
+        for (int kr = 0;; ++kr) {
+            const int er = cand(kr, r, a.H, rlo, rhi, a.ext);
+            if (er == -1000000) break;
+            for (int kc = 0;; ++kc) {
+                const int ec = cand(kc, c, a.W, clo, chi, a.ext);
+                if (ec == -1000000) break;
+                acc += at(a, dp, er, ec);
+            }
+        }
+        a.y[idx] = (T)acc;
     }
 };

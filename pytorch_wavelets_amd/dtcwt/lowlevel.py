@@ -27,11 +27,17 @@ def _empty(X):
     return X is None or X.shape == torch.Size([])
 
 
+def _placeholder(X, h):
+    """What the reference returns for a missing input (dtcwt/lowlevel.py:71-72 etc.).  Upstream writes ``X.device`` there and
+    so raises AttributeError for ``X is None``; the filter's device is used instead."""
+    return torch.zeros(1, 1, 1, 1, device=h.device if X is None else X.device)
+
+
 def colfilter(X, h, mode='symmetric'):
     """Filter the columns of X (along H) with the odd-length taps h, same size out (reference dtcwt/lowlevel.py:70-80):
     Y[i] = sum_j h[j] * ext(X, i + j - L//2), symmetric extension for mode 'symmetric', zero padding otherwise."""
     if _empty(X):
-        return torch.zeros(1, 1, 1, 1, device=X.device)
+        return _placeholder(X, h)
     L = h.numel()
     m = L // 2
     return ops.corr1d(X, 2, h, None, X.shape[2] + 2 * m - L + 1, -m, 1, 1, _sym_or_zero(mode))
@@ -40,7 +46,7 @@ def colfilter(X, h, mode='symmetric'):
 def rowfilter(X, h, mode='symmetric'):
     """Filter the rows of X (along W) (reference dtcwt/lowlevel.py:83-94)."""
     if _empty(X):
-        return torch.zeros(1, 1, 1, 1, device=X.device)
+        return _placeholder(X, h)
     L = h.numel()
     m = L // 2
     return ops.corr1d(X, 3, h, None, X.shape[3] + 2 * m - L + 1, -m, 1, 1, _sym_or_zero(mode))
@@ -65,7 +71,7 @@ def _dfilt(X, ha, hb, highpass, dim, what):
 def coldfilt(X, ha, hb, highpass=False, mode='symmetric'):
     """Dual-tree decimating column filter (reference dtcwt/lowlevel.py:97-122); rows must be a multiple of 4."""
     if _empty(X):
-        return torch.zeros(1, 1, 1, 1, device=X.device)
+        return _placeholder(X, ha)
     if mode != 'symmetric':
         raise NotImplementedError()
     return _dfilt(X, ha, hb, highpass, 2, 'rows')
@@ -74,7 +80,7 @@ def coldfilt(X, ha, hb, highpass=False, mode='symmetric'):
 def rowdfilt(X, ha, hb, highpass=False, mode='symmetric'):
     """Dual-tree decimating row filter (reference dtcwt/lowlevel.py:125-151); columns must be a multiple of 4."""
     if _empty(X):
-        return torch.zeros(1, 1, 1, 1, device=X.device)
+        return _placeholder(X, ha)
     if mode != 'symmetric':
         raise NotImplementedError()
     return _dfilt(X, ha, hb, highpass, 3, 'cols')
@@ -105,14 +111,14 @@ def _ifilt(X, ha, hb, highpass, dim, what):
 def colifilt(X, ha, hb, highpass=False, mode='symmetric'):
     """Dual-tree interpolating column filter (reference dtcwt/lowlevel.py:154-195); rows must be even."""
     if _empty(X):
-        return torch.zeros(1, 1, 1, 1, device=X.device)
+        return _placeholder(X, ha)
     return _ifilt(X, ha, hb, highpass, 2, 'rows')
 
 
 def rowifilt(X, ha, hb, highpass=False, mode='symmetric'):
     """Dual-tree interpolating row filter (reference dtcwt/lowlevel.py:198-239); columns must be even."""
     if _empty(X):
-        return torch.zeros(1, 1, 1, 1, device=X.device)
+        return _placeholder(X, ha)
     return _ifilt(X, ha, hb, highpass, 3, 'cols')
 
 

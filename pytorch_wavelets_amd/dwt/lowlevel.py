@@ -366,8 +366,9 @@ def prep_filt_sfb2d_nonsep(g0_col, g1_col, g0_row=None, g1_row=None, device=None
 
 
 class _AFB2DNonsep(Function):
-    """afb2d_nonsep as an autograd node.  Backward = the adjoint, evaluated by the synthesis kernel with the same
-    (mirrored) point-spread functions: exact where the forward has no mirrored samples (zero, periodization)."""
+    """afb2d_nonsep as an autograd node.  Backward = the true adjoint of the boundary gather + strided correlation in
+    every mode - what autograd gives upstream, where the function is a plain ATen chain (dwt/lowlevel.py:524-597):
+    mirrored / wrapped / repeated samples fold their gradient back onto their source (one kernel launch)."""
 
     @staticmethod
     def forward(ctx, x, filts, mode):
@@ -380,22 +381,14 @@ class _AFB2DNonsep(Function):
     def backward(ctx, dy):
         dx = None
         if ctx.needs_input_grad[0]:
-            if ctx.mode not in (0, 2):
-                raise NotImplementedError('gradient of afb2d_nonsep: zero and periodization modes only')
             filts, = ctx.saved_tensors
-            N, C, H, W = ctx.shape
-            dx = ops.sfb2d_nonsep(dy, filts, ctx.mode, out_hw=(H + (H & 1), W + (W & 1)) if ctx.mode == 2 else (H, W))
-            if ctx.mode == 2 and (H & 1 or W & 1):   # the repeated last row / column of an odd size
-                if H & 1:
-                    dx = torch.cat((dx[:, :, :H - 1], dx[:, :, H - 1:H] + dx[:, :, H:H + 1]), dim=2)
-                if W & 1:
-                    dx = torch.cat((dx[..., :W - 1], dx[..., W - 1:W] + dx[..., W:W + 1]), dim=3)
+            dx = ops.afb2d_nonsep_bwd(dy, filts, ctx.mode, ctx.shape[-2:])
         return dx, None, None
 
 
 class _SFB2DNonsep(Function):
-    """sfb2d_nonsep as an autograd node.  Backward = analysis with the same point-spread functions (the synthesis has
-    no boundary extension, so this is the exact adjoint for the non-periodization modes; periodization: circular)."""
+    """sfb2d_nonsep as an autograd node.  Backward = an analysis of the gradient with the same point-spread functions
+    (zero extension; periodic for periodization) - the exact adjoint in every mode, one kernel launch."""
 
     @staticmethod
     def forward(ctx, coeffs, filts, mode):
@@ -409,12 +402,7 @@ class _SFB2DNonsep(Function):
         dc = None
         if ctx.needs_input_grad[0]:
             filts, = ctx.saved_tensors
-            # dc[b][i][j] = sum_{p,q} dy[p][q] g[b][p + s - 2i][q + s - 2j]: a correlation of dy with g at offset -s
-            # = afb2d_nonsep(dy, g) with zero (non-periodization) / periodic extension; for periodization the analysis
-            # kernel's offset is that of the mirrored bank, so mirror g and shift by one period where needed
-            if ctx.mode == 2:
-                raise NotImplementedError('gradient of sfb2d_nonsep: not for periodization')
-            dc = ops.afb2d_nonsep(dy, filts, 0).reshape(ctx.shape)
+            dc = ops.sfb2d_nonsep_bwd(dy, filts, ctx.mode, ctx.shape)
         return dc, None, None
 
 

@@ -99,13 +99,3 @@ class SWTForward(nn.Module):
             coeffs.append(y)
             ll = y[:, 0::4]
         return coeffs
-
-
-def describe_path(module, x=None):
-    """Kernel names / launch counts of the DWT path (bench.py labels its roofline with this)."""
-    J = getattr(module, 'J', 3)
-    return {'fwd_path': 'specialised tile kernel, one launch per level',
-            'fwd_kernel': 'wl_kernel<WlAfbTile<float, 8, 16, 64, 0>>', 'fwd_launches': J,
-            'inv_path': 'specialised polyphase tile kernel, one launch per level',
-            'inv_kernel': 'wl_kernel<WlSfbTile<float, 8, 0>>',
-            'inv_launches': J}

@@ -69,6 +69,41 @@ def coeff_len(n, L, mode):
     return (n + 1) // 2 if mode == 2 else (n + L - 1) // 2
 
 
+def _plane_strides(t):
+    """(plane stride, row stride) in elements of a (N,C,H,W) tensor whose (n,c) planes are uniformly spaced and whose
+    columns have unit stride - or None when it has no such description (the caller then makes it dense).  The stride of a
+    size-1 dimension carries no information (PyTorch leaves it arbitrary: a grayscale channels_last tensor reports
+    stride(1) == 1 and still passes is_contiguous()), so only dimensions longer than 1 are consulted."""
+    N, C, H, W = t.shape
+    s0, s1, s2, s3 = t.stride()
+    if W > 1 and s3 != 1:
+        return None
+    rs = s2 if H > 1 else W
+    if rs < W:
+        return None
+    if C > 1:
+        ps = s1
+        if N > 1 and s0 != C * ps:
+            return None
+    elif N > 1:
+        ps = s0
+    else:
+        ps = H * rs
+    if ps < 0:
+        return None
+    return ps, rs
+
+
+def _planes(t):
+    """t (N,C,H,W) as (tensor, plane stride, row stride) with uniformly spaced planes of unit-stride rows (a copy only
+    when t has no such layout)."""
+    st = None if t.numel() == 0 else _plane_strides(t)
+    if st is None:
+        t = t.contiguous()
+        st = (t.shape[2] * t.shape[3], t.shape[3])
+    return t, st[0], st[1]
+
+
 def _ll_pitch(kw, itemsize):
     """Row pitch (elements) of an inner-level LL buffer: the next multiple of a 128-byte cache line."""
     q = 128 // itemsize
@@ -81,8 +116,7 @@ def afb2d(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, pad_ll=False):
     of a cache line) - the level loop uses it for the LL_j that only feed the next level."""
     _check_tensor(x, 'x')
     N, C, H, W = x.shape
-    if x.numel() == 0 or x.stride(3) != 1 or x.stride(0) != C * x.stride(1) or x.stride(2) < W:
-        x = x.contiguous()
+    x, x_ps, x_rs = _planes(x)
     hwl, hwh, hhl, hhh = (_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi))
     Lw, Lh = hwl.numel(), hhl.numel()
     Kh, Kw = coeff_len(H, Lh, mode), coeff_len(W, Lw, mode)
@@ -91,7 +125,7 @@ def afb2d(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, pad_ll=False):
     else:
         ll = torch.empty((N, C, Kh, Kw), dtype=x.dtype, device=x.device)
     highs = torch.empty((N, C, 3, Kh, Kw), dtype=x.dtype, device=x.device)
-    rc = _call('wl_dwt2d_analysis_strided', x, x.data_ptr(), x.stride(1), x.stride(2), ll.data_ptr(), ll.stride(1),
+    rc = _call('wl_dwt2d_analysis_strided', x, x.data_ptr(), x_ps, x_rs, ll.data_ptr(), ll.stride(1),
                                               ll.stride(2), highs.data_ptr(), _DTYPES[x.dtype], N * C, H, W,
                                               hwl.data_ptr(), hwh.data_ptr(), Lw, hhl.data_ptr(), hhh.data_ptr(), Lh,
                                               mode, _stream(x))
@@ -104,8 +138,7 @@ def sfb2d(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None):
     -> y (N,C,OH,OW); out_hw crops the result (used by the analysis backward)."""
     _check_tensor(ll, 'll')
     N, C, Kh, Kw = ll.shape
-    if ll.stride(3) != 1 or ll.stride(0) != C * ll.stride(1) or ll.numel() == 0:
-        ll = ll.contiguous()
+    ll, ll_ps, ll_rs = _planes(ll)
     if highs is not None:
         if highs.dtype != ll.dtype:
             highs = highs.to(ll.dtype)
@@ -120,7 +153,7 @@ def sfb2d(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None):
     if out_hw is not None:
         OH, OW = min(OH, out_hw[0]), min(OW, out_hw[1])
     y = torch.empty((N, C, OH, OW), dtype=ll.dtype, device=ll.device)
-    rc = _call('wl_dwt2d_synthesis', ll, ll.data_ptr(), ll.stride(1), ll.stride(2),
+    rc = _call('wl_dwt2d_synthesis', ll, ll.data_ptr(), ll_ps, ll_rs,
                                        None if highs is None else highs.data_ptr(), y.data_ptr(),
                                        _DTYPES[ll.dtype], N * C, Kh, Kw, OH, OW, gwl.data_ptr(),
                                        gwh.data_ptr(), Lw, ghl.data_ptr(), ghh.data_ptr(), Lh, mode,
@@ -130,6 +163,10 @@ def sfb2d(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None):
 
 
 _CU_COUNT = {}
+# configurations the streaming launchers declined (WL_ERR_UNSUPPORTED for reasons only they can see: rows wider than the
+# compute waves, LDS budget, schedule table, ...).  A decline depends on nothing but the key, so the outputs of a doomed
+# call are allocated once per configuration, not on every forward of the n = 3, 2, 1 ladder of the callers.
+_FUSED_DECLINED = set()
 
 
 def _num_cus(device):
@@ -156,6 +193,9 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=0):
             or (strips == 0 and 8 * N * C < 3 * _num_cus(x.device)) or strips > 2):
         return None
     x = x.contiguous()
+    key = ('afb', x.device, x.dtype, N * C, H, W, L, mode, nlev, strips)
+    if key in _FUSED_DECLINED or x.data_ptr() % 16:
+        return None
     hwl, hwh, hhl, hhh = (_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi))
     yh = []
     h, w = H, W
@@ -167,6 +207,7 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=0):
     rc = _call('wl_dwt2d_analysis_fused', x, x.data_ptr(), yl.data_ptr(), ptrs, _DTYPES[x.dtype], N * C, H, W, nlev,
                hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(), hhh.data_ptr(), L, mode, strips, _stream(x))
     if rc == -3:
+        _FUSED_DECLINED.add(key)
         return None
     _lib.check(rc, 'wl_dwt2d_analysis_fused')
     return yl, yh
@@ -198,20 +239,27 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=0):
     kh, kw = yh[-1].shape[3], yh[-1].shape[4]
     if (h, w) != (kh, kw):
         yl = yl[..., :kh, :kw]
-    if yl.stride(3) != 1 or yl.stride(2) != kw or yl.stride(0) != C * yl.stride(1) or (yl.stride(1) * es) % 4:
+    st = _plane_strides(yl)
+    if st is None or st[1] != kw or (st[0] * es) % 4:
         yl = yl.contiguous()
+        st = (kh * kw, kw)
+    yl_ps, yl_rs = st
     yh = [t.contiguous() for t in yh]
     for t in yh:
         _same_device(yl, t)
+    key = ('sfb', yl.device, yl.dtype, N * C, kh, kw, tuple(tuple(t.shape[3:]) for t in yh), L, mode, strips)
+    if key in _FUSED_DECLINED or yl.data_ptr() % 4 or any(t.data_ptr() % 4 for t in yh):
+        return None
     gwl, gwh, ghl, ghh = (_taps(g, yl) for g in (g_w_lo, g_w_hi, g_h_lo, g_h_hi))
     y = torch.empty((N, C, sh, sw), dtype=yl.dtype, device=yl.device)
     ptrs = (ctypes.c_void_p * nlev)(*[t.data_ptr() for t in yh])
     khs = (ctypes.c_int * nlev)(*[t.shape[3] for t in yh])
     kws = (ctypes.c_int * nlev)(*[t.shape[4] for t in yh])
-    rc = _call('wl_dwt2d_synthesis_fused', yl, yl.data_ptr(), yl.stride(1), yl.stride(2), kh, kw, ptrs, khs, kws,
+    rc = _call('wl_dwt2d_synthesis_fused', yl, yl.data_ptr(), yl_ps, yl_rs, kh, kw, ptrs, khs, kws,
                y.data_ptr(), _DTYPES[yl.dtype], N * C, nlev, gwl.data_ptr(), gwh.data_ptr(), ghl.data_ptr(),
                ghh.data_ptr(), L, mode, strips, _stream(yl))
     if rc == -3:
+        _FUSED_DECLINED.add(key)
         return None
     _lib.check(rc, 'wl_dwt2d_synthesis_fused')
     return y
@@ -264,8 +312,44 @@ def sfb2d_nonsep(coeffs, filts, mode, out_hw=None):
     return y
 
 
+def afb2d_nonsep_bwd(dy, filts, mode, in_hw):
+    """Gradient of afb2d_nonsep with respect to x: dy (N,4C,Kh,Kw) -> dx (N,C,H,W) - the adjoint of boundary gather +
+    correlation in every mode, as autograd gives it upstream (dwt/lowlevel.py:524-597 is a plain ATen chain)."""
+    _check_tensor(dy, 'dy')
+    dy = dy.contiguous()
+    H, W = in_hw
+    N, C4 = dy.shape[:2]
+    Ly, Lx = filts.shape[2], filts.shape[3]
+    if tuple(dy.shape[2:]) != (coeff_len(H, Ly, mode), coeff_len(W, Lx, mode)) or C4 % 4:
+        raise ValueError('afb2d_nonsep_bwd: dy %s does not belong to a %dx%d input' % (tuple(dy.shape), H, W))
+    f = _taps(filts, dy)
+    dx = torch.empty((N, C4 // 4, H, W), dtype=dy.dtype, device=dy.device)
+    if dx.numel():
+        rc = _call('wl_dwt2d_analysis_nonsep_bwd', dy, dy.data_ptr(), dx.data_ptr(), _DTYPES[dy.dtype], N * (C4 // 4), H, W,
+                   f.data_ptr(), Ly, Lx, mode, _stream(dy))
+        _lib.check(rc, 'wl_dwt2d_analysis_nonsep_bwd')
+    return dx
+
+
+def sfb2d_nonsep_bwd(dy, filts, mode, coeff_shape):
+    """Gradient of sfb2d_nonsep with respect to the coefficients: dy (N,C,OH,OW) -> dc of shape coeff_shape
+    ((N,C,4,Kh,Kw) or (N,4C,Kh,Kw))."""
+    _check_tensor(dy, 'dy')
+    dy = dy.contiguous()
+    N, C = dy.shape[:2]
+    Kh, Kw = coeff_shape[-2], coeff_shape[-1]
+    Ly, Lx = filts.shape[2], filts.shape[3]
+    g = _taps(filts, dy)
+    dc = torch.empty((N, C, 4, Kh, Kw), dtype=dy.dtype, device=dy.device)
+    if dc.numel():
+        rc = _call('wl_dwt2d_synthesis_nonsep_bwd', dy, dy.data_ptr(), dc.data_ptr(), _DTYPES[dy.dtype], N * C, Kh, Kw,
+                   g.data_ptr(), Ly, Lx, mode, _stream(dy))
+        _lib.check(rc, 'wl_dwt2d_synthesis_nonsep_bwd')
+    return dc.reshape(coeff_shape)
+
+
 # ---------------------------------------------------------------------------------------------- single axis
-EXT_ZERO, EXT_SYM, EXT_REFL, EXT_PERIODIC, EXT_PER, EXT_REPLICATE = 0, 1, 2, 3, 4, 5
+EXT_ZERO, EXT_SYM, EXT_REFL, EXT_PERIODIC, EXT_PER, EXT_REPLICATE, EXT_PER_FOLD1 = 0, 1, 2, 3, 4, 5, 6
 _MODE_TO_EXT = {0: EXT_ZERO, 1: EXT_SYM, 2: EXT_PER, 4: EXT_REFL, 6: EXT_PERIODIC}
 
 
@@ -312,9 +396,10 @@ def afb1d(x, h0, h1, mode, dim):
     K = coeff_len(n, L, mode)
     if mode == 2:
         if n + (n & 1) < L - 1:
-            raise NotImplementedError('periodization of a signal shorter than the filter along one axis '
-                                      '(the reference folds only once there): not implemented for the 1-D operators')
-        base = 1 - L // 2
+            # shorter than the filter: the reference folds the wrapped tail only once (dwt/lowlevel.py:146-150), which is
+            # not the circular form - evaluated literally by the kernel
+            return corr1d(x, dim, h0, h1, K, 1 - L, 2, 1, EXT_PER_FOLD1)
+        base = L // 2 - L + 1            # roll by -(L//2), pad L-1 (:143-145); = wl_afb_base, also for odd L
     else:
         base = -((2 * (K - 1) - n + L) // 2)
     return corr1d(x, dim, h0, h1, K, base, 2, 1, _MODE_TO_EXT[mode])
@@ -354,10 +439,7 @@ def sfb1d(lo, hi, g0, g1, mode, dim, out_len=None):
 # ---------------------------------------------------------------------------------------------- DTCWT
 def _ll_view(ll, ref_shape):
     """(ptr, plane_stride, row_stride) of a (N,C,h,w) view whose rows are unit-stride."""
-    N, C = ref_shape
-    if ll.stride(3) != 1 or ll.stride(0) != C * ll.stride(1):
-        ll = ll.contiguous()
-    return ll, ll.stride(1), ll.stride(2)
+    return _planes(ll)
 
 
 def dtcwt_fwd1(x, h0, h1, mode, skip_hps=False):

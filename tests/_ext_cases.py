@@ -101,6 +101,22 @@ def check_afb1d_functions(dev, tol):
     assert G.relerr(y.cpu().numpy(), g, 'y') < tol
 
 
+def check_afb1d_periodization(dev, dtype, tol):
+    """Function-level afb1d / sfb1d in mode 'periodization' with odd tap counts and signals shorter than the filter (the
+    reference rolls, convolves with zero padding and folds the wrapped tail ONCE, dwt/lowlevel.py:134-150, :252-261)."""
+    meta, g = G.INDEX['ext_afb1d_per'], G.load('ext_afb1d_per')
+    for c in meta['cases']:
+        k, d = c['key'], c['dim']
+        x = _t(g[k + '_x'], dev, dtype)
+        h0, h1 = _t(g[k + '_h0'], dev, dtype), _t(g[k + '_h1'], dev, dtype)   # tensors: taken as already reversed
+        lohi = dwl.afb1d(x, h0, h1, mode='periodization', dim=d)
+        assert G.relerr(lohi.cpu().numpy(), g, k + '_lohi') < tol, c
+        if c.get('syn'):
+            lo, hi = lohi[:, ::2].contiguous(), lohi[:, 1::2].contiguous()
+            y = dwl.sfb1d(lo, hi, _t(g[k + '_g0'], dev, dtype), _t(g[k + '_g1'], dev, dtype), mode='periodization', dim=d)
+            assert G.relerr(y.cpu().numpy(), g, k + '_y') < tol, c
+
+
 def check_scatj2(name, dev, dtype, tol):
     meta, g = G.INDEX[name], G.load(name)
     prev = torch.get_default_dtype()
@@ -146,8 +162,7 @@ NONSEP_CASES = sorted(k for k, v in G.INDEX.items() if v['kind'] == 'nonsep')
 
 def check_nonsep(name, dev, dtype, tol):
     """afb2d_nonsep / sfb2d_nonsep (+ their prep_filt functions) against the reference's outputs and against the
-    gradients autograd gives upstream (zero / periodization for the analysis, all non-periodization modes for the
-    synthesis; the other gradients raise)."""
+    gradients autograd gives upstream (every mode)."""
     import pytest
     meta, g = G.INDEX[name], G.load(name)
     mode = meta['mode']
@@ -172,16 +187,10 @@ def check_nonsep(name, dev, dtype, tol):
         x = _t(g['x'], dev, dtype).requires_grad_(True)
         y = dwl.afb2d_nonsep(x, fa, mode)
         assert G.relerr(y.detach().cpu().numpy(), g, 'y') < tol
-        loss = (y * _t(g['gy'], dev, dtype)).sum()
-        if mode in ('zero', 'periodization'):
-            dx, = torch.autograd.grad(loss, x)
-            assert G.relerr(dx.cpu().numpy(), g, 'dx') < tol
-        else:
-            with pytest.raises(NotImplementedError):
-                torch.autograd.grad(loss, x)
+        dx, = torch.autograd.grad((y * _t(g['gy'], dev, dtype)).sum(), x)   # every mode: the true adjoint, as upstream
+        assert G.relerr(dx.cpu().numpy(), g, 'dx') < tol
     c = _t(g['c'], dev, dtype).requires_grad_(True)
     rec = dwl.sfb2d_nonsep(c, fs, mode)
     assert G.relerr(rec.detach().cpu().numpy(), g, 'rec') < tol
-    if mode != 'periodization':
-        dc, = torch.autograd.grad((rec * _t(g['gr'], dev, dtype)).sum(), c)
-        assert G.relerr(dc.cpu().numpy(), g, 'dc') < tol
+    dc, = torch.autograd.grad((rec * _t(g['gr'], dev, dtype)).sum(), c)
+    assert G.relerr(dc.cpu().numpy(), g, 'dc') < tol

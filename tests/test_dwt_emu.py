@@ -346,3 +346,40 @@ def test_half_precision_tile_kernels(wave, mode, shape):
     for a, b in zip(yh, ryh):
         assert float((a.float() - b).abs().max()) < 4e-3 * float(b.abs().max())
     assert float((rec.float()[..., :shape[-2], :shape[-1]] - x).abs().max()) < 2e-2 * float(x.abs().max())
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_grayscale_channels_last_strides_are_not_trusted(fused):
+    """A (N,1,H,W) channels_last tensor reports stride(1) == 1 and is_contiguous(): the stride of a size-1 dimension
+    carries no information, so the plane stride handed to the kernels must not come from it (round-2 advisor finding:
+    DWTInverse on such a yl was wrong by O(1))."""
+    from pytorch_wavelets_amd.dwt import lowlevel as ll
+    torch.manual_seed(3)
+    x = torch.randn(4, 1, 20, 20)
+    xfm, ifm = pw.DWTForward(J=2, wave='db2', mode='symmetric'), pw.DWTInverse(wave='db2', mode='symmetric')
+    dx, di = pw.DTCWTForward(J=2), pw.DTCWTInverse()
+    prev = ll.FUSED_LEVELS
+    ll.FUSED_LEVELS = fused
+    try:
+        with emu_backend.emulated():
+            yl, yh = xfm(x)
+            def cl(t):   # what x.to(memory_format=torch.channels_last) / a permuted NHWC batch hands over for C == 1
+                return t.as_strided(t.shape, (t.shape[2] * t.shape[3], 1, t.shape[3], 1))
+            xcl = cl(x)
+            assert xcl.stride(1) == 1 and xcl.is_contiguous()
+            yl2, yh2 = xfm(xcl)
+            assert torch.equal(yl, yl2) and all(torch.equal(a, b) for a, b in zip(yh, yh2))
+            ylcl = cl(yl)
+            rec, rec2 = ifm((yl, yh)), ifm((ylcl, yh))
+            assert torch.equal(rec, rec2) and float((rec - x).abs().max()) < 1e-12
+            # one image, one channel: both leading strides are arbitrary
+            y1 = ifm((ylcl[:1], [h[:1] for h in yh]))
+            assert torch.equal(y1, rec[:1])
+            zl, zh = dx(x)
+            zl2, zh2 = dx(xcl)
+            assert torch.equal(zl, zl2)
+            r1 = di((zl, zh))
+            r2 = di((cl(zl), zh))
+            assert torch.equal(r1, r2) and float((r1 - x).abs().max()) < 1e-10
+    finally:
+        ll.FUSED_LEVELS = prev

@@ -70,6 +70,12 @@ def test_function_level_afb1d_sfb1d():
         E.check_afb1d_functions('cpu', 1e-5)
 
 
+def test_function_level_periodization_odd_taps_and_short_signals():
+    with emu_backend.emulated():
+        E.check_afb1d_periodization('cpu', torch.float64, 1e-12)
+        E.check_afb1d_periodization('cpu', torch.float32, 2e-5)
+
+
 def test_oracle_extras_vs_reference_goldens():
     """The numpy oracle's restatement of the 1-D DWT / a-trous bank / primitives reproduces the reference goldens."""
     from pytorch_wavelets_amd import filters

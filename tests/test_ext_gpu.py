@@ -54,6 +54,11 @@ def test_function_level_afb1d_sfb1d():
     E.check_afb1d_functions(DEV, 1e-5)
 
 
+def test_function_level_periodization_odd_taps_and_short_signals():
+    E.check_afb1d_periodization(DEV, torch.float64, 1e-12)
+    E.check_afb1d_periodization(DEV, torch.float32, 2e-5)
+
+
 def test_dwt1d_long_signals_vs_oracle_and_fp16():
     """Long rows (several workgroups per signal), odd length, float16 storage."""
     import pytorch_wavelets_amd as pw

@@ -36,7 +36,7 @@ def test_dwt_oracle_vs_reference(name):
         assert np.abs(rec[..., :x.shape[-2], :x.shape[-1]] - x).max() < 1e-9
 
 
-@pytest.mark.parametrize('name', [n for n in G.cases('dwt') if n != 'dwt_17'])
+@pytest.mark.parametrize('name', [n for n in G.cases('dwt') if n != 'dwt_17' and not n.startswith('dwt_r3_')])   # levels shorter than the filter: not restated there
 def test_torch_cpu_restatement_vs_reference(name):
     """oracle/torch_cpu.py (the reference's gather + grouped conv2d / conv_transpose2d formulation on PyTorch-CPU, the
     `cpu_baseline` of bench.py) against the same goldens."""
