@@ -1,18 +1,21 @@
 #!/usr/bin/env python
-"""Benchmark of the hot path: DWTForward + DWTInverse, J=3 db4 symmetric, N x 3 x 512 x 512 fp32
-(BASELINE.json configs[1]), synthetic data resident in HBM.
+"""Benchmark of the hot path on synthetic data resident in HBM.  Default workload = BASELINE.json configs[1]:
+DWTForward + DWTInverse, J=3 db4 symmetric, N x 3 x 512 x 512 fp32.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 20 --warmup 5                     # the metric
+    python bench.py --config dtcwt|scat|cfg5 ...                       # the other BASELINE configs, same flow
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W [--config ...]
 
-A "step" = one forward + one inverse transform of this rank's batch (N=128 planes-of-3 per GPU,
-weak scaling: the batch dimension shards with no data-path collective; the only collective is the
-one-off broadcast of the filter banks from rank 0).  Rank 0 prints ONE JSON line.
+A "step" = one pass of the workload over this rank's batch (dwt / dtcwt: forward + inverse; scat, cfg5: forward).
+The batch dimension shards with no data-path collective; the only collective is the one-off broadcast of the filter
+banks from rank 0.  dwt / dtcwt / cfg5 scale weakly (the configured batch per GPU); scat is BASELINE configs[3]:
+256 images split over the ranks (strong).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,19 +24,18 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); a float4 copy reaches ~6300 GB/s
 
 
-def algorithmic_bytes_fwd(N, C, H, W, J, L, itemsize):
+def algorithmic_bytes_fwd(N, C, H, W, J, L, itemsize, periodization=False):
     """every input element read once, every output element written once."""
-    n_in = H * W
     n_out = 0
     h, w = H, W
     for _ in range(J):
-        h, w = (h + L - 1) // 2, (w + L - 1) // 2
+        h, w = ((h + 1) // 2, (w + 1) // 2) if periodization else ((h + L - 1) // 2, (w + L - 1) // 2)
         n_out += 3 * h * w
     n_out += h * w
-    return N * C * (n_in + n_out) * itemsize
+    return N * C * (H * W + n_out) * itemsize
 
 
 def source_digest():
@@ -53,7 +55,7 @@ def source_digest():
 def cpu_baseline(args):
     """The reference's CPU path, restated: oracle/torch_cpu.py = its gather + grouped conv2d / conv_transpose2d
     formulation on PyTorch-CPU (the reference itself is Python on ATen and cannot travel to this box; the restatement is
-    pinned to its golden vectors by tests/test_oracle_golden.py), all host cores, on a bounded sample of the workload.
+    pinned to its golden vectors by tests/test_oracle_golden.py), on a bounded sample of the workload.
     The OpenMP C port of the numpy oracle (oracle/dwt_port.c) is timed next to it."""
     import numpy as np
     from oracle import torch_cpu as tc
@@ -86,7 +88,8 @@ def cpu_baseline(args):
            'host_cores': ncores, 'mpix_s_by_torch_threads': tried,
            'sample': 'oracle/torch_cpu.py (the reference\'s conv2d / conv_transpose2d formulation on PyTorch-CPU, fp32), '
                      'fwd+inv J=3 db4 symmetric on %dx3x512x512, %d reps at the best thread count; the real reference '
-                     'measured 23.0 Mpixels/s on the 8 vCPU of the authoring container with this torch build (profiles/r02_reference_cpu_timing.json; BASELINE.md quotes 16.2 for an older torch)' % (n, best[2])}
+                     'measured 23.0 Mpixels/s on the 8 vCPU of the authoring container with this torch build '
+                     '(profiles/r02_reference_cpu_timing.json; BASELINE.md quotes 16.2 for an older torch)' % (n, best[2])}
     try:
         from oracle import dwt_port
         rng = np.random.RandomState(0)
@@ -104,10 +107,118 @@ def cpu_baseline(args):
     return out
 
 
-def _kernel_name(lib):
-    """Functor of the kernel this thread launched last, as the engine reports it (wl_last_kernel)."""
-    raw = lib.wl_last_kernel().decode()
-    return raw.split('K = ')[-1].rstrip(']') if 'K = ' in raw else raw
+def membench():
+    """tools/micro/bin/membench (built by __graft_entry__.build()): what plain copy / read / write kernels reach on
+    THIS box with the footprint of the forward launch, in the access forms the engine uses."""
+    exe = os.path.join(ROOT, 'tools', 'micro', 'bin', 'membench')
+    if not os.path.exists(exe):
+        return None
+    try:
+        res = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120)
+        return json.loads(res.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:
+        return {'error': str(e)[:80]}
+
+
+class Workload(object):
+    """One BASELINE config: modules, this rank's input, the parts of a step ('f' forward, 'i' inverse) and their
+    algorithmic bytes."""
+    scaling = 'weak'
+    seq = 'fi'
+
+    def run(self, part):
+        with torch.no_grad():
+            if part == 'f':
+                self.coefs = self.xfm(self.x)
+                return self.coefs
+            self.rec = self.ifm(self.coefs)
+            return self.rec
+
+    def step(self):
+        for p in self.seq:
+            out = self.run(p)
+        return out
+
+
+class DwtWorkload(Workload):
+    key = 'dwt'
+    metric = 'Mpixels/s fwd+inv DWT J=3 db4, Nx3x512x512 fp32; % HBM roofline'
+    dtype_name = 'f32'
+
+    def __init__(self, pw, dev, rank, world, args, emu):
+        self.N = args.batch or 128
+        self.C, self.H, self.W, self.J = 3, (64 if emu else 512), (64 if emu else 512), 3
+        self.xfm = pw.DWTForward(J=3, wave='db4', mode='symmetric').to(dev)
+        self.ifm = pw.DWTInverse(wave='db4', mode='symmetric').to(dev)
+        self.x = torch.randn(self.N, 3, self.H, self.W, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
+        b = algorithmic_bytes_fwd(self.N, 3, self.H, self.W, 3, 8, 4)
+        self.bytes = {'f': b, 'i': b}
+        self.global_batch = world * self.N
+        self.workload = ('DWTForward+DWTInverse J=3 db4 symmetric, %dx3x%dx%d fp32 per GPU (BASELINE configs[1])'
+                         % (self.N, self.H, self.W))
+
+
+class DtcwtWorkload(Workload):
+    key = 'dtcwt'
+    metric = 'Mpixels/s fwd+inv DTCWT J=3 near_sym_a/qshift_a, Nx3x512x512 fp32; % HBM roofline'
+    dtype_name = 'f32'
+
+    def __init__(self, pw, dev, rank, world, args, emu):
+        self.N = args.batch or 64
+        self.C, self.H, self.W, self.J = 3, (32 if emu else 512), (32 if emu else 512), 3
+        self.xfm = pw.DTCWTForward(J=3, biort='near_sym_a', qshift='qshift_a').to(dev)
+        self.ifm = pw.DTCWTInverse(biort='near_sym_a', qshift='qshift_a').to(dev)
+        self.x = torch.randn(self.N, 3, self.H, self.W, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
+        b = 20 * self.x.numel()      # SURVEY 8(d): out = exactly 4.0 P per plane -> 5 P x 4 B
+        self.bytes = {'f': b, 'i': b}
+        self.global_batch = world * self.N
+        self.workload = ('DTCWTForward+DTCWTInverse J=3 near_sym_a qshift_a, %dx3x%dx%d fp32 per GPU (BASELINE configs[2])'
+                         % (self.N, self.H, self.W))
+
+
+class ScatWorkload(Workload):
+    key = 'scat'
+    metric = 'Mpixels/s ScatLayer (DTCWT scatternet, 6 orientations), 256x3x256x256 fp32 batch-sharded; % HBM roofline'
+    dtype_name = 'f32'
+    scaling = 'strong'
+    seq = 'f'
+
+    def __init__(self, pw, dev, rank, world, args, emu):
+        from pytorch_wavelets_amd import parallel
+        total = args.batch or 256
+        lo, hi = parallel.shard_bounds(total, world, rank)
+        self.N = hi - lo
+        self.C, self.H, self.W = 3, (32 if emu else 256), (32 if emu else 256)
+        self.xfm = pw.ScatLayer().to(dev)
+        self.ifm = None
+        self.x = torch.randn(self.N, 3, self.H, self.W, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
+        self.bytes = {'f': 11 * self.x.numel()}     # read P, write 7P/4
+        self.global_batch = total
+        self.workload = ('ScatLayer near_sym_a, %dx3x%dx%d fp32 in total, %d images on this rank (BASELINE configs[3])'
+                         % (total, self.H, self.W, self.N))
+
+
+class Cfg5Workload(Workload):
+    key = 'cfg5'
+    metric = 'Mpixels/s DWTForward J=4 db8 periodization, Nx16x2048x2048 fp16; % HBM roofline'
+    dtype_name = 'f16'
+    seq = 'f'
+
+    def __init__(self, pw, dev, rank, world, args, emu):
+        self.N = args.batch or 32
+        self.C, self.H, self.W, self.J = (2 if emu else 16), (128 if emu else 2048), (128 if emu else 2048), 4
+        self.xfm = pw.DWTForward(J=4, wave='db8', mode='periodization').to(dev).half()
+        self.ifm = pw.DWTInverse(wave='db8', mode='periodization').to(dev).half()
+        self.x = torch.randn(self.N, self.C, self.H, self.W, device=dev, dtype=torch.float16,
+                             generator=torch.Generator(device=dev).manual_seed(1234 + rank))
+        b = 4 * self.x.numel()       # critically sampled: out = exactly P -> 2 P x 2 B
+        self.bytes = {'f': b, 'i': b}
+        self.global_batch = world * self.N
+        self.workload = ('DWTForward J=4 db8 periodization, %dx%dx%dx%d fp16 per GPU (BASELINE configs[4]); the inverse is '
+                         'timed beside it' % (self.N, self.C, self.H, self.W))
+
+
+WORKLOADS = {w.key: w for w in (DwtWorkload, DtcwtWorkload, ScatWorkload, Cfg5Workload)}
 
 
 def main():
@@ -115,9 +226,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=128, help='images per GPU (BASELINE configs[1]: 128)')
+    ap.add_argument('--config', choices=sorted(WORKLOADS), default='dwt',
+                    help='dwt = BASELINE configs[1] (the metric); dtcwt / scat / cfg5 = configs[2] / [3] / [4]')
+    ap.add_argument('--batch', type=int, default=0, help='images per GPU (scat: in total); 0 = the BASELINE value')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-other-configs', action='store_true', help='skip the DTCWT / ScatLayer / fp16 context timings')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the context timings of the other configs')
     ap.add_argument('--emulate', action='store_true',
                     help='TEST ONLY: run the whole harness on CPU tensors through the host emulation of the kernels '
                          '(tests/emu) with the gloo backend - exercises the multi-rank control flow without a GPU')
@@ -132,14 +245,12 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, 'tests'))
         import emu_backend
         from pytorch_wavelets_amd import ops
-        ops._TEST_BACKEND = lib = emu_backend.handle()
-    else:
-        if rank == 0:
-            ge.build()
+        ops._TEST_BACKEND = emu_backend.handle()
+    elif rank == 0:
+        ge.build()
     import pytorch_wavelets_amd as pw
     from pytorch_wavelets_amd import parallel
     if not emu:
-        from pytorch_wavelets_amd import _lib
         assert torch.cuda.is_available(), 'bench.py needs a GPU'
         dev = torch.device('cuda', local_rank)
         torch.cuda.set_device(dev)
@@ -151,234 +262,290 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=dev)   # nccl == RCCL on ROCm
-        dist.barrier()
-    if not emu:
-        lib = _lib.get()
+        dist.barrier()   # (ranks > 0 load the library rank 0 has just built only after this point)
 
     def sync():
         if not emu:
             torch.cuda.synchronize()
-
-    class _Timer(object):
-        """HIP events on the launch stream (wall clock in emulation mode)."""
-        def __init__(self):
-            self.e0 = self.e1 = None
-            if not emu:
-                self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-
-        def run(self, fn, n):
-            for _ in range(1 if emu else 60):   # long enough for the clocks to settle on the new load pattern
-                fn()
-            sync()
-            if emu:
-                t0 = time.perf_counter()
-                for _ in range(n):
-                    fn()
-                return (time.perf_counter() - t0) * 1e3 / n
-            self.e0.record()
-            for _ in range(n):
-                fn()
-            self.e1.record()
-            torch.cuda.synchronize()
-            return self.e0.elapsed_time(self.e1) / n
-    timer = _Timer()
-
-    N, C, H, W, J, wave, mode = args.batch, 3, 512, 512, 3, 'db4', 'symmetric'
-    if emu:
-        H = W = 64
-    xfm = pw.DWTForward(J=J, wave=wave, mode=mode).to(dev)
-    ifm = pw.DWTInverse(wave=wave, mode=mode).to(dev)
-    if world > 1:
-        parallel.broadcast_filter_banks(xfm, src=0)
-        parallel.broadcast_filter_banks(ifm, src=0)
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x = torch.randn(N, C, H, W, device=dev, generator=g)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         sync()
 
-    def step():
-        with torch.no_grad():
-            yl, yh = xfm(x)
-            return ifm((yl, yh))
+    wl = WORKLOADS[args.config](pw, dev, rank, world, args, emu)
+    if world > 1:
+        parallel.broadcast_filter_banks(wl.xfm, src=0)
+        if wl.ifm is not None:
+            parallel.broadcast_filter_banks(wl.ifm, src=0)
+    K = args.steps
 
-    # The GPU takes ~20 ms of continuous work to reach its steady clocks (tools/gpu_rampup_probe.py: the first ~100
-    # launches of a cold process run 10 % slower).  A fixed, untimed spin-up precedes the W warmup steps; a job of any
-    # realistic length spends its life in the steady state.
+    def timed_region():
+        """W warmup steps, then EXACTLY K steps between barrier + synchronize on both sides; MAX over ranks."""
+        for _ in range(args.warmup):
+            wl.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            out = wl.step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, out
+
+    # 1. cold: a fresh process, W warmup steps, K timed steps - the number a one-shot caller sees
+    dt_cold, _ = timed_region()
+    # 2. steady: the GPU takes ~20 ms of continuous work to reach its steady clocks (tools/gpu_rampup_probe.py: the first
+    #    ~100 launches of a cold process run ~10 % slower); a job of any realistic length lives here.  `value` is this one,
+    #    the cold figure is printed beside it.
     RAMP_STEPS = 0 if emu else 100
     for _ in range(RAMP_STEPS):
-        step()
-    for _ in range(args.warmup):
-        rec = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rec = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
-    err = float((rec - x).abs().max() / x.abs().max())
+        wl.step()
+    dt, out = timed_region()
+    err = None
+    if wl.seq == 'fi':
+        err = float((out - wl.x).abs().max() / wl.x.abs().max())
 
-    # ---- per-kernel roofline.  The forward transform is ONE launch of the streaming kernel (all J levels, LL_j in
-    # LDS): it is the dominant kernel, timed alone with HIP events on the launch stream; its algorithmic bytes are
-    # x in + yl, yh[j] out (SURVEY.md 8(d)).  The kernel names are the engine's own report of what it dispatched.
-    with torch.no_grad():
-        yl, yh = xfm(x)
-        fwd_launches = 0
-        # Per-kernel durations are taken LIVE in the step loop (the same alternating forward / inverse stream as the timed
-        # region, K more steps right behind it), HIP events around each transform on the launch stream: a loop of one
-        # kernel alone measures the power-management transient of a changed load pattern, not the kernel (rocprofv3
-        # trace of this command: the same launch takes 170 us in the step loop and 205-213 us in the first 30 launches
-        # of a forward-only loop).  The launch is asynchronous and far shorter on the host than on the GPU, so the
-        # stream never runs dry between the events.
+    # ---- per-part durations WITHOUT touching the stream between launches.  HIP events only bracket whole loops of K
+    # iterations of a launch sequence: S = the step itself, S + 'f' = the step with the forward issued twice, S + 'i' with
+    # the inverse twice.  duration(forward) = T(S + f) - T(S), duration(inverse) = T(S + i) - T(S): the kernels run in the
+    # same back-to-back stream as in the timed region (the rocprofv3 trace of this command shows Start[k+1] == End[k]),
+    # no event packet sits between two launches, and forward + inverse must add up to the step (reported as `closure`).
+    wl.run('f')
+    kernel = {'f': pw.last_kernel()}
+    if wl.ifm is not None:
+        wl.run('i')
+        kernel['i'] = pw.last_kernel()
+    parts = [p for p in 'fi' if p == 'f' or wl.ifm is not None]
+
+    def time_seq(seq, n):
+        for _ in range(3):
+            for p in seq:
+                wl.run(p)
+        sync()
         if emu:
-            fwd_ms = timer.run(lambda: xfm(x), args.steps)
-            fwd_kernel = _kernel_name(lib)
-            inv_ms = timer.run(lambda: ifm((yl, yh)), args.steps)
-            inv_kernel = _kernel_name(lib)
-        else:
-            for _ in range(10):
-                step()
-            ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-            for k in range(args.steps):
-                ev[k][0].record()
-                a_, b_ = xfm(x)
-                if k == 0:
-                    fwd_kernel = _kernel_name(lib)
-                ev[k][1].record()
-                ifm((a_, b_))
-                if k == 0:
-                    inv_kernel = _kernel_name(lib)
-                ev[k][2].record()
-            torch.cuda.synchronize()
-            fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
-            inv_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
-    from pytorch_wavelets_amd.dwt import lowlevel as _ll
-    fused = 'WlAfbRows' in fwd_kernel
-    fwd_launches = 1 if fused else J
-    fwd_bytes = algorithmic_bytes_fwd(N, C, H, W, J, 8, 4)
-    fwd_gbs = fwd_bytes / (fwd_ms * 1e-3) / 1e9
-    inv_gbs = fwd_bytes / (inv_ms * 1e-3) / 1e9
-    inv_fused = 'WlSfbRows' in inv_kernel
-    # the same transforms as one tile-kernel launch per level (the round-1 path), for the record
-    with torch.no_grad():
+            t0 = time.perf_counter()
+            for _ in range(n):
+                for p in seq:
+                    wl.run(p)
+            return (time.perf_counter() - t0) * 1e3 / n
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            for p in seq:
+                wl.run(p)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    seqs = {'S': wl.seq}
+    for p in parts:
+        seqs['S+' + p] = wl.seq + p
+    samples = {k: [] for k in seqs}
+    for _ in range(1 if emu else 5):           # interleaved repetitions, medians: box noise hits every sequence alike
+        for k, s in seqs.items():
+            samples[k].append(time_seq(s, K))
+    med = {k: sorted(v)[len(v) // 2] for k, v in samples.items()}
+    part_ms = {p: max(med['S+' + p] - med['S'], 1e-6) for p in parts}
+    closure = sum(part_ms[p] for p in wl.seq) / med['S']
+
+    # the same transforms as one tile-kernel launch per level (the round-1 path), for the record (dwt only)
+    tile = {}
+    if wl.key == 'dwt':
+        from pytorch_wavelets_amd.dwt import lowlevel as _ll
         _ll.FUSED_LEVELS = False
-        tile_ms = timer.run(lambda: xfm(x), args.steps)
-        tile_kernel = _kernel_name(lib)
-        inv_tile_ms = timer.run(lambda: ifm((yl, yh)), args.steps)
-        inv_tile_kernel = _kernel_name(lib)
-        _ll.FUSED_LEVELS = True
-    # what a plain device copy of the same footprint achieves on this box (read + write bytes / time)
-    with torch.no_grad():
-        cdst = torch.empty_like(x)
-        copy_gbs = 2 * x.numel() * 4 / (timer.run(lambda: cdst.copy_(x), args.steps) * 1e-3) / 1e9
-        del cdst
-    # the other BASELINE configs (parity-test cases, not the metric): timed once on rank 0 at N=1 as context
-    other = None
-    if world == 1 and not args.no_other_configs and not emu:
-        other = {}
+        try:
+            for p in parts:
+                base = time_seq(wl.seq, K)
+                tile[p] = {'avg_ms': round(max(time_seq(wl.seq + p, K) - base, 1e-6), 4)}
+                wl.run(p)
+                tile[p]['kernel'] = pw.last_kernel()
+                tile[p]['frac'] = round(wl.bytes[p] / (tile[p]['avg_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        finally:
+            _ll.FUSED_LEVELS = True
+    # what plain device copies of the same footprint achieve on this box
+    copy_gbs, mb = None, None
+    if not emu and rank == 0:
         with torch.no_grad():
-            xd = torch.randn(64, 3, 512, 512, device=dev)
-            dx, di = pw.DTCWTForward(J=3).to(dev), pw.DTCWTInverse().to(dev)
-            dyl, dyh = dx(xd)
-            tf, ti = timer.run(lambda: dx(xd), 10), timer.run(lambda: di((dyl, dyh)), 10)
-            other['dtcwt_j3_near_sym_a_qshift_a_64x3x512x512_fp32'] = {
-                'fwd_ms': round(tf, 4), 'inv_ms': round(ti, 4), 'fwd_inv_mpix_s': round(xd.numel() / (tf + ti) / 1e3, 1),
-                'fwd_frac_of_hbm_peak_at_20B_per_px': round(20 * xd.numel() / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                'inv_frac_of_hbm_peak_at_20B_per_px': round(20 * xd.numel() / (ti * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            del xd, dyl, dyh
-            xs = torch.randn(256, 3, 256, 256, device=dev)
-            sl = pw.ScatLayer().to(dev)
-            ts = timer.run(lambda: sl(xs), 10)
-            other['scatlayer_256x3x256x256_fp32_one_gpu'] = {
-                'fwd_ms': round(ts, 4), 'mpix_s': round(xs.numel() / ts / 1e3, 1),
-                'frac_of_hbm_peak_at_11B_per_px': round(11 * xs.numel() / (ts * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            del xs
-            xh = torch.randn(32, 16, 2048, 2048, device=dev, dtype=torch.float16)   # configs[4] at its full size (4.3 GB)
-            hx = pw.DWTForward(J=4, wave='db8', mode='periodization').to(dev).half()
-            hi = pw.DWTInverse(wave='db8', mode='periodization').to(dev).half()
-            hyl, hyh = hx(xh)
-            th = timer.run(lambda: hx(xh), 3)
-            hk = _kernel_name(lib)
-            tih = timer.run(lambda: hi((hyl, hyh)), 3)
-            other['dwt_j4_db8_periodization_32x16x2048x2048_fp16'] = {
-                'fwd_ms': round(th, 4), 'inv_ms': round(tih, 4), 'fwd_mpix_s': round(xh.numel() / th / 1e3, 1),
-                'fwd_frac_of_hbm_peak_at_4B_per_px': round(4 * xh.numel() / (th * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                'inv_frac_of_hbm_peak_at_4B_per_px': round(4 * xh.numel() / (tih * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                'last_fwd_kernel': hk}
-            del xh, hyl, hyh
-    # HBM traffic of the dominant kernel: only from a PMC summary measured on THIS build of the sources
-    traffic = inv_traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'r02_hbm_traffic.json')
+            cdst = torch.empty_like(wl.x)
+            copy_gbs = 2 * wl.x.numel() * wl.x.element_size() / (time_seq_fn(lambda: cdst.copy_(wl.x), K, sync) * 1e-3) / 1e9
+            del cdst
+        if world == 1:
+            mb = membench()
+
+    other = None
+    if world == 1 and not args.no_other_configs and not emu and wl.key == 'dwt':
+        other = other_configs(pw, dev, sync)
+
+    # HBM traffic of the dominant kernels: only from a PMC summary measured on THIS build of the sources
+    traffic = {}
+    tpath = os.path.join(ROOT, 'profiles', 'r03_hbm_traffic.json')
     if os.path.exists(tpath) and not emu:
         try:
             tj = json.load(open(tpath))
             if tj.get('source_digest') == source_digest():
                 for k, v in tj.get('kernels', {}).items():   # rocprof prints defaulted template arguments too
-                    if k.strip().startswith(fwd_kernel.rstrip('>')):
-                        traffic = v.get('hbm_bytes_corrected')
-                    if k.strip().startswith(inv_kernel.rstrip('>')):
-                        inv_traffic = v.get('hbm_bytes_corrected')
+                    for p in parts:
+                        if k.strip().startswith(kernel[p].rstrip('>')):
+                            traffic[p] = v.get('hbm_bytes_corrected')
         except Exception:
-            traffic = inv_traffic = None
+            traffic = {}
 
     if rank == 0:
-        pixels = world * N * C * H * W
+        per_rank_px = wl.x.numel()
+        pixels = per_rank_px * world if wl.scaling == 'weak' else wl.global_batch * wl.C * wl.H * wl.W
+        names = {'f': 'forward', 'i': 'inverse'}
+
+        def block(p):
+            gbs = wl.bytes[p] / (part_ms[p] * 1e-3) / 1e9
+            b = {'kernel': kernel[p], 'achieved': round(gbs, 1), 'frac': round(gbs / HBM_PEAK_GBS, 4),
+                 'avg_launch_ms': round(part_ms[p], 4), 'algorithmic_bytes_per_launch': wl.bytes[p],
+                 'traffic': traffic.get(p)}
+            if copy_gbs:
+                best = max([copy_gbs] + [v for k, v in (mb or {}).items() if k.startswith('copy_') and isinstance(v, (int, float))])
+                b['frac_of_device_copy'] = round(gbs / best, 4)
+            if p in tile:
+                b['per_level_tile_kernels'] = tile[p]
+            return b
+        roof = {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'how_timed': 'HIP events bracket whole loops of %d iterations of a launch sequence on the launch stream, never '
+                             'single launches: T(step), T(step + forward), T(step + inverse), 5 interleaved repetitions each, '
+                             'medians; duration(part) = T(step + part) - T(step).  closure = (sum of the parts of a step) / '
+                             'T(step)' % K,
+                'closure': round(closure, 4), 'step_ms_events': round(med['S'], 4)}
+        roof.update(block('f'))
+        if wl.key == 'dwt':
+            roof['launches_per_forward'] = 1 if 'WlAfbRows' in kernel['f'] else wl.J
+        if 'i' in part_ms:
+            roof['inverse'] = block('i')
+        if copy_gbs:
+            roof['device_copy_gbs'] = round(copy_gbs, 1)
+            roof['device_copy_kind'] = 'torch.Tensor.copy_ of the input footprint (read + write bytes / time); see membench'
+        if mb is not None:
+            roof['membench'] = mb
         out = {
-            'metric': 'Mpixels/s fwd+inv DWT J=3 db4, Nx3x512x512 fp32; % HBM roofline',
-            'value': round(pixels * args.steps / dt / 1e6, 1),
+            'metric': wl.metric,
+            'value': round(pixels * K / dt / 1e6, 1),
             'unit': 'Mpixels/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(dt / args.steps * 1e3, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'clock_ramp_steps_untimed': RAMP_STEPS,
-            'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'DWTForward+DWTInverse J=3 db4 symmetric, %dx3x%dx%d fp32 per GPU '
-                                   '(BASELINE configs[1])' % (N, H, W),
-                       'global_batch': world * N, 'parallelism': 'batch-sharded x%d, no data-path collective' % world,
-                       'fwd_path': ('one launch of the streaming kernel for all %d levels (LL_j in LDS)' % J) if fused
-                                   else 'one tile-kernel launch per level',
-                       'inv_path': ('one launch of the streaming kernel for all %d levels (low-passes in LDS)' % J) if inv_fused
-                                   else 'one polyphase tile-kernel launch per level'},
-            'roofline': {'bound': 'hbm', 'kernel': fwd_kernel + (' (all %d levels, one launch)' % J if fused else ' (last level)'),
-                         'how_timed': 'HIP events around each transform inside %d further steps of the same forward/inverse '
-                                      'stream (launches serialised by the events; in the free-running timed region consecutive '
-                                      'launches overlap their tails, so ms_per_step < forward + inverse)' % args.steps,
-                         'achieved': round(fwd_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(fwd_gbs / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                         'algorithmic_bytes_per_launch': fwd_bytes, 'avg_launch_ms': round(fwd_ms, 4),
-                         'launches_per_forward': fwd_launches,
-                         'device_copy_gbs': round(copy_gbs, 1), 'frac_of_device_copy': round(fwd_gbs / copy_gbs, 4),
-                         'forward_per_level_tile_kernels': {'kernel': tile_kernel, 'avg_ms': round(tile_ms, 4),
-                                                            'frac': round(fwd_bytes / (tile_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                         'inverse': {'kernel': inv_kernel + (' (all %d levels, one launch)' % J if inv_fused else ' (last level)'),
-                                     'achieved': round(inv_gbs, 1),
-                                     'frac': round(inv_gbs / HBM_PEAK_GBS, 4), 'avg_ms': round(inv_ms, 4),
-                                     'frac_of_device_copy': round(inv_gbs / copy_gbs, 4), 'traffic': inv_traffic,
-                                     'launches_per_inverse': 1 if inv_fused else J,
-                                     'inverse_per_level_tile_kernels': {
-                                         'kernel': inv_tile_kernel, 'avg_ms': round(inv_tile_ms, 4),
-                                         'frac': round(fwd_bytes / (inv_tile_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}},
-            'fwd_mpix_s': round(N * C * H * W / (fwd_ms * 1e-3) / 1e6, 1),
-            'inv_mpix_s': round(N * C * H * W / (inv_ms * 1e-3) / 1e6, 1),
-            'roundtrip_rel_err': err,
+            'n_gpus': world, 'steps': K, 'warmup': args.warmup,
+            'ms_per_step': round(dt / K * 1e3, 4),
+            'higher_is_better': True, 'scaling': wl.scaling, 'vs_baseline': None,
+            'clock_ramp_steps_untimed': RAMP_STEPS,
+            'cold': {'ms_per_step': round(dt_cold / K * 1e3, 4), 'value': round(pixels * K / dt_cold / 1e6, 1),
+                     'what': 'the first %d steps of the process after %d warmup steps, before the %d ramp steps'
+                             % (K, args.warmup, RAMP_STEPS)},
+            'dtype': wl.dtype_name, 'data': 'synthetic',
+            'config': {'workload': wl.workload, 'global_batch': wl.global_batch,
+                       'parallelism': 'batch-sharded x%d, no data-path collective' % world,
+                       'step': ' + '.join(names[p] for p in wl.seq)},
+            'roofline': roof,
         }
+        for p in parts:
+            out['%s_mpix_s' % ('fwd' if p == 'f' else 'inv')] = round(per_rank_px / (part_ms[p] * 1e-3) / 1e6, 1)
+        if err is not None:
+            out['roundtrip_rel_err'] = err
         if emu:
             out['data'] = 'synthetic (HOST EMULATION of the kernels: control-flow test, not a measurement)'
         if other is not None:
             out['other_configs'] = other
-        if not args.no_cpu_baseline and world == 1 and not emu:
+        if not args.no_cpu_baseline and world == 1 and not emu and wl.key == 'dwt':
             out['cpu_baseline'] = cpu_baseline(args)
-        elif world > 1 or emu:
+        else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def time_seq_fn(fn, n, sync):
+    for _ in range(10):
+        fn()
+    sync()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def other_configs(pw, dev, sync):
+    """The other BASELINE configs and the paths around the hot path, timed once on rank 0 at N=1 as context (events
+    around loops of launches, after 10 untimed calls).  Not the metric."""
+    other = {}
+
+    def frac(bytes_, ms):
+        return round(bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    with torch.no_grad():
+        xd = torch.randn(64, 3, 512, 512, device=dev)
+        dx, di = pw.DTCWTForward(J=3).to(dev), pw.DTCWTInverse().to(dev)
+        dyl, dyh = dx(xd)
+        tf, ti = time_seq_fn(lambda: dx(xd), 10, sync), time_seq_fn(lambda: di((dyl, dyh)), 10, sync)
+        other['dtcwt_j3_near_sym_a_qshift_a_64x3x512x512_fp32'] = {
+            'fwd_ms': round(tf, 4), 'inv_ms': round(ti, 4), 'fwd_inv_mpix_s': round(xd.numel() / (tf + ti) / 1e3, 1),
+            'fwd_frac_of_hbm_peak_at_20B_per_px': frac(20 * xd.numel(), tf),
+            'inv_frac_of_hbm_peak_at_20B_per_px': frac(20 * xd.numel(), ti)}
+        del xd, dyl, dyh
+        xs = torch.randn(256, 3, 256, 256, device=dev)
+        sl = pw.ScatLayer().to(dev)
+        ts = time_seq_fn(lambda: sl(xs), 10, sync)
+        other['scatlayer_256x3x256x256_fp32_one_gpu'] = {
+            'fwd_ms': round(ts, 4), 'mpix_s': round(xs.numel() / ts / 1e3, 1),
+            'frac_of_hbm_peak_at_11B_per_px': frac(11 * xs.numel(), ts)}
+        # f2: ScatLayerj2 and the rotationally symmetric variant (no fused kernel: single-axis launches)
+        xs2 = xs[:64]
+        s2 = pw.ScatLayerj2().to(dev)
+        t2 = time_seq_fn(lambda: s2(xs2), 5, sync)
+        sr = pw.ScatLayer(biort='near_sym_b_bp').to(dev)
+        tr = time_seq_fn(lambda: sr(xs2), 5, sync)
+        other['scatlayerj2_64x3x256x256_fp32'] = {'fwd_ms': round(t2, 4), 'mpix_s': round(xs2.numel() / t2 / 1e3, 1)}
+        other['scatlayer_rot_near_sym_b_bp_64x3x256x256_fp32'] = {'fwd_ms': round(tr, 4), 'mpix_s': round(xs2.numel() / tr / 1e3, 1)}
+        del xs, xs2
+        # f3: 1-D DWT and the stationary transform (generic single-axis kernels)
+        x1 = torch.randn(64, 16, 65536, device=dev)
+        d1 = pw.DWT1DForward(J=3, wave='db4', mode='symmetric').to(dev)
+        t1 = time_seq_fn(lambda: d1(x1), 5, sync)
+        other['dwt1d_j3_db4_64x16x65536_fp32'] = {'fwd_ms': round(t1, 4), 'msamples_s': round(x1.numel() / t1 / 1e3, 1),
+                                                  'frac_of_hbm_peak_at_8B_per_sample': frac(8 * x1.numel(), t1)}
+        del x1
+        from pytorch_wavelets_amd.dwt.transform2d import SWTForward
+        xw = torch.randn(16, 3, 512, 512, device=dev)
+        sw = SWTForward(J=2, wave='db2', mode='periodic').to(dev)
+        tw = time_seq_fn(lambda: sw(xw), 5, sync)
+        other['swt_j2_db2_periodic_16x3x512x512_fp32'] = {'fwd_ms': round(tw, 4), 'mpix_s': round(xw.numel() / tw / 1e3, 1)}
+        del xw
+        # outside the fused streaming envelope of round 2: wider images, longer filters
+        for tag, shape, wave, L in (('dwt_j3_db4_16x3x1024x1024_fp32', (16, 3, 1024, 1024), 'db4', 8),
+                                    ('dwt_j3_db8_128x3x512x512_fp32', (128, 3, 512, 512), 'db8', 16)):
+            xl = torch.randn(*shape, device=dev)
+            fx, fi = pw.DWTForward(J=3, wave=wave, mode='symmetric').to(dev), pw.DWTInverse(wave=wave, mode='symmetric').to(dev)
+            c = fx(xl)
+            tf = time_seq_fn(lambda: fx(xl), 10, sync)
+            kf = pw.last_kernel()
+            ti = time_seq_fn(lambda: fi(c), 10, sync)
+            b = algorithmic_bytes_fwd(shape[0], shape[1], shape[2], shape[3], 3, L, 4)
+            other[tag] = {'fwd_ms': round(tf, 4), 'inv_ms': round(ti, 4), 'fwd_frac': frac(b, tf), 'inv_frac': frac(b, ti),
+                          'last_fwd_kernel': kf, 'last_inv_kernel': pw.last_kernel()}
+            del xl, c
+        xh = torch.randn(32, 16, 2048, 2048, device=dev, dtype=torch.float16)   # configs[4] at its full size (4.3 GB)
+        hx = pw.DWTForward(J=4, wave='db8', mode='periodization').to(dev).half()
+        hi = pw.DWTInverse(wave='db8', mode='periodization').to(dev).half()
+        hyl, hyh = hx(xh)
+        th = time_seq_fn(lambda: hx(xh), 3, sync)
+        hk = pw.last_kernel()
+        tih = time_seq_fn(lambda: hi((hyl, hyh)), 3, sync)
+        other['dwt_j4_db8_periodization_32x16x2048x2048_fp16'] = {
+            'fwd_ms': round(th, 4), 'inv_ms': round(tih, 4), 'fwd_mpix_s': round(xh.numel() / th / 1e3, 1),
+            'fwd_frac_of_hbm_peak_at_4B_per_px': frac(4 * xh.numel(), th),
+            'inv_frac_of_hbm_peak_at_4B_per_px': frac(4 * xh.numel(), tih),
+            'last_fwd_kernel': hk, 'last_inv_kernel': pw.last_kernel()}
+        del xh, hyl, hyh
+    return other
 
 
 if __name__ == '__main__':

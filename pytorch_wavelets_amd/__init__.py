@@ -17,8 +17,8 @@ from . import parallel                                  # noqa: E402,F401
 def last_kernel():
     """Name of the kernel functor the engine dispatched last on this thread (wl_last_kernel of the C ABI): what actually
     ran for the last forward / inverse / backward, after every dispatch decision - bench.py and the tests quote it."""
-    from . import _lib
-    raw = _lib.get().wl_last_kernel().decode()
+    from . import ops
+    raw = ops._backend().wl_last_kernel().decode()
     return raw.split('K = ')[-1].rstrip(']') if 'K = ' in raw else raw
 
 

@@ -81,6 +81,27 @@ struct WlCtx {
 // The host emulation defers each copy until the lane's wl_wait_vm releases it, so a missing or too permissive wait
 // reads NaN-poisoned LDS in the CPU tests.
 // ---------------------------------------------------------------------------------------------
+// WL_STREAM_NT (A/B builds, tools/build_ab.sh): bit 0 = the LDS-DMA loads carry the non-temporal hint (data read once),
+// bit 1 = the band / output stores of the streaming kernels are non-temporal
+#ifndef WL_STREAM_NT
+#define WL_STREAM_NT 0
+#endif
+#if WL_STREAM_NT & 1
+#define WL_DMA_NT " nt"
+#else
+#define WL_DMA_NT ""
+#endif
+#if defined(__HIPCC__)
+template <typename T> WL_DEV void wl_store_stream(T* p, T v) {
+#if WL_STREAM_NT & 2
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+#else
+template <typename T> inline void wl_store_stream(T* p, T v) { *p = v; }
+#endif
 #if defined(__HIPCC__)
 WL_DEV int wl_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 WL_DEV float wl_uniform_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
@@ -88,23 +109,23 @@ WL_DEV void wl_dma16(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool 
     const unsigned m0 = __builtin_amdgcn_readfirstlane(ctx.lds_base + lds_off);
     // lanes that are off copy nothing; the instruction still counts once per wave as long as one lane is on
     if (lane_on)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0), "v"(gsrc) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" WL_DMA_NT : : "s"(m0), "v"(gsrc) : "memory", "m0");
 }
 // the same with the global address split into a wave-uniform base (scalar registers) and a 32-bit per-lane byte offset
 WL_DEV void wl_dma16_s(const WlCtx& ctx, unsigned lds_off, const void* sbase, unsigned voff, bool lane_on) {
     const unsigned m0 = __builtin_amdgcn_readfirstlane(ctx.lds_base + lds_off);
     if (lane_on)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(m0), "v"(voff), "s"(sbase) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" WL_DMA_NT : : "s"(m0), "v"(voff), "s"(sbase) : "memory", "m0");
 }
 WL_DEV void wl_dma4_s(const WlCtx& ctx, unsigned lds_off, const void* sbase, unsigned voff, bool lane_on) {
     const unsigned m0 = __builtin_amdgcn_readfirstlane(ctx.lds_base + lds_off);
     if (lane_on)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" : : "s"(m0), "v"(voff), "s"(sbase) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" WL_DMA_NT : : "s"(m0), "v"(voff), "s"(sbase) : "memory", "m0");
 }
 WL_DEV void wl_dma4(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on) {   // 4 bytes per lane
     const unsigned m0 = __builtin_amdgcn_readfirstlane(ctx.lds_base + lds_off);
     if (lane_on)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(m0), "v"(gsrc) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" WL_DMA_NT : : "s"(m0), "v"(gsrc) : "memory", "m0");
 }
 template <int N> WL_DEV void wl_wait_vm() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");

@@ -309,9 +309,9 @@ struct WlAfbRows {
         // keep: the row belongs to this segment (wave-uniform); halo rows of a cut plane are computed, not stored
         const bool st = keep && (!(WL_ROWS_ABLATE & 1) || (cl.x + cl.y + ch.x + ch.y == 12345.f));
         if (st) {
-            *reinterpret_cast<T*>(R.hp0 + ob) = (T)cl.y;    // W-lo / H-hi
-            *reinterpret_cast<T*>(R.hp1 + ob) = (T)ch.x;    // W-hi / H-lo
-            *reinterpret_cast<T*>(R.hp2 + ob) = (T)ch.y;    // W-hi / H-hi
+            wl_store_stream(reinterpret_cast<T*>(R.hp0 + ob), (T)cl.y);    // W-lo / H-hi
+            wl_store_stream(reinterpret_cast<T*>(R.hp1 + ob), (T)ch.x);    // W-hi / H-lo
+            wl_store_stream(reinterpret_cast<T*>(R.hp2 + ob), (T)ch.y);    // W-hi / H-hi
         }
         if (LAST) {
             if (st) *reinterpret_cast<T*>(R.llp + ((unsigned)orow * R.llrowb + R.kb)) = (T)cl.x;

@@ -339,9 +339,16 @@ struct WlSfbRows {
             char* r0 = R.yp + ((unsigned)m * R.yrowb + R.ycol);
             char* r1 = r0 + R.yrowb;
             if (!R.odd_wave) {
+#if (WL_STREAM_NT & 2) && defined(__HIPCC__)
+                typedef T WlVec2 __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+                WlVec2 v = {(T)y0.x, (T)y1.x}, w = {(T)y0.y, (T)y1.y};
+                __builtin_nontemporal_store(v, reinterpret_cast<WlVec2*>(r0));
+                __builtin_nontemporal_store(w, reinterpret_cast<WlVec2*>(r1));
+#else
                 T v[2] = {(T)y0.x, (T)y1.x}, w[2] = {(T)y0.y, (T)y1.y};
                 *reinterpret_cast<WlPairT*>(r0) = *reinterpret_cast<WlPairT*>(v);
                 *reinterpret_cast<WlPairT*>(r1) = *reinterpret_cast<WlPairT*>(w);
+#endif
             } else {   // the wave that holds the last pair of an odd-width row: that lane has one column only
                 *reinterpret_cast<T*>(r0) = (T)y0.x;
                 *reinterpret_cast<T*>(r1) = (T)y0.y;

@@ -163,6 +163,8 @@ def sfb2d(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None):
 
 
 _CU_COUNT = {}
+FUSED_STRIPS = 0   # default `strips` of the two streaming entry points below: 0 = the engine's policy (the planes must fill
+                   # the chip), 1 / 2 = force the streaming kernels whatever the batch (tests pin their backward passes so)
 # configurations the streaming launchers declined (WL_ERR_UNSUPPORTED for reasons only they can see: rows wider than the
 # compute waves, LDS budget, schedule table, ...).  A decline depends on nothing but the key, so the outputs of a doomed
 # call are allocated once per configuration, not on every forward of the n = 3, 2, 1 ladder of the callers.
@@ -178,13 +180,15 @@ def _num_cus(device):
     return _CU_COUNT[idx]
 
 
-def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=0):
+def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None):
     """`nlev` (1..3) analysis levels in ONE launch of the streaming kernel (one workgroup per plane, LL_j stay in LDS,
     HBM traffic = the algorithmic minimum).  Returns (yl, [yh_0..]) or None when the kernel does not cover the
     configuration (caller goes level by level).  strips: 0 = only when the planes alone fill the chip (the engine cuts
     some planes in two to fill whole rounds), 1 = force, whole planes only, 2 = force, every plane cut in two."""
     import ctypes
     _check_tensor(x, 'x')
+    if strips is None:
+        strips = FUSED_STRIPS
     N, C, H, W = x.shape
     L = h_w_lo.numel()
     # the launcher's envelope, checked here first so that a decline costs no allocation
@@ -213,12 +217,14 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=0):
     return yl, yh
 
 
-def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=0):
+def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
     """All len(yh) (1..3) synthesis levels in ONE launch of the streaming kernel: yl (N,C,h,w) [may be a strided crop],
     yh = [finest .. coarsest] of (N,C,3,Kh_j,Kw_j) -> x (N,C,OH,OW).  The intermediate low-passes never leave the
     chip.  Returns None when the kernel does not cover the configuration (caller goes level by level)."""
     import ctypes
     _check_tensor(yl, 'yl')
+    if strips is None:
+        strips = FUSED_STRIPS
     nlev = len(yh)
     N, C, h, w = yl.shape
     L = g_w_lo.numel()

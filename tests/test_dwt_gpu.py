@@ -58,6 +58,68 @@ def test_dwt_vs_reference_goldens(name):
             assert G.relerr(npy(gr[1 + j]), g, 'dyh%d' % j) < TOL
 
 
+STREAMABLE = [n for n in G.cases('dwt') if 'dx' in G.load(n) and G.INDEX[n]['mode'] in ('zero', 'symmetric', 'reflect')
+              and len(F.dwt_analysis_taps(G.INDEX[n]['wave'])[0]) <= 12 and G.INDEX[n]['shape'][-1] % 4 == 0]
+
+
+@pytest.mark.parametrize('name', STREAMABLE)
+def test_streaming_kernels_forward_and_backward_vs_reference_goldens(name, monkeypatch):
+    """The golden-gradient cases are small batches, which the engine's policy sends to the tile kernels: here the two
+    streaming kernels are FORCED (ops.FUSED_STRIPS = 1 / 2), so that their forward AND the two hand-written backward
+    passes they carry (AFB2DMulti.backward runs on WlSfbRows with the analysis taps) are pinned to the reference's own
+    outputs directly, not through the tile kernels."""
+    from pytorch_wavelets_amd import ops
+    meta, g = G.INDEX[name], G.load(name)
+    J, wave, mode = meta['J'], meta['wave'], meta['mode']
+    xfm = pw.DWTForward(J=J, wave=wave, mode=mode).to(DEV)
+    ifm = pw.DWTInverse(wave=wave, mode=mode).to(DEV)
+    for strips in (1, 2):
+        monkeypatch.setattr(ops, 'FUSED_STRIPS', strips)
+        x = t(g['x']).requires_grad_(True)
+        yl, yh = xfm(x)
+        kf = pw.last_kernel()
+        if 'WlAfbRows' not in kf:      # geometry the streaming kernel declines (e.g. halves too short to cut)
+            assert strips == 2, (name, kf)
+            continue
+        assert G.relerr(npy(yl), g, 'yl') < TOL
+        for j in range(J):
+            assert G.relerr(npy(yh[j]), g, 'yh%d' % j) < TOL
+        loss = (yl * t(g['gl'])).sum() + sum((yh[j] * t(g['gh%d' % j])).sum() for j in range(J))
+        dx, = torch.autograd.grad(loss, x)
+        assert 'WlSfbRows' in pw.last_kernel(), pw.last_kernel()
+        assert G.relerr(npy(dx), g, 'dx') < TOL
+        ylr = t(g['yl']).requires_grad_(True)
+        yhr = [t(g['yh%d' % j]).requires_grad_(True) for j in range(J)]
+        rec = ifm((ylr, yhr))
+        assert 'WlSfbRows' in pw.last_kernel(), pw.last_kernel()
+        assert G.relerr(npy(rec), g, 'rec') < TOL
+        gr = torch.autograd.grad((rec * t(g['gy'])).sum(), [ylr] + yhr)
+        assert G.relerr(npy(gr[0]), g, 'dyl') < TOL
+        for j in range(J):
+            assert G.relerr(npy(gr[1 + j]), g, 'dyh%d' % j) < TOL
+
+
+def test_grayscale_channels_last_strides_are_not_trusted():
+    """(N,1,H,W) with stride(1) == 1 (what channels_last hands over for one channel): the stride of a size-1 dimension
+    carries no information - forward, inverse and the DTCWT pair give the same numbers as on the dense tensor."""
+    torch.manual_seed(3)
+    x = torch.randn(4, 1, 40, 40, device=DEV)
+
+    def cl(v):
+        return v.as_strided(v.shape, (v.shape[2] * v.shape[3], 1, v.shape[3], 1))
+    xfm, ifm = pw.DWTForward(J=2, wave='db2', mode='symmetric').to(DEV), pw.DWTInverse(wave='db2', mode='symmetric').to(DEV)
+    dx, di = pw.DTCWTForward(J=2).to(DEV), pw.DTCWTInverse().to(DEV)
+    yl, yh = xfm(x)
+    yl2, yh2 = xfm(cl(x))
+    assert torch.equal(yl, yl2) and all(torch.equal(a, b) for a, b in zip(yh, yh2))
+    rec, rec2 = ifm((yl, yh)), ifm((cl(yl), yh))
+    assert torch.equal(rec, rec2) and float((rec - x).abs().max()) < 1e-4
+    assert torch.equal(ifm((cl(yl)[:1], [h[:1] for h in yh])), rec[:1])
+    zl, zh = dx(x)
+    assert torch.equal(zl, dx(cl(x))[0])
+    assert torch.equal(di((zl, zh)), di((cl(zl), zh)))
+
+
 def test_dwt_q1_separate_row_col_filters_and_none_highs():
     g = G.load('dwt_q1')
     xfm = pw.DWTForward(J=2, wave=tuple(g['h%d' % i] for i in range(4)), mode='symmetric').to(DEV)

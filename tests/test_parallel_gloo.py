@@ -66,25 +66,41 @@ def test_shard_bounds():
             assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
 
 
-def test_bench_multi_rank_control_flow_on_emulator():
-    """bench.py's world>1 branch (process-group init, filter-bank broadcast, barriers, MAX all-reduce of the timed
-    region, one JSON line from rank 0 only) executed for real with two gloo ranks on the host emulation of the
-    kernels - the driver launches exactly this with nccl on 2/4/8 GPUs."""
+def _run_bench_emulated(extra):
     import json
     import subprocess
-    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = 29500 + (os.getpid() % 2000)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
            '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2',
-           '--warmup', '1', '--batch', '2', '--emulate']
+           '--warmup', '1', '--emulate'] + extra
     env = dict(os.environ, OMP_NUM_THREADS='2')
-    res = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    res = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith('{')]
     assert len(lines) == 1, lines   # rank 0 only
-    out = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_other_configs_multi_rank_on_emulator():
+    """The same world>1 flow for BASELINE configs[3] (ScatLayer: 256 images - here 5 - split over the ranks, strong
+    scaling) and configs[2] (DTCWT forward + inverse, weak), on the host emulation with two gloo ranks."""
+    out = _run_bench_emulated(['--config', 'scat', '--batch', '5'])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'strong' and out['config']['global_batch'] == 5
+    assert 'ScatLayer' in out['metric'] and out['config']['step'] == 'forward' and 'inverse' not in out['roofline']
+    assert abs(out['value'] - 5 * 3 * 32 * 32 / (out['ms_per_step'] * 1e-3) / 1e6) <= 0.06
+    out = _run_bench_emulated(['--config', 'dtcwt', '--batch', '1'])
+    assert out['scaling'] == 'weak' and out['config']['global_batch'] == 2 and out['roundtrip_rel_err'] < 1e-5
+    assert 'inverse' in out['roofline'] and 'closure' in out['roofline']   # (wall-clock noise on the emulator: no value check)
+
+
+def test_bench_multi_rank_control_flow_on_emulator():
+    """bench.py's world>1 branch (process-group init, filter-bank broadcast, barriers, MAX all-reduce of the timed
+    region, one JSON line from rank 0 only) executed for real with two gloo ranks on the host emulation of the
+    kernels - the driver launches exactly this with nccl on 2/4/8 GPUs."""
+    out = _run_bench_emulated(['--batch', '2'])
     assert out['n_gpus'] == 2 and out['steps'] == 2 and out['scaling'] == 'weak' and out['cpu_baseline'] is None
     assert out['config']['global_batch'] == 4 and out['roundtrip_rel_err'] < 1e-5
     # whole-job pixels / max-over-ranks time (value is printed with one decimal)
     assert out['value'] > 0 and abs(out['value'] - 2 * 2 * 3 * 64 * 64 / (out['ms_per_step'] * 1e-3) / 1e6) <= 0.06
+    assert out['cold']['ms_per_step'] > 0 and 'WlAfbRows' in out['roofline']['kernel'] and 'WlSfbRows' in out['roofline']['inverse']['kernel']
