@@ -43,8 +43,8 @@ const char* wl_backend(void);
 
 /* Diagnostics.  wl_set_option("generic_only", 1) routes every operator to the runtime-L generic kernels (the test-suite
  * compares the two kernel families); the initial value is read once from $WL_GENERIC_ONLY.  Returns 0, or
- * WL_ERR_UNSUPPORTED for an unknown name.  wl_last_kernel(): name of the kernel functor the calling thread launched
- * last (static storage), so that a benchmark can label its numbers with the dispatch actually taken. */
+ * WL_ERR_UNSUPPORTED for an unknown name.  wl_last_kernel(): name of the kernel functor launched last by any thread of
+ * the process (static storage; autograd runs backward passes on its own threads), so that a benchmark can label its numbers with the dispatch actually taken. */
 int wl_set_option(const char* name, int value);
 const char* wl_last_kernel(void);
 

@@ -17,10 +17,13 @@ __global__ void __launch_bounds__(K::kThreads, K::kMinWaves) wl_kernel(const typ
     K::run(a, ctx);
 }
 
-// name of the kernel functor the calling thread launched last (wl_last_kernel() of the C ABI: bench.py labels its
+// name of the kernel functor launched last by ANY thread of the process (autograd runs backward passes on its own
+// threads; a relaxed atomic pointer to a string literal - a diagnostic, not a synchronisation point)
+// (wl_last_kernel() of the C ABI: bench.py labels its
 // roofline with the dispatch that was actually taken)
-inline thread_local const char* wl_last_kernel_ptr = "";
-static const char* wl_last_kernel_name() { return wl_last_kernel_ptr; }
+#include <atomic>
+inline std::atomic<const char*> wl_last_kernel_ptr{""};
+static const char* wl_last_kernel_name() { return wl_last_kernel_ptr.load(std::memory_order_relaxed); }
 
 // compute units of the current device (persistent kernels size their grid from it)
 static int wl_num_cus() {
@@ -39,7 +42,7 @@ template <typename K>
 static int wl_launch(const typename K::Args& a, int64_t nblocks, size_t lds, void* stream) {
     if (nblocks <= 0) return 0;
     if (nblocks > 2147483647LL || lds > 160 * 1024) return -2;
-    wl_last_kernel_ptr = __PRETTY_FUNCTION__;
+    wl_last_kernel_ptr.store(__PRETTY_FUNCTION__, std::memory_order_relaxed);
     if (lds > 48 * 1024) {
         // opt in to large dynamic LDS once per kernel (idempotent, cheap)
         static thread_local unsigned granted = 0;   // bit d: done for device d (the attribute is per device)

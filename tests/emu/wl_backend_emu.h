@@ -16,7 +16,7 @@
 
 // a deliberately tiny "chip" so that persistent kernels walk several tiles per workgroup in the tests
 static int wl_num_cus() { return 2; }
-static thread_local const char* wl_last_kernel_ptr = "";
+static const char* wl_last_kernel_ptr = "";
 static const char* wl_last_kernel_name() { return wl_last_kernel_ptr; }
 
 struct WlEmuBlock {
