@@ -174,6 +174,16 @@ int wl_scat_bwd_level1(const void* dz, const void* drdx, const void* drdy, void*
                        int H, int W, const void* h0, int L0, const void* h1, int L1, int mode, int combine_colour,
                        void* stream);
 
+/* ONE analysis level by the streaming strip kernel (csrc/wl_dwt_strip.h): the same operator as wl_dwt2d_analysis_strided
+ * (AFB2D.forward, dwt/lowlevel.py:336-347) for one square filter length L (even, <= 20), float32 / float16, every mode, rows
+ * of any width that are a whole number of 16-byte pieces: every input sample is read once per column strip and row
+ * segment, by LDS-DMA.  policy 0 = the engine decides whether the launch pays (enough workgroups for the chip), 1 = force.
+ * Returns WL_ERR_UNSUPPORTED outside its envelope (callers then use wl_dwt2d_analysis_strided). */
+int wl_dwt2d_analysis_stream(const void* x, int64_t x_plane_stride, int x_row_stride, void* ll, int64_t ll_plane_stride,
+                             int ll_row_stride, void* highs, int dtype, int64_t planes, int H, int W, const void* h_w_lo,
+                             const void* h_w_hi, const void* h_h_lo, const void* h_h_hi, int L, int mode, int policy,
+                             void* stream);
+
 /* Gradients of the two non-separable banks, as autograd gives them upstream (where afb2d_nonsep / sfb2d_nonsep are
  * plain differentiable ATen chains, dwt/lowlevel.py:524-597, :746-798):
  *   wl_dwt2d_analysis_nonsep_bwd : dy (planes,4,Kh,Kw) -> dx (planes,H,W), the adjoint of the boundary gather + strided

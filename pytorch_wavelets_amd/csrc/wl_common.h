@@ -142,6 +142,81 @@ void wl_emu_wait_vm(int n);
 template <int N> inline void wl_wait_vm() { wl_emu_wait_vm(N); }
 #endif
 
+#define WL_IROWS_MAX_VM 48      // DMA instructions a loader wave may have outstanding (range of wl_wait_vm_dyn)
+#if defined(__HIPCC__)
+WL_DEV void wl_fail() { __builtin_trap(); }
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n in [0, 48].  The count is an immediate, and both a switch and a
+// hand-written decision tree come out of the compiler as a chain through every case (hundreds of cycles per
+// half-batch in the loader waves, which every other wave then waits for at the barrier): a computed jump into a table
+// of (s_waitcnt, s_branch) pairs instead - 8 bytes per entry, the table starts 20 bytes behind the s_getpc.
+WL_DEV void wl_wait_vm_dyn(int n) {
+    static_assert(WL_IROWS_MAX_VM == 48, "the table below has 49 entries");
+    int t = n < WL_IROWS_MAX_VM ? n : WL_IROWS_MAX_VM;
+    asm volatile(
+        "s_getpc_b64 vcc\n\t"
+        "s_lshl_b32 %0, %0, 3\n\t"
+        "s_add_u32 %0, %0, 20\n\t"
+        "s_add_u32 vcc_lo, vcc_lo, %0\n\t"
+        "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+        "s_setpc_b64 vcc\n\t"
+        "s_waitcnt vmcnt(0)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(1)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(2)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(3)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(4)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(5)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(6)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(7)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(8)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(9)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(10)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(11)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(12)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(13)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(14)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(15)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(16)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(17)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(18)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(19)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(20)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(21)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(22)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(23)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(24)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(25)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(26)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(27)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(28)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(29)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(30)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(31)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(32)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(33)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(34)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(35)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(36)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(37)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(38)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(39)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(40)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(41)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(42)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(43)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(44)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(45)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(46)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(47)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        "s_waitcnt vmcnt(48)\n\ts_branch .Lwl_vm_end_%=\n\t"
+        ".Lwl_vm_end_%=:"
+        : "+s"(t) : : "memory", "vcc", "scc");
+}
+#else
+inline void wl_fail() { abort(); }
+inline void wl_wait_vm_dyn(int n) { wl_emu_wait_vm(n < WL_IROWS_MAX_VM ? n : WL_IROWS_MAX_VM); }
+#endif
+
+
 // ---------------------------------------------------------------------------------------------
 // Boundary extension: extended position i of a length-n signal -> source position, or -1 for a
 // zero sample.  Closed forms of SURVEY.md §8 (reference: dwt/lowlevel.py:28-88, utils.py:146-174).

@@ -1,0 +1,452 @@
+// Streaming ONE-level 2-D DWT analysis over column strips: the streaming design of wl_dwt_rows.h for everything its
+// fused multi-level form cannot take - rows wider than one workgroup's lanes (1024, 2048, 4096 columns), 14 to 20 taps,
+// periodization (rows and columns wrap), odd filter-bank offsets, float16 planes of any width, few planes.
+//
+// A workgroup owns one (plane, column strip, row segment) and marches down it once:
+//   * two STAGER waves bring every input row of the strip in by LDS-DMA (global_load_lds_dwordx4, 16-byte pieces, three
+//     half-batches ahead, counted waits) into a private ring in the input's own type.  A piece is a run of 16 bytes of
+//     the EXTENDED row: for the wrapping modes (periodic, periodization) the pieces beyond either end of the row simply
+//     come from the other end - a row is a whole number of pieces, so wrapping is per-piece address arithmetic, resolved
+//     once per lane - and a strip in the middle of the row gets its halo columns from its neighbours' columns;
+//   * the same waves then STAGE the rows they loaded: float32 copies (the float16 -> float32 conversion happens here,
+//     once per sample instead of once per tap) into a two-slot ring whose origin is chosen so that every compute lane
+//     reads its samples as whole, conflict-free 16-byte words; the mirrored cells of symmetric / reflect extension
+//     are written here too, zero padding is cells (and rows) that stay zero;
+//   * a compute lane owns TWO adjacent output columns.  Per pair of new rows it reads 2 x ceil((L+2)/4) 16-byte words (its
+//     L+2 samples - the two columns share L-2 of them), runs the row filter for both columns (v_pk_fma_f32 on (lo,hi)
+//     tap pairs held in scalar registers, the sample picked by op_sel) into an L-row window held in registers, and the
+//     column filter from the window: 4L packed FMAs per output sample pair of each sub-band quadruple and no other
+//     arithmetic.  The window is a circular buffer whose rotation is compile-time: the loop over half-batches is
+//     unrolled by the rotation period, so no register is ever moved;
+//   * the four sub-bands leave as pairs (8 / 4 contiguous bytes per lane), whole strip rows per half-batch.
+// HBM traffic = the strip's columns once + (L-2) halo columns per strip and (L-2) halo rows per segment + the outputs.
+// One level per launch: LL goes to HBM (a J-level transform on this kernel moves 1.33x the bytes of the fused kernel,
+// which remains the path for up to 12 taps on rows of up to ~630 outputs).
+//
+// Restates AFB2D.forward (reference dwt/lowlevel.py:336-347 = afb1d along W, then along H, :91-172), every mode.
+#pragma once
+#include "wl_common.h"
+#include "wl_dwt_rows.h"   // wl_pk_fma_x / _y, wl_pk_mul_x / _y, wl_uniform_v2
+
+#ifndef WL_STRIP_CWAVES
+#define WL_STRIP_CWAVES 4
+#endif
+// compute waves (two output columns per lane: up to 512 output columns per strip)
+#ifndef WL_STRIP_SWAVES
+#define WL_STRIP_SWAVES 4       // stager waves: each loads and stages 4 / SWAVES of the 4 rows of a half-batch (one wave alone is
+                                // latency-bound: with two stagers the staging took longer than the arithmetic, with four it hides)
+#endif
+#ifndef WL_STRIP_ABLATE
+#define WL_STRIP_ABLATE 0       // measurement builds only (tools/build_ab_strip.sh): 1 = no arithmetic / stores in the compute
+#endif                          // waves, 2 = the stagers load but do not stage
+#ifndef WL_STRIP_D
+#define WL_STRIP_D 3            // half-batches of LDS-DMA in flight = slots of the DMA ring
+#endif
+#if (WL_STRIP_ABLATE & 8) && defined(__HIPCC__)
+#define WL_STICK() __builtin_readcyclecounter()
+#else
+#define WL_STICK() 0ull
+#endif
+#define WL_STRIP_MAXPPR 5       // 1 KiB DMA instructions per row at most (strip rows of up to 5 KiB)
+
+template <typename T>
+struct WlStripArgs {
+    const T* x;                    // (NC, H, W) through x_ps / x_rs
+    T* ll;                         // (NC, Kh, Kw) through ll_ps / ll_rs
+    T* highs;                      // (NC, 3, Kh, Kw) dense
+    const float* h_w_lo;
+    const float* h_w_hi;
+    const float* h_h_lo;
+    const float* h_h_hi;
+    int64_t NC, x_ps, ll_ps, nblocks;
+    int x_rs, ll_rs;
+    int H, W, Kh, Kw, ext, base;
+    int nstrips, strip_cols;       // output columns per strip (even); the last strip may be narrower
+    int nseg, seg_rows;            // output rows per segment; the last segment may be shorter
+    int dma_off, dma_pitch;        // DMA ring: WL_STRIP_D slots x 4 rows x dma_pitch bytes (input type)
+    int st_off, st_pitch;          // staged ring: 2 slots x 4 rows x st_pitch bytes (float32)
+    int lds_bytes;
+    int pair_ok;                   // every output-column pair of every band row is one aligned 2-element store (even Kw, ll_rs)
+};
+
+template <typename T, int LT>
+struct WlAfbStrip {
+    typedef WlStripArgs<T> Args;
+    static const int kWaves = WL_STRIP_CWAVES + WL_STRIP_SWAVES;
+    static const int kThreads = 64 * kWaves;
+    static const int kMinWaves = LT >= 18 ? 3 : 4;   // two 8-wave workgroups per CU need four waves per SIMD: at most 128 registers (18, 20 taps: 168)
+    static const int SZ = (int)sizeof(T);
+    static const int A = 16 / SZ;          // elements per 16-byte piece
+    static const int WARM = (LT - 2) / 2;  // feeds that only fill the window
+    static const int LW = (LT + 3) / 4 * 4;            // window slots: a multiple of the 4 rows of a half-batch
+    static const int PERIOD = LW / 4;      // half-batches after which the circular window is back where it started
+    static const int NV4 = (LT + 2 + 3) / 4;           // 16-byte words a lane reads per row: its L+2 samples
+    static const int D = WL_STRIP_D;
+    static const bool kPipe = LT >= 14;    // see compute(): when the rows of a half-batch's second feed are requested
+    static const int LROWS = 4 / WL_STRIP_SWAVES;
+
+    // geometry of one workgroup's strip, derived by every wave from the strip index (wave-uniform)
+    struct Strip {
+        int k0, k1;            // output columns [k0, k1)
+        int e_lo;              // first extended column a lane reads = 2 k0 + base
+        int c0a;               // extended column of DMA-ring cell 0 (a multiple of A, <= e_lo)
+        int np;                // 16-byte pieces per DMA-ring row (up to the last one that is loaded)
+        int ppr;               // DMA instructions per row
+        int ng;                // 4-cell groups per DMA-ring row
+        int dm;                // (e_lo - c0a) mod 4
+        int lane_off;          // staged-ring byte offset of the first sample of output-column pair 0
+        int o_lo, o_hi;        // output rows [o_lo, o_hi) of this segment
+        int nfeeds, nhb;
+    };
+    static WL_HD bool wraps(int ext) { return ext == WL_EXT_PERIODIC || ext == WL_EXT_PER; }
+    static WL_HD Strip geometry(const Args& a, int strip, int seg) {
+        Strip s;
+        s.k0 = strip * a.strip_cols;
+        s.k1 = s.k0 + a.strip_cols < a.Kw ? s.k0 + a.strip_cols : a.Kw;
+        s.e_lo = 2 * s.k0 + a.base;
+        const int e_hi = 2 * (s.k1 - 1) + a.base + LT - 1 + 2;          // (+2: a lane always reads both its columns' samples)
+        s.c0a = s.e_lo >= 0 ? s.e_lo / A * A : -((-s.e_lo + A - 1) / A * A);
+        int last = e_hi;                                                 // last extended column that arrives by DMA
+        if (!wraps(a.ext) && last > a.W - 1) last = a.W - 1;
+        s.np = (last - s.c0a) / A + 1;
+        s.ppr = (s.np + 63) / 64;
+        s.ng = s.np * A / 4;
+        const int d = s.e_lo - s.c0a;
+        s.dm = d & 3;
+        s.lane_off = (d - s.dm + 4) * 4;
+        s.o_lo = seg * a.seg_rows;
+        s.o_hi = s.o_lo + a.seg_rows < a.Kh ? s.o_lo + a.seg_rows : a.Kh;
+        s.nfeeds = s.o_hi - s.o_lo + WARM;
+        s.nhb = (s.nfeeds + 1) / 2;
+        return s;
+    }
+    // staged-ring cell index of DMA-ring cell c (both along one row)
+    static WL_HD int staged_of(const Strip& s, int c) { return c + 4 - s.dm; }
+
+    // ---- stager wave --------------------------------------------------------------------------------------------
+    // One row, DMA ring -> staged ring: this lane's groups i in [imin, imax) (group = 4 cells; source at srow + i * 256 SZ,
+    // destination at drow + i * 1024), six at a time: the LDS reads of a batch are all in flight before the first
+    // conversion (a wave alone hides no latency otherwise), reads and conversions are unconditional (a read beyond the row
+    // stays inside the rings), only the writes are predicated.  DM = (e_lo - c0a) mod 4 decides how a group meets the
+    // 16-byte words of the staged row: 0 one ds_write_b128, 2 two ds_write_b64, odd b32 + b64 + b32; DM 4 = a row of zeros.
+    template <int DM>
+    static WL_DEV void stage_row(const char* srow, char* drow, int imin, int imax, int ngl) {
+        typedef T Quad4 __attribute__((ext_vector_type(4), may_alias));
+        for (int i0 = 0; i0 < ngl; i0 += 6) {
+            Quad4 raw[6];
+            if (DM != 4) {
+#pragma unroll
+                for (int u = 0; u < 6; ++u)
+                    if (i0 + u < ngl) raw[u] = *reinterpret_cast<const Quad4*>(srow + (i0 + u) * 256 * SZ);
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                if (i0 + u >= ngl) break;
+                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+                if (DM != 4) { v0 = (float)raw[u].x; v1 = (float)raw[u].y; v2 = (float)raw[u].z; v3 = (float)raw[u].w; }
+                if (i0 + u >= imin && i0 + u < imax) {
+                    float* dst = reinterpret_cast<float*>(drow + (i0 + u) * 1024);
+                    if (DM == 0) {
+                        wl_vf4 w; w.x = v0; w.y = v1; w.z = v2; w.w = v3;
+                        *reinterpret_cast<wl_vf4*>(dst) = w;
+                    } else if (DM == 2) {
+                        wl_f2 w0, w1; w0.x = v0; w0.y = v1; w1.x = v2; w1.y = v3;
+                        *reinterpret_cast<wl_f2*>(dst) = w0; *reinterpret_cast<wl_f2*>(dst + 2) = w1;
+                    } else if (DM == 1) {                     // odd: the middle two cells are 8-byte aligned
+                        wl_f2 w; w.x = v1; w.y = v2;
+                        dst[0] = v0; *reinterpret_cast<wl_f2*>(dst + 1) = w; dst[3] = v3;
+                    } else {                                  // zeros, any alignment
+                        dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f; dst[3] = 0.f;
+                    }
+                }
+            }
+        }
+    }
+
+    static WL_DEV void stager(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int lane, int sidx) {
+        const char* xp = reinterpret_cast<const char*>(a.x + (size_t)plane * a.x_ps);
+        const int row_stride = a.x_rs * SZ;
+        const bool wrap = wraps(a.ext);
+        const int We = a.W;                                   // (wrapping modes need an even W: the launcher checks)
+        const int e_first = a.base + 2 * s.o_lo;              // extended row of the segment's first feed
+        const int e_last = a.base + 2 * (s.o_lo + s.nfeeds) - 1;
+        const int rfirst = sidx * LROWS;
+        // per lane: source byte (inside a row) of its piece in each of the ppr DMA instructions of a row; -1 = off
+        int gbyte[WL_STRIP_MAXPPR];
+#pragma unroll
+        for (int q = 0; q < WL_STRIP_MAXPPR; ++q) {
+            const int p = q * 64 + lane;
+            int col = s.c0a + p * A;
+            bool on = q < s.ppr && p < s.np;
+            if (on && (unsigned)col >= (unsigned)a.W) {
+                if (wrap) col = wl_pmod(col, We); else on = false;
+            }
+            gbyte[q] = on ? col * SZ : -1;
+        }
+        // mirrored cells (symmetric / reflect, strips at either edge): item = (row r of my rows, cell); a lane handles
+        // items lane and lane + 64.  dst = staged cell, src = DMA-ring cell, both as byte offsets inside my rows' block.
+        int hdst[2], hsrc[2];
+        {
+            const int e_hi = 2 * (s.k1 - 1) + a.base + LT - 1 + 2;
+            const int nl = s.e_lo < 0 ? -s.e_lo : 0;                              // extended columns left of the row
+            const int nr = e_hi > a.W - 1 ? e_hi - (a.W - 1) : 0;                 // and right of it
+            const int NH = (a.ext == WL_EXT_SYM || a.ext == WL_EXT_REFL) ? nl + nr : 0;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int it = lane + 64 * u;
+                hdst[u] = hsrc[u] = -1;
+                if (it < LROWS * NH) {
+                    const int r = it / NH, c = it - r * NH;
+                    const int e = c < nl ? s.e_lo + c : a.W + (c - nl);
+                    const int src = wl_ext(e, a.W, a.ext);
+                    hdst[u] = r * a.st_pitch + staged_of(s, e - s.c0a) * 4;
+                    hsrc[u] = r * a.dma_pitch + (src - s.c0a) * SZ;
+                }
+            }
+        }
+        auto issue = [&](int h) {
+            const int slot = a.dma_off + (h % D) * 4 * a.dma_pitch;
+#pragma unroll
+            for (int rr = 0; rr < LROWS; ++rr) {
+                const int r = rfirst + rr;
+                int e = e_first + 4 * h + r;
+                e = e < e_last ? e : e_last;
+                int src = e;
+                if ((unsigned)e >= (unsigned)a.H) {
+                    src = wl_ext(e, a.H, a.ext);
+                    src = src < 0 ? 0 : src;                  // zero rows: a dummy row keeps the DMA count exact
+                }
+                const char* grow = xp + (size_t)src * row_stride;
+#pragma unroll
+                for (int q = 0; q < WL_STRIP_MAXPPR; ++q)
+                    if (q < s.ppr) wl_dma16(ctx, (unsigned)(slot + r * a.dma_pitch + q * 1024), grow + gbyte[q], gbyte[q] >= 0);
+            }
+        };
+        const int nl_inst = LROWS * s.ppr;                    // DMA instructions per half-batch of this wave
+        // the 4-cell groups of a DMA-ring row that hold loaded data: [g_lo, g_hi); this lane owns groups lane + 64 i,
+        // i in [imin, imax)
+        const int ngl = (s.ng + 63) >> 6;
+        int imin, imax;
+        {
+            int g_lo = 0, g_hi = s.ng;
+            if (!wrap) {
+                if (s.c0a < 0) g_lo = (-s.c0a + 3) / 4;
+                const int lim = (a.W - s.c0a) / 4;            // (W and c0a are multiples of 4)
+                if (lim < g_hi) g_hi = lim;
+            }
+            imin = g_lo > lane ? (g_lo - lane + 63) / 64 : 0;
+            imax = g_hi > lane ? (g_hi - lane + 63) / 64 : 0;
+        }
+        for (int h = 0; h < D && h < s.nhb; ++h) issue(h);
+        int inflight = (D < s.nhb ? D : s.nhb);               // half-batches issued and not yet waited for
+        unsigned long long tw = 0, tg = 0, tb = 0, ti = 0;
+        for (int hb = 0; hb < s.nhb; ++hb) {
+            const unsigned long long c0 = WL_STICK();
+            wl_wait_vm_dyn((inflight - 1) * nl_inst);         // my rows of this half-batch have landed
+            --inflight;
+            const unsigned long long c1 = WL_STICK();
+            // stage my rows: DMA slot -> staged slot (float32, origin shifted so that lanes read aligned 16-byte words)
+            char* dslot = ctx.smem + a.dma_off + (hb % D) * 4 * a.dma_pitch + rfirst * a.dma_pitch;
+            char* sslot = ctx.smem + a.st_off + (hb & 1) * 4 * a.st_pitch + rfirst * a.st_pitch;
+            bool zrow[LROWS];
+#pragma unroll
+            for (int rr = 0; rr < LROWS; ++rr) {
+                int e = e_first + 4 * hb + rfirst + rr;
+                e = e < e_last ? e : e_last;
+                zrow[rr] = a.ext == WL_EXT_ZERO && (unsigned)e >= (unsigned)a.H;
+            }
+            // a lane stages the 4-cell groups lane, lane + 64, .. of each of its rows (see stage_row)
+            if (!(WL_STRIP_ABLATE & 2)) {
+#pragma unroll
+                for (int rr = 0; rr < LROWS; ++rr) {
+                    const char* srow = dslot + rr * a.dma_pitch + lane * 4 * SZ;
+                    char* drow = sslot + rr * a.st_pitch + lane * 16 + (4 - s.dm) * 4;
+                    if (zrow[rr]) stage_row<4>(srow, drow, imin, imax, ngl);
+                    else if (s.dm == 0) stage_row<0>(srow, drow, imin, imax, ngl);
+                    else if (s.dm == 2) stage_row<2>(srow, drow, imin, imax, ngl);
+                    else stage_row<1>(srow, drow, imin, imax, ngl);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (hdst[u] >= 0) *reinterpret_cast<float*>(sslot + hdst[u]) = (float)*reinterpret_cast<const T*>(dslot + hsrc[u]);
+            const unsigned long long c2 = WL_STICK();
+            ctx.sync();
+            const unsigned long long c3 = WL_STICK();
+            if (hb + D < s.nhb) { issue(hb + D); ++inflight; }   // into the slot staged just now (nobody else reads it)
+            tw += c1 - c0; tg += c2 - c1; tb += c3 - c2; ti += WL_STICK() - c3;
+        }
+        wl_wait_vm<0>();
+        if ((WL_STRIP_ABLATE & 8) && lane == 0 && sidx == 0 && s.k0 == 0 && s.o_lo == 0) {
+            T* o = a.ll + (size_t)plane * a.ll_ps;
+            o[8] = (T)(float)(tw >> 10); o[9] = (T)(float)(tg >> 10); o[10] = (T)(float)(tb >> 10); o[11] = (T)(float)(ti >> 10);
+        }
+    }
+
+    // ---- compute wave ---------------------------------------------------------------------------------------------
+    struct Wave {
+        wl_v2 tw[LT], th[LT];      // (lo,hi) tap pairs along W / along H (wave-uniform: scalar registers)
+        char* llp; char* hp0; char* hp1; char* hp2;
+        unsigned rowb, llrowb;
+        bool two, pair_ok;
+    };
+    // row filter of one staged row for both columns of the lane: s = its L+2 samples as (even, odd) pairs
+    static WL_DEV void row_pass(const Wave& R, const wl_v2 (&s)[2 * NV4], wl_v2& ra, wl_v2& rb) {
+        wl_v2 a0 = wl_pk_mul_x(R.tw[0], s[0]), b0 = wl_pk_mul_x(R.tw[0], s[1]);
+        wl_v2 a1 = wl_pk_mul_y(R.tw[1], s[0]), b1 = wl_pk_mul_y(R.tw[1], s[1]);
+#pragma unroll
+        for (int u = 1; u < LT / 2; ++u) {
+            wl_pk_fma_x(a0, R.tw[2 * u], s[u]);
+            wl_pk_fma_x(b0, R.tw[2 * u], s[u + 1]);
+            wl_pk_fma_y(a1, R.tw[2 * u + 1], s[u]);
+            wl_pk_fma_y(b1, R.tw[2 * u + 1], s[u + 1]);
+        }
+        ra = a0 + a1;
+        rb = b0 + b1;
+    }
+    // column filter over the circular window whose OLDEST row sits in slot `first` (compile-time after unrolling)
+    static WL_DEV void col_pass(const Wave& R, const wl_v2 (&w)[LW], int first, wl_v2& cl, wl_v2& ch) {
+        wl_v2 l0 = wl_pk_mul_x(R.th[0], w[first % LW]), h0 = wl_pk_mul_y(R.th[0], w[first % LW]);
+        wl_v2 l1 = wl_pk_mul_x(R.th[1], w[(first + 1) % LW]), h1 = wl_pk_mul_y(R.th[1], w[(first + 1) % LW]);
+#pragma unroll
+        for (int t = 2; t < LT; t += 2) {
+            wl_pk_fma_x(l0, R.th[t], w[(first + t) % LW]);
+            wl_pk_fma_y(h0, R.th[t], w[(first + t) % LW]);
+            wl_pk_fma_x(l1, R.th[t + 1], w[(first + t + 1) % LW]);
+            wl_pk_fma_y(h1, R.th[t + 1], w[(first + t + 1) % LW]);
+        }
+        cl = l0 + l1;
+        ch = h0 + h1;
+    }
+    static WL_DEV void load_row(const char* p, wl_v2 (&s)[2 * NV4]) {
+#pragma unroll
+        for (int u = 0; u < NV4; ++u) {
+            const wl_vf4 t = *reinterpret_cast<const wl_vf4*>(p + 16 * u);
+            s[2 * u] = wl_v2{t.x, t.y};
+            s[2 * u + 1] = wl_v2{t.z, t.w};
+        }
+    }
+    // the two columns of a lane: one aligned 2-element store when the geometry makes every pair aligned (even band
+    // width), else element stores (an odd band width has rows on odd element offsets and a last lane with one column)
+    static WL_DEV void store_pair(const Wave& R, char* p, float va, float vb) {
+        if (R.pair_ok) {
+            typedef T Vec2 __attribute__((ext_vector_type(2)));
+            Vec2 v = {(T)va, (T)vb};
+            *reinterpret_cast<Vec2*>(p) = v;
+        } else {
+            *reinterpret_cast<T*>(p) = (T)va;
+            if (R.two) *reinterpret_cast<T*>(p + SZ) = (T)vb;
+        }
+    }
+
+    static WL_DEV void compute(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int cw, int lane) {
+        const int jp = 64 * cw + lane;                        // column pair inside the strip
+        const int kA = s.k0 + 2 * jp;
+        const bool active = kA < s.k1;
+        Wave R;
+#pragma unroll
+        for (int t = 0; t < LT; ++t) {
+            R.tw[t] = wl_uniform_v2(wl_v2{a.h_w_lo[t], a.h_w_hi[t]});
+            R.th[t] = wl_uniform_v2(wl_v2{a.h_h_lo[t], a.h_h_hi[t]});
+        }
+        const unsigned bplane = (unsigned)a.Kh * (unsigned)a.Kw;
+        R.hp0 = reinterpret_cast<char*>(a.highs + (size_t)plane * 3 * bplane);
+        R.hp1 = R.hp0 + (size_t)bplane * SZ;
+        R.hp2 = R.hp1 + (size_t)bplane * SZ;
+        R.llp = reinterpret_cast<char*>(a.ll + (size_t)plane * a.ll_ps);
+        R.rowb = (unsigned)a.Kw * SZ; R.llrowb = (unsigned)a.ll_rs * SZ;
+        R.two = kA + 1 < s.k1;
+        R.pair_ok = a.pair_ok != 0;
+        const int soff = s.lane_off + 16 * (active ? jp : 0);
+        unsigned ob = (unsigned)s.o_lo * R.rowb + (unsigned)kA * SZ;          // this lane's next output sample in a band plane
+        unsigned obl = (unsigned)s.o_lo * R.llrowb + (unsigned)kA * SZ;
+        wl_v2 wa[LW], wb[LW];                                                 // circular windows of the two columns
+#pragma unroll
+        for (int t = 0; t < LW; ++t) wa[t] = wb[t] = wl_v2{0.f, 0.f};
+        char* const smem = ctx.smem;
+        int fed = 0;                                                          // feeds done (wave-uniform)
+        unsigned long long tbar = 0, tmath = 0;
+        for (int hb0 = 0; hb0 < s.nhb; hb0 += PERIOD) {
+#pragma unroll
+            for (int ph = 0; ph < PERIOD; ++ph) {
+                const int hb = hb0 + ph;
+                if (hb >= s.nhb) break;
+                const unsigned long long c0 = WL_STICK();
+                ctx.sync();
+                const unsigned long long c1 = WL_STICK();
+                tbar += c1 - c0;
+                const int left = s.nfeeds - fed;
+                const int n = left > 2 ? 2 : left;
+                const char* slot = smem + a.st_off + (hb & 1) * 4 * a.st_pitch + soff;
+                if (active && !(WL_STRIP_ABLATE & 1)) {
+                    // Short filters: all four rows of the half-batch are requested from LDS before the first FMA.  From 14
+                    // taps on the registers do not allow that at four waves per SIMD: the rows of the second feed are
+                    // requested behind the row filter of the first and land during its column filter.
+                    // (The last half-batch of a segment may hold one feed only: the other two rows are read and ignored.)
+                    wl_v2 sr[4][2 * NV4];
+                    load_row(slot, sr[0]);
+                    load_row(slot + a.st_pitch, sr[1]);
+                    if (!kPipe) { load_row(slot + 2 * a.st_pitch, sr[2]); load_row(slot + 3 * a.st_pitch, sr[3]); }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if (i < n) {
+                            const int w0 = (4 * ph + 2 * i) % LW;             // slots of the two new rows
+                            row_pass(R, sr[2 * i], wa[w0], wb[w0]);
+                            row_pass(R, sr[2 * i + 1], wa[(w0 + 1) % LW], wb[(w0 + 1) % LW]);
+                            if (kPipe && i == 0) { load_row(slot + 2 * a.st_pitch, sr[2]); load_row(slot + 3 * a.st_pitch, sr[3]); }
+                            if (fed + i >= WARM) {
+                                // the L rows of this output end with the two new ones: the oldest sits LT-1 slots back
+                                const int first = (w0 + 1 + LW - (LT - 1)) % LW;
+                                wl_v2 cla, cha, clb, chb;
+                                col_pass(R, wa, first, cla, cha);
+                                col_pass(R, wb, first, clb, chb);
+                                if (!(WL_STRIP_ABLATE & 4) || cla.x + clb.y + cha.x + chb.y == 1.2345e30f) {
+                                    store_pair(R, R.llp + obl, cla.x, clb.x);
+                                    store_pair(R, R.hp0 + ob, cla.y, clb.y);
+                                    store_pair(R, R.hp1 + ob, cha.x, chb.x);
+                                    store_pair(R, R.hp2 + ob, cha.y, chb.y);
+                                }
+                                ob += R.rowb; obl += R.llrowb;
+                            }
+                        }
+                    }
+                }
+                fed += n;
+                tmath += WL_STICK() - c1;
+            }
+        }
+        if ((WL_STRIP_ABLATE & 8) && lane == 0 && cw == 0 && s.k0 == 0 && s.o_lo == 0) {
+            T* o = a.ll + (size_t)plane * a.ll_ps;
+            o[0] = (T)(float)(tbar >> 10); o[1] = (T)(float)(tmath >> 10);
+        }
+    }
+
+    static WL_DEV void run(const Args& a, const WlCtx& ctx) {
+        const int tid = ctx.tid;
+        const int wave = wl_uniform(tid >> 6), lane = tid & 63;
+        // workgroup -> (plane, segment, strip): strips of one plane and segment are neighbours on the same XCD (they
+        // share halo columns), segments next
+        const int64_t lbid = wl_xcd_remap(ctx.bid, a.nblocks);
+        const int per_plane = a.nstrips * a.nseg;
+        const int64_t plane = lbid / per_plane;
+        const int rem = (int)(lbid - plane * per_plane);
+        const int seg = rem / a.nstrips, strip = rem - seg * a.nstrips;
+        const Strip s = geometry(a, strip, seg);
+        // LDS starts as zeros: staged cells nobody writes are the zero padding
+        for (int i = tid * 16; i < a.lds_bytes; i += kThreads * 16) {
+            wl_f4 z; z.x = z.y = z.z = z.w = 0.f;
+            *reinterpret_cast<wl_f4*>(ctx.smem + i) = z;
+        }
+        ctx.sync();
+        if (wave >= WL_STRIP_CWAVES) {
+#if defined(__HIPCC__)
+            __builtin_amdgcn_s_setprio(2);   // every compute wave waits for the stagers at the barrier
+#endif
+            stager(a, s, ctx, plane, lane, wave - WL_STRIP_CWAVES);
+        } else if (64 * 2 * wave < s.k1 - s.k0) {
+            compute(a, s, ctx, plane, wave, lane);
+        } else {
+            for (int hb = 0; hb < s.nhb; ++hb) ctx.sync();   // spare wave (narrow strip): keeps the barrier count
+        }
+    }
+};

@@ -51,7 +51,7 @@ class AFB2D(Function):
         ctx.save_for_backward(h0_row, h1_row, h0_col, h1_col)
         ctx.shape = x.shape[-2:]
         ctx.mode = mode
-        return ops.afb2d(x, h0_row, h1_row, h0_col, h1_col, mode)
+        return ops.afb2d_best(x, h0_row, h1_row, h0_col, h1_col, mode)
 
     @staticmethod
     @once_differentiable
@@ -83,7 +83,7 @@ class SFB2D(Function):
         dlow, dhigh = None, None
         if ctx.needs_input_grad[0] or (ctx.has_highs and ctx.needs_input_grad[1]):
             g0_row, g1_row, g0_col, g1_col = ctx.saved_tensors
-            dlow, dhigh = ops.afb2d(dy, g0_row, g1_row, g0_col, g1_col, ctx.mode)
+            dlow, dhigh = ops.afb2d_best(dy, g0_row, g1_row, g0_col, g1_col, ctx.mode)
             if not ctx.has_highs:
                 dhigh = None
         return dlow, dhigh, None, None, None, None, None
@@ -147,7 +147,7 @@ class SFB2DMulti(Function):
             g0_row, g1_row, g0_col, g1_col = ctx.saved_tensors
             d = dy
             for j in range(J):
-                d, dhigh = ops.afb2d(d, g0_row, g1_row, g0_col, g1_col, ctx.mode)
+                d, dhigh = ops.afb2d_best(d, g0_row, g1_row, g0_col, g1_col, ctx.mode)
                 if ctx.has_highs[j] and ctx.needs_input_grad[6 + j]:
                     grads[j] = dhigh
                 full = ctx.ll_shapes[j]
@@ -188,7 +188,7 @@ class AFB2DMulti(Function):
             if res is None:
                 n = 1
                 shapes.append(tuple(ll.shape[-2:]))
-                ll, high = ops.afb2d(ll, h0_row, h1_row, h0_col, h1_col, mode, pad_ll=_PAD_LL and done + 1 < J)
+                ll, high = ops.afb2d_best(ll, h0_row, h1_row, h0_col, h1_col, mode, pad_ll=_PAD_LL and done + 1 < J)
                 yh.append(high)
             else:
                 shapes.append(tuple(ll.shape[-2:]))

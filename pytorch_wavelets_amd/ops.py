@@ -163,6 +163,7 @@ def sfb2d(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None):
 
 
 _CU_COUNT = {}
+STREAM_FORCE = False   # tests: send every single-level analysis the strip kernel covers to it, whatever the shape
 FUSED_STRIPS = 0   # default `strips` of the two streaming entry points below: 0 = the engine's policy (the planes must fill
                    # the chip), 1 / 2 = force the streaming kernels whatever the batch (tests pin their backward passes so)
 # configurations the streaming launchers declined (WL_ERR_UNSUPPORTED for reasons only they can see: rows wider than the
@@ -269,6 +270,44 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
         return None
     _lib.check(rc, 'wl_dwt2d_synthesis_fused')
     return y
+
+
+def afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=False):
+    """One analysis level on the streaming strip kernel (wl_dwt2d_analysis_stream): x (N,C,H,W) -> (ll, highs) like afb2d,
+    or None when the kernel does not cover the configuration (rows that are not whole 16-byte pieces, odd tap counts,
+    float64, too few workgroups to fill the chip unless `force`)."""
+    _check_tensor(x, 'x')
+    N, C, H, W = x.shape
+    L = h_w_lo.numel()
+    es = x.element_size()
+    if (x.dtype == torch.float64 or h_h_lo.numel() != L or L % 2 or L > 20 or (W * es) % 16 or W < 2 * L or H < 2
+            or x.numel() == 0 or (mode == 2 and (H + (H & 1) < L - 1 or W + (W & 1) < L - 1))):
+        return None
+    if not force and W * es < 2048:
+        return None                      # the engine's policy: narrower rows stay on the tile kernels
+    x, x_ps, x_rs = _planes(x)
+    key = ('afbs', x.device, x.dtype, N * C, H, W, x_ps, x_rs, L, mode, bool(force))
+    if key in _FUSED_DECLINED or x.data_ptr() % 16 or (x_rs * es) % 16 or (x_ps * es) % 16:
+        return None
+    hwl, hwh, hhl, hhh = (_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi))
+    Kh, Kw = coeff_len(H, L, mode), coeff_len(W, L, mode)
+    ll = torch.empty((N, C, Kh, Kw), dtype=x.dtype, device=x.device)
+    highs = torch.empty((N, C, 3, Kh, Kw), dtype=x.dtype, device=x.device)
+    rc = _call('wl_dwt2d_analysis_stream', x, x.data_ptr(), x_ps, x_rs, ll.data_ptr(), Kh * Kw, Kw, highs.data_ptr(),
+               _DTYPES[x.dtype], N * C, H, W, hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(), hhh.data_ptr(), L, mode,
+               1 if force else 0, _stream(x))
+    if rc == -3:
+        _FUSED_DECLINED.add(key)
+        return None
+    _lib.check(rc, 'wl_dwt2d_analysis_stream')
+    return ll, highs
+
+
+def afb2d_best(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, pad_ll=False):
+    """One analysis level on whichever single-level kernel the engine prefers for the shape: the streaming strip kernel
+    (rows of 2 KiB and more, enough workgroups for the chip), else the tile kernels."""
+    res = afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=STREAM_FORCE)
+    return res if res is not None else afb2d(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, pad_ll=pad_ll)
 
 
 def afb2d_nonsep(x, filts, mode):

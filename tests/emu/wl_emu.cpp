@@ -2,3 +2,4 @@
 #include "wl_backend_emu.h"
 #include "../../pytorch_wavelets_amd/csrc/wl_api.inc"
 #include "../../pytorch_wavelets_amd/csrc/wl_rows_api.inc"
+#include "../../pytorch_wavelets_amd/csrc/wl_strip_api.inc"

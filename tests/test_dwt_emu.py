@@ -383,3 +383,78 @@ def test_grayscale_channels_last_strides_are_not_trusted(fused):
             assert torch.equal(r1, r2) and float((r1 - x).abs().max()) < 1e-10
     finally:
         ll.FUSED_LEVELS = prev
+
+
+STRIP_CASES = [('db4', 'symmetric', (2, 1, 64, 64)), ('db4', 'zero', (1, 2, 40, 72)), ('db8', 'periodization', (1, 1, 64, 128)),
+               ('db2', 'reflect', (1, 1, 33, 48)), ('db3', 'periodic', (1, 1, 50, 64)), ('haar', 'zero', (1, 1, 16, 16)),
+               ('db8', 'periodization', (1, 1, 37, 1024)), ('db10', 'symmetric', (1, 1, 70, 600)), ('db6', 'periodization', (1, 1, 37, 96)),
+               ('db4', 'symmetric', (1, 1, 300, 1320)), ('db7', 'reflect', (1, 1, 64, 256)), ('db9', 'zero', (1, 1, 64, 256))]
+
+
+@pytest.mark.parametrize('wave,mode,shape', STRIP_CASES)
+def test_strip_streaming_analysis_kernel_vs_oracle(wave, mode, shape):
+    """wl_dwt2d_analysis_stream (csrc/wl_dwt_strip.h) on the emulator: every mode, 2-20 taps, one and several column
+    strips / row segments, wrapped and mirrored halos, odd filter-bank offsets; float32 storage (the kernel's arithmetic
+    type) against the float64 oracle."""
+    from pytorch_wavelets_amd import filters, ops
+    from pytorch_wavelets_amd.dwt import lowlevel as ll
+    from oracle import wavelet_oracle as wo
+    rng = np.random.RandomState(5)
+    h0, h1 = filters.dwt_analysis_taps(wave)
+    x = rng.randn(*shape).astype(np.float32)
+    th = [torch.tensor(np.asarray(v), dtype=torch.float32) for v in (h0, h1, h0, h1)]
+    with emu_backend.emulated():
+        res = ops.afb2d_stream(torch.tensor(x), *th, ll.mode_to_int(mode), force=True)
+        assert res is not None and 'WlAfbStrip' in pw.last_kernel()
+    oyl, oyh = wo.dwt_forward(x.astype(np.float64), 1, h0, h1, h0, h1, mode)
+    assert np.abs(res[0].numpy() - oyl).max() < 2e-6 * np.abs(oyl).max()
+    assert np.abs(res[1].numpy() - oyh[0]).max() < 2e-6 * np.abs(oyh[0]).max()
+
+
+def test_strip_kernel_float16_and_strided_input_and_declines():
+    from pytorch_wavelets_amd import filters, ops
+    from oracle import wavelet_oracle as wo
+    rng = np.random.RandomState(6)
+    h0, h1 = filters.dwt_analysis_taps('db8')
+    th = [torch.tensor(np.asarray(v), dtype=torch.float32) for v in (h0, h1, h0, h1)]
+    x = torch.tensor(rng.randn(1, 2, 48, 2048)).half()
+    with emu_backend.emulated():
+        res = ops.afb2d_stream(x, *th, 2, force=True)                      # config-5 geometry: periodization, odd offset
+        assert res is not None and res[0].dtype == torch.float16
+        oyl, oyh = wo.dwt_forward(x.double().numpy(), 1, h0, h1, h0, h1, 'periodization')
+        assert np.abs(res[0].double().numpy() - oyl).max() < 2e-3 * np.abs(oyl).max()
+        assert np.abs(res[1].double().numpy() - oyh[0]).max() < 2e-3 * np.abs(oyh[0]).max()
+        # a row-padded view (16-byte row pitch): read in place
+        xp = torch.zeros(1, 2, 40, 80, dtype=torch.float32)
+        xv = xp[..., :64]
+        xv.copy_(torch.tensor(rng.randn(1, 2, 40, 64), dtype=torch.float32))
+        r2 = ops.afb2d_stream(xv, *th, 1, force=True)
+        o2 = wo.dwt_forward(xv.double().numpy(), 1, h0, h1, h0, h1, 'symmetric')
+        assert r2 is not None and np.abs(r2[0].numpy() - o2[0]).max() < 2e-6 * np.abs(o2[0]).max()
+        # outside the envelope: odd width (rows that are not whole 16-byte pieces), float64, the engine's own policy
+        assert ops.afb2d_stream(torch.randn(1, 1, 32, 63, dtype=torch.float32), *th, 1, force=True) is None
+        assert ops.afb2d_stream(torch.randn(1, 1, 32, 64).double(), *th, 1, force=True) is None
+        assert ops.afb2d_stream(torch.randn(1, 1, 32, 64, dtype=torch.float32), *th, 1) is None   # rows under 2 KiB: tile kernels
+        assert ops.afb2d_stream(torch.randn(1, 1, 32, 64, dtype=torch.float32), *th, 1, force=True) is not None
+
+
+def test_modules_use_the_strip_kernel_for_wide_rows(monkeypatch):
+    """DWTForward on rows of 2 KiB: the levels the fused kernel declines (16 taps) run on the strip kernel; values and the
+    reference's backward against the per-level tile path."""
+    from pytorch_wavelets_amd import ops
+    torch.manual_seed(4)
+    x = torch.randn(2, 1, 40, 512, dtype=torch.float32)
+    xfm = pw.DWTForward(J=2, wave='db8', mode='symmetric').float()
+    with emu_backend.emulated():
+        xa = x.clone().requires_grad_(True)
+        yl, yh = xfm(xa)
+        k = pw.last_kernel()
+        monkeypatch.setattr(ops, 'afb2d_stream', lambda *a, **k: None)
+        xb = x.clone().requires_grad_(True)
+        yl2, yh2 = xfm(xb)
+        assert 'WlAfbStrip' not in pw.last_kernel()
+        g = torch.randn_like(yl)
+        (yl * g).sum().backward()
+        (yl2 * g).sum().backward()
+    assert float((yl - yl2).abs().max()) < 1e-5 and all(float((a - b).abs().max()) < 1e-5 for a, b in zip(yh, yh2))
+    assert float((xa.grad - xb.grad).abs().max()) < 1e-5

@@ -205,15 +205,17 @@ def test_fp16_config5_reference_golden():
 
 @pytest.mark.parametrize('W', [2048, 2046])
 def test_fp16_config5_full_plane_size(W):
-    """configs[4] at its real plane size, 2 x 16 x 2048 x W float16 (W = 2048: four-element staging loads; W = 2046:
-    rows that are not a multiple of four take the pair-staging instantiation): J=4 forward against the oracle in
+    """configs[4] at its real plane size, 2 x 16 x 2048 x W float16 (W = 2048: levels 1 and 2 on the streaming strip kernel,
+    the narrower ones on the tile kernel; W = 2046: rows that are not whole 16-byte pieces stay on the tile kernels): J=4 forward against the oracle in
     float64 on the rounded input (two sampled planes), inverse, round trip."""
     torch.manual_seed(8)
     x = torch.randn(2, 16, 2048, W, device=DEV).half()
     xfm = pw.DWTForward(J=4, wave='db8', mode='periodization').to(DEV).half()
     ifm = pw.DWTInverse(wave='db8', mode='periodization').to(DEV).half()
     pw.DWTForward(J=1, wave='db8', mode='periodization').to(DEV).half()(x)
-    assert _last_kernel() == ('WlAfbTile<_Float16, 16, 16, 64, 1, 1>' if W % 4 == 0 else 'WlAfbTile<_Float16, 16, 16, 64, 1>'), _last_kernel()   # V4 = 0 is the template default
+    # W = 2048: rows of whole 16-byte pieces -> the streaming strip kernel; W = 2046: the tile kernel (pair staging; V4 = 0
+    # is the template default)
+    assert _last_kernel() == ('WlAfbStrip<_Float16, 16>' if W % 8 == 0 else 'WlAfbTile<_Float16, 16, 16, 64, 1>'), _last_kernel()
     yl, yh = xfm(x)
     assert yl.shape == (2, 16, 128, (W + 15) // 16) and yh[0].shape == (2, 16, 3, 1024, W // 2)
     h0, h1 = F.dwt_analysis_taps('db8')
@@ -315,6 +317,63 @@ def test_streaming_kernel_vs_oracle(wave, mode, J, shape):
         assert rel(res[0].float(), oyl) < 3e-3
         for a, b in zip(res[1], oyh):
             assert rel(a.float(), b) < 3e-3
+
+
+STRIP_GPU_CASES = [('db8', 'periodization', (4, 16, 1024, 2048), torch.float16), ('db4', 'symmetric', (3, 3, 1024, 1024), torch.float32),
+                   ('db8', 'symmetric', (8, 3, 512, 512), torch.float32), ('db10', 'reflect', (2, 2, 300, 1320), torch.float32),
+                   ('db2', 'zero', (2, 3, 640, 4096), torch.float16), ('db3', 'periodic', (5, 1, 257, 768), torch.float32),
+                   ('db6', 'periodization', (7, 2, 511, 512), torch.float32), ('haar', 'symmetric', (2, 2, 64, 64), torch.float32)]
+
+
+@pytest.mark.parametrize('wave,mode,shape,dtype', STRIP_GPU_CASES)
+def test_strip_streaming_analysis_kernel(wave, mode, shape, dtype):
+    """wl_dwt2d_analysis_stream (forced) through the C ABI against the oracle (sampled planes) and against the tile
+    kernel (every plane): several strips and row segments, wrapped and mirrored halos, odd offsets, both dtypes."""
+    from pytorch_wavelets_amd import ops
+    torch.manual_seed(12)
+    x = torch.randn(*shape, device=DEV).to(dtype)
+    h0, h1 = F.dwt_analysis_taps(wave)
+    th = [torch.tensor(np.asarray(v), dtype=torch.float32, device=DEV) for v in (h0, h1, h0, h1)]
+    m = lowlevel.mode_to_int(mode)
+    res = ops.afb2d_stream(x, *th, m, force=True)
+    assert res is not None and 'WlAfbStrip' in pw.last_kernel(), pw.last_kernel()
+    ref = ops.afb2d(x, *th, m)
+    tol = 2e-3 if dtype == torch.float16 else 2e-6
+    for a, b in zip(res, ref):
+        assert a.shape == b.shape and a.dtype == dtype
+        assert float((a.float() - b.float()).abs().max()) <= tol * float(b.float().abs().max())
+    for n, c in ((0, 0), (shape[0] - 1, shape[1] - 1)):
+        oyl, oyh = wo.dwt_forward(x[n:n + 1, c:c + 1].double().cpu().numpy(), 1, h0, h1, h0, h1, mode)
+        assert rel(res[0][n:n + 1, c:c + 1].float(), oyl) < tol and rel(res[1][n:n + 1, c:c + 1].float(), oyh[0]) < tol
+
+
+def test_modules_pick_the_strip_kernel_and_goldens_hold(monkeypatch):
+    """A golden of the reference with gradients (2 x 3 x 64 x 64, db4 symmetric J=3: forward, inverse, both backward
+    passes) with every single-level analysis forced onto the strip kernel (ops.STREAM_FORCE): the levels the fused kernel
+    is kept away from run on WlAfbStrip, and so does SFB2DMulti.backward (an analysis with the synthesis taps)."""
+    from pytorch_wavelets_amd import ops
+    monkeypatch.setattr(ops, 'STREAM_FORCE', True)
+    monkeypatch.setattr(lowlevel, 'FUSED_LEVELS', False)
+    name = 'dwt_01'
+    meta, g = G.INDEX[name], G.load(name)
+    J = meta['J']
+    xfm = pw.DWTForward(J=J, wave=meta['wave'], mode=meta['mode']).to(DEV)
+    ifm = pw.DWTInverse(wave=meta['wave'], mode=meta['mode']).to(DEV)
+    pw.DWTForward(J=1, wave=meta['wave'], mode=meta['mode']).to(DEV)(t(g['x']))
+    assert 'WlAfbStrip' in pw.last_kernel(), pw.last_kernel()
+    x = t(g['x']).requires_grad_(True)
+    yl, yh = xfm(x)
+    assert G.relerr(npy(yl), g, 'yl') < TOL
+    for j in range(J):
+        assert G.relerr(npy(yh[j]), g, 'yh%d' % j) < TOL
+    dx, = torch.autograd.grad((yl * t(g['gl'])).sum() + sum((yh[j] * t(g['gh%d' % j])).sum() for j in range(J)), x)
+    assert G.relerr(npy(dx), g, 'dx') < TOL
+    ylr = t(g['yl']).requires_grad_(True)
+    yhr = [t(g['yh%d' % j]).requires_grad_(True) for j in range(J)]
+    gr = torch.autograd.grad((ifm((ylr, yhr)) * t(g['gy'])).sum(), [ylr] + yhr)
+    assert G.relerr(npy(gr[0]), g, 'dyl') < TOL
+    for j in range(J):
+        assert G.relerr(npy(gr[1 + j]), g, 'dyh%d' % j) < TOL
 
 
 def test_fused_levels_equal_per_level_launches_full_size(monkeypatch):
