@@ -184,6 +184,15 @@ int wl_dwt2d_analysis_stream(const void* x, int64_t x_plane_stride, int x_row_st
                              const void* h_w_hi, const void* h_h_lo, const void* h_h_hi, int L, int mode, int policy,
                              void* stream);
 
+/* ONE synthesis level by the streaming strip kernel (csrc/wl_idwt_strip.h): the same operator as wl_dwt2d_synthesis
+ * (SFB2D.forward, dwt/lowlevel.py:671-680; the (OH, OW) crop is AFB2D.backward's, :356-364) for one square filter length L
+ * (even, <= 20), float32 / float16, every mode, coefficient rows that are whole 16-byte pieces; highs must be present.
+ * policy as for wl_dwt2d_analysis_stream.  Returns WL_ERR_UNSUPPORTED outside its envelope. */
+int wl_dwt2d_synthesis_stream(const void* ll, int64_t ll_plane_stride, int ll_row_stride, const void* highs, void* y,
+                              int dtype, int64_t planes, int Kh, int Kw, int OH, int OW, const void* g_w_lo,
+                              const void* g_w_hi, const void* g_h_lo, const void* g_h_hi, int L, int mode, int policy,
+                              void* stream);
+
 /* Gradients of the two non-separable banks, as autograd gives them upstream (where afb2d_nonsep / sfb2d_nonsep are
  * plain differentiable ATen chains, dwt/lowlevel.py:524-597, :746-798):
  *   wl_dwt2d_analysis_nonsep_bwd : dy (planes,4,Kh,Kw) -> dx (planes,H,W), the adjoint of the boundary gather + strided

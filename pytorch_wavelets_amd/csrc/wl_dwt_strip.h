@@ -49,6 +49,50 @@
 #endif
 #define WL_STRIP_MAXPPR 5       // 1 KiB DMA instructions per row at most (strip rows of up to 5 KiB)
 
+// One row, DMA ring -> staged float32 ring, by one stager wave (shared by the analysis and the synthesis strip kernels).
+template <typename T>
+struct WlStage {
+    static const int SZ = (int)sizeof(T);
+    // One row, DMA ring -> staged ring: this lane's groups i in [imin, imax) (group = 4 cells; source at srow + i * 256 SZ,
+    // destination at drow + i * 1024), six at a time: the LDS reads of a batch are all in flight before the first
+    // conversion (a wave alone hides no latency otherwise), reads and conversions are unconditional (a read beyond the row
+    // stays inside the rings), only the writes are predicated.  DM = (e_lo - c0a) mod 4 decides how a group meets the
+    // 16-byte words of the staged row: 0 one ds_write_b128, 2 two ds_write_b64, odd b32 + b64 + b32; DM 4 = a row of zeros.
+    template <int DM>
+    static WL_DEV void stage_row(const char* srow, char* drow, int imin, int imax, int ngl) {
+        typedef T Quad4 __attribute__((ext_vector_type(4), may_alias));
+        for (int i0 = 0; i0 < ngl; i0 += 6) {
+            Quad4 raw[6];
+            if (DM != 4) {
+    #pragma unroll
+                for (int u = 0; u < 6; ++u)
+                    if (i0 + u < ngl) raw[u] = *reinterpret_cast<const Quad4*>(srow + (i0 + u) * 256 * SZ);
+            }
+    #pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                if (i0 + u >= ngl) break;
+                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+                if (DM != 4) { v0 = (float)raw[u].x; v1 = (float)raw[u].y; v2 = (float)raw[u].z; v3 = (float)raw[u].w; }
+                if (i0 + u >= imin && i0 + u < imax) {
+                    float* dst = reinterpret_cast<float*>(drow + (i0 + u) * 1024);
+                    if (DM == 0) {
+                        wl_vf4 w; w.x = v0; w.y = v1; w.z = v2; w.w = v3;
+                        *reinterpret_cast<wl_vf4*>(dst) = w;
+                    } else if (DM == 2) {
+                        wl_f2 w0, w1; w0.x = v0; w0.y = v1; w1.x = v2; w1.y = v3;
+                        *reinterpret_cast<wl_f2*>(dst) = w0; *reinterpret_cast<wl_f2*>(dst + 2) = w1;
+                    } else if (DM == 1) {                     // odd: the middle two cells are 8-byte aligned
+                        wl_f2 w; w.x = v1; w.y = v2;
+                        dst[0] = v0; *reinterpret_cast<wl_f2*>(dst + 1) = w; dst[3] = v3;
+                    } else {                                  // zeros, any alignment
+                        dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f; dst[3] = 0.f;
+                    }
+                }
+            }
+        }
+    }
+};
+
 template <typename T>
 struct WlStripArgs {
     const T* x;                    // (NC, H, W) through x_ps / x_rs
@@ -124,45 +168,6 @@ struct WlAfbStrip {
     static WL_HD int staged_of(const Strip& s, int c) { return c + 4 - s.dm; }
 
     // ---- stager wave --------------------------------------------------------------------------------------------
-    // One row, DMA ring -> staged ring: this lane's groups i in [imin, imax) (group = 4 cells; source at srow + i * 256 SZ,
-    // destination at drow + i * 1024), six at a time: the LDS reads of a batch are all in flight before the first
-    // conversion (a wave alone hides no latency otherwise), reads and conversions are unconditional (a read beyond the row
-    // stays inside the rings), only the writes are predicated.  DM = (e_lo - c0a) mod 4 decides how a group meets the
-    // 16-byte words of the staged row: 0 one ds_write_b128, 2 two ds_write_b64, odd b32 + b64 + b32; DM 4 = a row of zeros.
-    template <int DM>
-    static WL_DEV void stage_row(const char* srow, char* drow, int imin, int imax, int ngl) {
-        typedef T Quad4 __attribute__((ext_vector_type(4), may_alias));
-        for (int i0 = 0; i0 < ngl; i0 += 6) {
-            Quad4 raw[6];
-            if (DM != 4) {
-#pragma unroll
-                for (int u = 0; u < 6; ++u)
-                    if (i0 + u < ngl) raw[u] = *reinterpret_cast<const Quad4*>(srow + (i0 + u) * 256 * SZ);
-            }
-#pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                if (i0 + u >= ngl) break;
-                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-                if (DM != 4) { v0 = (float)raw[u].x; v1 = (float)raw[u].y; v2 = (float)raw[u].z; v3 = (float)raw[u].w; }
-                if (i0 + u >= imin && i0 + u < imax) {
-                    float* dst = reinterpret_cast<float*>(drow + (i0 + u) * 1024);
-                    if (DM == 0) {
-                        wl_vf4 w; w.x = v0; w.y = v1; w.z = v2; w.w = v3;
-                        *reinterpret_cast<wl_vf4*>(dst) = w;
-                    } else if (DM == 2) {
-                        wl_f2 w0, w1; w0.x = v0; w0.y = v1; w1.x = v2; w1.y = v3;
-                        *reinterpret_cast<wl_f2*>(dst) = w0; *reinterpret_cast<wl_f2*>(dst + 2) = w1;
-                    } else if (DM == 1) {                     // odd: the middle two cells are 8-byte aligned
-                        wl_f2 w; w.x = v1; w.y = v2;
-                        dst[0] = v0; *reinterpret_cast<wl_f2*>(dst + 1) = w; dst[3] = v3;
-                    } else {                                  // zeros, any alignment
-                        dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f; dst[3] = 0.f;
-                    }
-                }
-            }
-        }
-    }
-
     static WL_DEV void stager(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int lane, int sidx) {
         const char* xp = reinterpret_cast<const char*>(a.x + (size_t)plane * a.x_ps);
         const int row_stride = a.x_rs * SZ;
@@ -261,10 +266,10 @@ struct WlAfbStrip {
                 for (int rr = 0; rr < LROWS; ++rr) {
                     const char* srow = dslot + rr * a.dma_pitch + lane * 4 * SZ;
                     char* drow = sslot + rr * a.st_pitch + lane * 16 + (4 - s.dm) * 4;
-                    if (zrow[rr]) stage_row<4>(srow, drow, imin, imax, ngl);
-                    else if (s.dm == 0) stage_row<0>(srow, drow, imin, imax, ngl);
-                    else if (s.dm == 2) stage_row<2>(srow, drow, imin, imax, ngl);
-                    else stage_row<1>(srow, drow, imin, imax, ngl);
+                    if (zrow[rr]) WlStage<T>::template stage_row<4>(srow, drow, imin, imax, ngl);
+                    else if (s.dm == 0) WlStage<T>::template stage_row<0>(srow, drow, imin, imax, ngl);
+                    else if (s.dm == 2) WlStage<T>::template stage_row<2>(srow, drow, imin, imax, ngl);
+                    else WlStage<T>::template stage_row<1>(srow, drow, imin, imax, ngl);
                 }
             }
 #pragma unroll

@@ -1,0 +1,328 @@
+// Streaming ONE-level 2-D DWT synthesis over column strips: the mirror image of wl_dwt_strip.h, for what the fused
+// multi-level synthesis kernel (wl_idwt_rows.h) does not take - periodization (coefficient rows and columns wrap, the
+// output is rolled by L/2-1), 14 to 20 taps, planes wider than one workgroup, float16 planes of any width.
+//
+// A workgroup owns one (plane, strip of output columns, segment of output rows) and marches down it once:
+//   * four STAGER waves, one per source (ll, lh, hl, hh), bring the coefficient rows of the strip in by LDS-DMA (16-byte
+//     pieces of the EXTENDED row: under periodization the pieces beyond either end come from the other end), three
+//     half-batches ahead, and copy what they loaded as float32 (the float16 -> float32 conversion happens once per
+//     coefficient) into a two-slot ring laid out so that every compute lane reads aligned 8-byte words;
+//   * a compute lane owns FOUR adjacent output columns = two polyphase column pairs.  Per coefficient row ("feed") it
+//     reads its L/2+1 (+1) coefficients of each source, runs the polyphase row synthesis of both pairs,
+//         (a, b)[pair] = sum_j (ll | hl, lh | hh)[q - j] * (g[2j], g[2j+1]),
+//     into a circular window of L/2 rows in registers (rotation resolved at compile time: the loop over half-batches is
+//     unrolled by its period) and emits two output rows by the polyphase column synthesis: 17 packed FMAs per output
+//     sample and nothing else;
+//   * periodization with L % 4 == 0 rolls the output by an ODD number of samples: the lane's pairs then straddle two
+//     polyphase pairs, which is the same sum with the tap pairs shifted by one, (g[2j-1], g[2j]) with g[-1] = g[L] = 0 -
+//     one more tap pair per row, no shuffles (template parameter SODD);
+//   * an output row leaves as 8 / 16 contiguous bytes per lane.
+// HBM traffic = the strip's coefficients once (+ L/2 halo columns per strip, L/2-1 halo rows per segment) + the output.
+//
+// Restates SFB2D.forward (reference dwt/lowlevel.py:671-680 = sfb1d along H twice, then along W, :226-271), every mode;
+// the crop to (OH, OW) is AFB2D.backward's (:356-364).
+#pragma once
+#include "wl_common.h"
+#include "wl_dwt_rows.h"   // wl_pk_fma_x / _y, wl_pk_mul_x / _y, wl_uniform_v2
+#include "wl_dwt_strip.h"  // WlStage, WL_STRIP_* geometry constants
+
+template <typename T>
+struct WlIStripArgs {
+    const T* ll;                   // (NC, Kh, Kw) through ll_ps / ll_rs
+    const T* highs;                // (NC, 3, Kh, Kw) dense
+    T* y;                          // (NC, OH, OW) dense
+    const float* g_w_lo;
+    const float* g_w_hi;
+    const float* g_h_lo;
+    const float* g_h_hi;
+    int64_t NC, ll_ps, nblocks;
+    int ll_rs;
+    int Kh, Kw, OH, OW, per;       // per: periodization (coefficient rows / columns wrap, N = 2K outputs)
+    int sw, sh;                    // z-column / z-row of output column / row 0 (z = the un-rolled, un-cropped synthesis)
+    int nstrips, strip_units;      // lane units (4 output columns each) per strip; the last strip may be narrower
+    int nseg, seg_pairs;           // z-row pairs per segment
+    int m_first, m_end;            // z-row pairs [m_first, m_end) that hold output rows
+    int dma_off, dma_pitch;        // DMA ring: WL_STRIP_D slots x 8 rows (4 sources x 2 coefficient rows) x dma_pitch bytes
+    int st_off, st_pitch;          // staged ring: 2 slots x 8 rows x st_pitch bytes (float32)
+    int lds_bytes;
+    int quad_ok;                   // every lane's 4 output columns are one aligned store (OW % 4 == 0, aligned y)
+};
+
+template <typename T, int LT, int SODD>
+struct WlSfbStrip {
+    typedef WlIStripArgs<T> Args;
+    static const int kWaves = WL_STRIP_CWAVES + 4;
+    static const int kThreads = 64 * kWaves;
+    static const int kMinWaves = LT >= 18 ? 3 : 4;
+    static const int SZ = (int)sizeof(T);
+    static const int A = 16 / SZ;
+    static const int HL = LT / 2;
+    static const int NT = HL + SODD;       // tap pairs of the row synthesis
+    static const int NC2 = (NT + 1 + 1) / 2;   // 8-byte words a lane reads per source row: its NT + 1 coefficients
+    static const int LW = (HL + 1) / 2 * 2;    // window slots: a multiple of the 2 rows of a half-batch
+    static const int PERIOD = LW / 2;
+    static const int D = WL_STRIP_D;
+
+    struct Strip {
+        int u0, u1;            // lane units [u0, u1): output columns [4 u0, 4 u1)
+        int q_lo;              // first coefficient column a lane reads
+        int c0a;               // coefficient column of DMA-ring cell 0 (a multiple of A, <= q_lo)
+        int np, ppr, ng;       // pieces / DMA instructions / 4-cell groups per DMA-ring row
+        int dm;                // (q_lo - c0a) & 1
+        int lane_off;          // staged-ring byte offset of lane unit u0's first coefficient
+        int m_lo, m_hi;        // z-row pairs of this segment
+        int e_first, nfeeds, nhb;
+    };
+    static WL_HD Strip geometry(const Args& a, int strip, int seg) {
+        Strip s;
+        s.u0 = strip * a.strip_units;
+        const int units = (a.OW + 3) / 4;
+        s.u1 = s.u0 + a.strip_units < units ? s.u0 + a.strip_units : units;
+        const int qoff = (a.sw + SODD) / 2;
+        s.q_lo = 2 * s.u0 + qoff - NT + 1;
+        const int q_hi = 2 * (s.u1 - 1) + qoff + 1;
+        s.c0a = s.q_lo >= 0 ? s.q_lo / A * A : -((-s.q_lo + A - 1) / A * A);
+        int last = q_hi;
+        if (!a.per && last > a.Kw - 1) last = a.Kw - 1;
+        s.np = (last - s.c0a) / A + 1;
+        s.ppr = (s.np + 63) / 64;
+        s.ng = s.np * A / 4;
+        const int d = s.q_lo - s.c0a;
+        s.dm = d & 1;
+        s.lane_off = (d + s.dm) * 4;                 // staged cell of DMA cell c = c + dm: lanes read 8-byte aligned
+        s.m_lo = a.m_first + seg * a.seg_pairs;
+        s.m_hi = s.m_lo + a.seg_pairs < a.m_end ? s.m_lo + a.seg_pairs : a.m_end;
+        s.e_first = s.m_lo - (HL - 1);
+        s.nfeeds = s.m_hi - s.e_first;
+        s.nhb = (s.nfeeds + 1) / 2;
+        return s;
+    }
+
+    // ---- stager wave: source b (0 = ll, 1..3 = the high-pass bands) ---------------------------------------------------
+    static WL_DEV void stager(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int lane, int b) {
+        const char* bp = b == 0 ? reinterpret_cast<const char*>(a.ll + (size_t)plane * a.ll_ps)
+                                : reinterpret_cast<const char*>(a.highs + ((size_t)plane * 3 + (b - 1)) * ((size_t)a.Kh * a.Kw));
+        const int row_stride = (b == 0 ? a.ll_rs : a.Kw) * SZ;
+        const int e_last = s.e_first + s.nfeeds - 1;
+        int gbyte[WL_STRIP_MAXPPR];
+#pragma unroll
+        for (int q = 0; q < WL_STRIP_MAXPPR; ++q) {
+            const int p = q * 64 + lane;
+            int col = s.c0a + p * A;
+            bool on = q < s.ppr && p < s.np;
+            if (on && (unsigned)col >= (unsigned)a.Kw) {
+                if (a.per) col = wl_pmod(col, a.Kw); else on = false;
+            }
+            gbyte[q] = on ? col * SZ : -1;
+        }
+        const int ngl = (s.ng + 63) >> 6;
+        int imin, imax;
+        {
+            int g_lo = 0, g_hi = s.ng;
+            if (!a.per) {
+                if (s.c0a < 0) g_lo = (-s.c0a + 3) / 4;
+                const int lim = (a.Kw - s.c0a) / 4;
+                if (lim < g_hi) g_hi = lim;
+            }
+            imin = g_lo > lane ? (g_lo - lane + 63) / 64 : 0;
+            imax = g_hi > lane ? (g_hi - lane + 63) / 64 : 0;
+        }
+        auto issue = [&](int h) {
+            const int slot = a.dma_off + (h % D) * 8 * a.dma_pitch;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int e = s.e_first + 2 * h + i;
+                e = e < e_last ? e : e_last;
+                const int r = a.per ? wl_pmod(e, a.Kh) : e;      // (non-periodization: every feed is a real row)
+                const char* grow = bp + (size_t)r * row_stride;
+#pragma unroll
+                for (int q = 0; q < WL_STRIP_MAXPPR; ++q)
+                    if (q < s.ppr) wl_dma16(ctx, (unsigned)(slot + (2 * b + i) * a.dma_pitch + q * 1024), grow + gbyte[q], gbyte[q] >= 0);
+            }
+        };
+        const int nl_inst = 2 * s.ppr;
+        for (int h = 0; h < D && h < s.nhb; ++h) issue(h);
+        int inflight = D < s.nhb ? D : s.nhb;
+        for (int hb = 0; hb < s.nhb; ++hb) {
+            wl_wait_vm_dyn((inflight - 1) * nl_inst);
+            --inflight;
+            const char* dslot = ctx.smem + a.dma_off + (hb % D) * 8 * a.dma_pitch + 2 * b * a.dma_pitch;
+            char* sslot = ctx.smem + a.st_off + (hb & 1) * 8 * a.st_pitch + 2 * b * a.st_pitch;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* srow = dslot + i * a.dma_pitch + lane * 4 * SZ;
+                char* drow = sslot + i * a.st_pitch + lane * 16 + s.dm * 4;
+                if (s.dm == 0) WlStage<T>::template stage_row<0>(srow, drow, imin, imax, ngl);
+                else WlStage<T>::template stage_row<1>(srow, drow, imin, imax, ngl);
+            }
+            ctx.sync();
+            if (hb + D < s.nhb) { issue(hb + D); ++inflight; }
+        }
+        wl_wait_vm<0>();
+    }
+
+    // ---- compute wave ---------------------------------------------------------------------------------------------
+    struct Wave {
+        wl_v2 twl[NT], twh[NT];    // row-synthesis tap pairs of the W-low / W-high bank (shifted by one for SODD)
+        wl_v2 ghl[HL], ghh[HL];    // (g[2t], g[2t+1]) of the H-low / H-high bank
+    };
+    // the NT + 1 coefficients of one staged source row, as (even, odd) pairs
+    static WL_DEV void load_row(const char* p, wl_v2 (&v)[NC2]) {
+#pragma unroll
+        for (int i = 0; i < NC2; ++i) {
+            const wl_f2 t = *reinterpret_cast<const wl_f2*>(p + 8 * i);
+            v[i] = wl_v2{t.x, t.y};
+        }
+    }
+    // acc += tap * cell r of the lane's coefficients (r compile-time: the half is picked by op_sel)
+    template <int r> static WL_DEV void fma_cell(wl_v2& acc, wl_v2 tap, const wl_v2 (&v)[NC2]) {
+        if (r & 1) wl_pk_fma_y(acc, tap, v[r / 2]); else wl_pk_fma_x(acc, tap, v[r / 2]);
+    }
+    template <int r> static WL_DEV wl_v2 mul_cell(wl_v2 tap, const wl_v2 (&v)[NC2]) {
+        return (r & 1) ? wl_pk_mul_y(tap, v[r / 2]) : wl_pk_mul_x(tap, v[r / 2]);
+    }
+    // polyphase row synthesis of one coefficient row for pair P (0: cells NT-1-j, 1: cells NT-j): lo / hi = the W-low and
+    // the W-high source (ll, hl -> a;  lh, hh -> b)
+    template <int P, int J> struct RowSyn {
+        static WL_DEV void run(const Wave& R, const wl_v2 (&lo)[NC2], const wl_v2 (&hi)[NC2], wl_v2& acc) {
+            fma_cell<NT - 1 - J + P>(acc, R.twl[J], lo);
+            fma_cell<NT - 1 - J + P>(acc, R.twh[J], hi);
+            RowSyn<P, J + 1>::run(R, lo, hi, acc);
+        }
+    };
+    template <int P> struct RowSyn<P, NT> {
+        static WL_DEV void run(const Wave&, const wl_v2 (&)[NC2], const wl_v2 (&)[NC2], wl_v2&) {}
+    };
+    template <int P>
+    static WL_DEV wl_v2 row_syn(const Wave& R, const wl_v2 (&lo)[NC2], const wl_v2 (&hi)[NC2]) {
+        wl_v2 acc = mul_cell<NT - 1 + P>(R.twl[0], lo);
+        fma_cell<NT - 1 + P>(acc, R.twh[0], hi);
+        RowSyn<P, 1>::run(R, lo, hi, acc);
+        return acc;
+    }
+    // polyphase column synthesis from the circular window whose NEWEST row sits in slot `newest`:
+    // y0 = (z-row 2m, 2m+1) of the pair's even column, y1 of its odd column
+    static WL_DEV void col_syn(const Wave& R, const wl_v2 (&wa)[LW], const wl_v2 (&wb)[LW], int newest, wl_v2& y0, wl_v2& y1) {
+        y0 = wl_pk_mul_x(R.ghl[0], wa[newest % LW]); y1 = wl_pk_mul_y(R.ghl[0], wa[newest % LW]);
+        wl_pk_fma_x(y0, R.ghh[0], wb[newest % LW]);
+        wl_pk_fma_y(y1, R.ghh[0], wb[newest % LW]);
+#pragma unroll
+        for (int t = 1; t < HL; ++t) {
+            wl_pk_fma_x(y0, R.ghl[t], wa[(newest + LW - t) % LW]);
+            wl_pk_fma_y(y1, R.ghl[t], wa[(newest + LW - t) % LW]);
+            wl_pk_fma_x(y0, R.ghh[t], wb[(newest + LW - t) % LW]);
+            wl_pk_fma_y(y1, R.ghh[t], wb[(newest + LW - t) % LW]);
+        }
+    }
+
+    static WL_DEV void compute(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int cw, int lane) {
+        const int u = s.u0 + 64 * cw + lane;                  // lane unit: output columns 4u .. 4u+3
+        const bool active = u < s.u1;
+        Wave R;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            // SODD: pairs (g[2j-1], g[2j]) with g[-1] = g[L] = 0
+            const int i0 = 2 * j - SODD, i1 = 2 * j + 1 - SODD;
+            const float l0 = i0 >= 0 && i0 < LT ? a.g_w_lo[i0 >= 0 && i0 < LT ? i0 : 0] : 0.f;
+            const float l1 = i1 >= 0 && i1 < LT ? a.g_w_lo[i1 >= 0 && i1 < LT ? i1 : 0] : 0.f;
+            const float h0 = i0 >= 0 && i0 < LT ? a.g_w_hi[i0 >= 0 && i0 < LT ? i0 : 0] : 0.f;
+            const float h1 = i1 >= 0 && i1 < LT ? a.g_w_hi[i1 >= 0 && i1 < LT ? i1 : 0] : 0.f;
+            R.twl[j] = wl_uniform_v2(wl_v2{l0, l1});
+            R.twh[j] = wl_uniform_v2(wl_v2{h0, h1});
+        }
+#pragma unroll
+        for (int t = 0; t < HL; ++t) {
+            R.ghl[t] = wl_uniform_v2(wl_v2{a.g_h_lo[2 * t], a.g_h_lo[2 * t + 1]});
+            R.ghh[t] = wl_uniform_v2(wl_v2{a.g_h_hi[2 * t], a.g_h_hi[2 * t + 1]});
+        }
+        char* const yp = reinterpret_cast<char*>(a.y + (size_t)plane * a.OH * a.OW);
+        const unsigned rowb = (unsigned)a.OW * SZ;
+        const unsigned colb = (unsigned)(4 * u) * SZ;
+        const int ncols = active ? (a.OW - 4 * u < 4 ? a.OW - 4 * u : 4) : 0;   // columns of this lane inside the output
+        const int soff = s.lane_off + 8 * (active ? u - s.u0 : 0);
+        const int N2 = 2 * a.Kh;
+        wl_v2 waA[LW], wbA[LW], waB[LW], wbB[LW];              // circular windows: (a, b) of the two pairs
+#pragma unroll
+        for (int t = 0; t < LW; ++t) waA[t] = wbA[t] = waB[t] = wbB[t] = wl_v2{0.f, 0.f};
+        char* const smem = ctx.smem;
+        int fed = 0;
+        for (int hb0 = 0; hb0 < s.nhb; hb0 += PERIOD) {
+#pragma unroll
+            for (int ph = 0; ph < PERIOD; ++ph) {
+                const int hb = hb0 + ph;
+                if (hb >= s.nhb) break;
+                ctx.sync();
+                const int left = s.nfeeds - fed;
+                const int n = left > 2 ? 2 : left;
+                const char* slot = smem + a.st_off + (hb & 1) * 8 * a.st_pitch + soff;
+                if (active) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if (i < n) {
+                            wl_v2 cll[NC2], clh[NC2], chl[NC2], chh[NC2];
+                            load_row(slot + (0 + i) * a.st_pitch, cll);
+                            load_row(slot + (2 + i) * a.st_pitch, clh);
+                            load_row(slot + (4 + i) * a.st_pitch, chl);
+                            load_row(slot + (6 + i) * a.st_pitch, chh);
+                            const int w = (2 * ph + i) % LW;
+                            waA[w] = row_syn<0>(R, cll, chl); wbA[w] = row_syn<0>(R, clh, chh);
+                            waB[w] = row_syn<1>(R, cll, chl); wbB[w] = row_syn<1>(R, clh, chh);
+                            if (fed + i >= HL - 1) {
+                                wl_v2 y0A, y1A, y0B, y1B;
+                                col_syn(R, waA, wbA, w, y0A, y1A);
+                                col_syn(R, waB, wbB, w, y0B, y1B);
+                                // z-rows 2m, 2m+1 of feed m -> output rows 2m - sh (+1), rolled under periodization
+                                const int m = s.e_first + fed + i;
+                                int p0 = 2 * m - a.sh, p1 = p0 + 1;
+                                if (a.per) { p0 = p0 < 0 ? p0 + N2 : p0; p1 = p1 < 0 ? p1 + N2 : (p1 >= N2 ? p1 - N2 : p1); }
+                                store_row(a, yp + (unsigned)p0 * rowb + colb, p0, ncols, y0A.x, y1A.x, y0B.x, y1B.x);
+                                store_row(a, yp + (unsigned)p1 * rowb + colb, p1, ncols, y0A.y, y1A.y, y0B.y, y1B.y);
+                            }
+                        }
+                    }
+                }
+                fed += n;
+            }
+        }
+    }
+    static WL_DEV void store_row(const Args& a, char* p, int row, int ncols, float v0, float v1, float v2, float v3) {
+        if ((unsigned)row >= (unsigned)a.OH) return;          // cropped away (AFB2D.backward's out_hw)
+        if (a.quad_ok) {
+            typedef T Vec4 __attribute__((ext_vector_type(4)));
+            Vec4 v = {(T)v0, (T)v1, (T)v2, (T)v3};
+            *reinterpret_cast<Vec4*>(p) = v;
+        } else {
+            T* o = reinterpret_cast<T*>(p);
+            if (ncols > 0) o[0] = (T)v0;
+            if (ncols > 1) o[1] = (T)v1;
+            if (ncols > 2) o[2] = (T)v2;
+            if (ncols > 3) o[3] = (T)v3;
+        }
+    }
+
+    static WL_DEV void run(const Args& a, const WlCtx& ctx) {
+        const int tid = ctx.tid;
+        const int wave = wl_uniform(tid >> 6), lane = tid & 63;
+        const int64_t lbid = wl_xcd_remap(ctx.bid, a.nblocks);
+        const int per_plane = a.nstrips * a.nseg;
+        const int64_t plane = lbid / per_plane;
+        const int rem = (int)(lbid - plane * per_plane);
+        const int seg = rem / a.nstrips, strip = rem - seg * a.nstrips;
+        const Strip s = geometry(a, strip, seg);
+        for (int i = tid * 16; i < a.lds_bytes; i += kThreads * 16) {
+            wl_f4 z; z.x = z.y = z.z = z.w = 0.f;
+            *reinterpret_cast<wl_f4*>(ctx.smem + i) = z;
+        }
+        ctx.sync();
+        if (wave >= WL_STRIP_CWAVES) {
+#if defined(__HIPCC__)
+            __builtin_amdgcn_s_setprio(2);
+#endif
+            stager(a, s, ctx, plane, lane, wave - WL_STRIP_CWAVES);
+        } else if (64 * wave < s.u1 - s.u0) {
+            compute(a, s, ctx, plane, wave, lane);
+        } else {
+            for (int hb = 0; hb < s.nhb; ++hb) ctx.sync();
+        }
+    }
+};

@@ -59,7 +59,7 @@ class AFB2D(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             h0_row, h1_row, h0_col, h1_col = ctx.saved_tensors
-            dx = ops.sfb2d(low, highs, h0_row, h1_row, h0_col, h1_col, ctx.mode,
+            dx = ops.sfb2d_best(low, highs, h0_row, h1_row, h0_col, h1_col, ctx.mode,
                            out_hw=tuple(ctx.shape))
         return dx, None, None, None, None, None
 
@@ -75,7 +75,7 @@ class SFB2D(Function):
         ctx.mode = mode
         ctx.save_for_backward(g0_row, g1_row, g0_col, g1_col)
         ctx.has_highs = highs is not None
-        return ops.sfb2d(low, highs, g0_row, g1_row, g0_col, g1_col, mode)
+        return ops.sfb2d_best(low, highs, g0_row, g1_row, g0_col, g1_col, mode)
 
     @staticmethod
     @once_differentiable
@@ -132,7 +132,7 @@ class SFB2DMulti(Function):
                     ll = ll[..., :-1, :]
                 if ll.shape[-1] > h.shape[-1]:
                     ll = ll[..., :-1]
-            ll = ops.sfb2d(ll, h, g0_row, g1_row, g0_col, g1_col, mode)
+            ll = ops.sfb2d_best(ll, h, g0_row, g1_row, g0_col, g1_col, mode)
             j -= 1
         ctx.ll_shapes = ll_shapes
         return ll
@@ -222,7 +222,7 @@ class AFB2DMulti(Function):
                     H, W = ctx.shapes[j + 1]
                     dx = res[..., :H, :W]
                     continue
-                dx = ops.sfb2d(dx, dyh[j], h0_row, h1_row, h0_col, h1_col, ctx.mode, out_hw=ctx.shapes[j])
+                dx = ops.sfb2d_best(dx, dyh[j], h0_row, h1_row, h0_col, h1_col, ctx.mode, out_hw=ctx.shapes[j])
                 j -= 1
             if not dx.is_contiguous():
                 dx = dx.contiguous()

@@ -303,6 +303,50 @@ def afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=False):
     return ll, highs
 
 
+def sfb2d_stream(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None, force=False):
+    """One synthesis level on the streaming strip kernel (wl_dwt2d_synthesis_stream): like sfb2d, or None when the kernel
+    does not cover the configuration (no highs, coefficient rows that are not whole 16-byte pieces, odd tap counts,
+    float64, too few workgroups / narrow rows unless `force`)."""
+    _check_tensor(ll, 'll')
+    if highs is None or ll.dtype == torch.float64:
+        return None
+    N, C, Kh, Kw = ll.shape
+    L = g_w_lo.numel()
+    es = ll.element_size()
+    if (g_h_lo.numel() != L or L % 2 or L > 20 or (Kw * es) % 16 or Kw < L or Kh < L // 2 or ll.numel() == 0
+            or tuple(highs.shape) != (N, C, 3, Kh, Kw) or highs.dtype != ll.dtype
+            or (mode == 2 and (2 * Kh < L - 2 or 2 * Kw < L - 2))):
+        return None
+    OH = 2 * Kh if mode == 2 else 2 * Kh - L + 2
+    OW = 2 * Kw if mode == 2 else 2 * Kw - L + 2
+    if out_hw is not None:
+        OH, OW = min(OH, out_hw[0]), min(OW, out_hw[1])
+    if not force and (OW * es < 1024 or OW % 4):
+        return None                      # the engine's policy: narrow rows / unaligned 4-column groups stay on the other kernels
+    ll, ll_ps, ll_rs = _planes(ll)
+    highs = highs.contiguous()
+    _same_device(ll, highs)
+    key = ('sfbs', ll.device, ll.dtype, N * C, Kh, Kw, ll_ps, ll_rs, OH, OW, L, mode, bool(force))
+    if (key in _FUSED_DECLINED or ll.data_ptr() % 16 or highs.data_ptr() % 16 or (ll_rs * es) % 16 or (ll_ps * es) % 16):
+        return None
+    gwl, gwh, ghl, ghh = (_taps(g, ll) for g in (g_w_lo, g_w_hi, g_h_lo, g_h_hi))
+    y = torch.empty((N, C, OH, OW), dtype=ll.dtype, device=ll.device)
+    rc = _call('wl_dwt2d_synthesis_stream', ll, ll.data_ptr(), ll_ps, ll_rs, highs.data_ptr(), y.data_ptr(), _DTYPES[ll.dtype],
+               N * C, Kh, Kw, OH, OW, gwl.data_ptr(), gwh.data_ptr(), ghl.data_ptr(), ghh.data_ptr(), L, mode,
+               1 if force else 0, _stream(ll))
+    if rc == -3:
+        _FUSED_DECLINED.add(key)
+        return None
+    _lib.check(rc, 'wl_dwt2d_synthesis_stream')
+    return y
+
+
+def sfb2d_best(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None):
+    """One synthesis level on whichever single-level kernel the engine prefers for the shape."""
+    res = sfb2d_stream(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=out_hw, force=STREAM_FORCE)
+    return res if res is not None else sfb2d(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=out_hw)
+
+
 def afb2d_best(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, pad_ll=False):
     """One analysis level on whichever single-level kernel the engine prefers for the shape: the streaming strip kernel
     (rows of 2 KiB and more, enough workgroups for the chip), else the tile kernels."""

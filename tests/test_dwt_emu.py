@@ -458,3 +458,71 @@ def test_modules_use_the_strip_kernel_for_wide_rows(monkeypatch):
         (yl2 * g).sum().backward()
     assert float((yl - yl2).abs().max()) < 1e-5 and all(float((a - b).abs().max()) < 1e-5 for a, b in zip(yh, yh2))
     assert float((xa.grad - xb.grad).abs().max()) < 1e-5
+
+
+ISTRIP_CASES = [('db4', 'symmetric', (2, 1, 36, 36), None), ('db4', 'zero', (1, 2, 24, 40), None), ('db8', 'periodization', (1, 1, 32, 64), None),
+                ('db2', 'reflect', (1, 1, 18, 24), None), ('db3', 'periodic', (1, 1, 27, 32), None), ('haar', 'zero', (1, 1, 8, 8), None),
+                ('db8', 'periodization', (1, 1, 20, 1024), None), ('db10', 'symmetric', (1, 1, 44, 308), None),
+                ('db6', 'periodization', (1, 1, 19, 48), None), ('db4', 'symmetric', (1, 1, 153, 664), None),
+                ('db7', 'reflect', (1, 1, 38, 136), None), ('db2', 'periodization', (1, 1, 16, 32), None),
+                ('db4', 'symmetric', (1, 1, 36, 36), (63, 61)), ('db4', 'periodization', (1, 1, 70, 600), None)]
+
+
+@pytest.mark.parametrize('wave,mode,cshape,out_hw', ISTRIP_CASES)
+def test_strip_streaming_synthesis_kernel_vs_oracle(wave, mode, cshape, out_hw):
+    """wl_dwt2d_synthesis_stream (csrc/wl_idwt_strip.h) on the emulator: every mode, 2-20 taps, the odd roll of
+    periodization with L % 4 == 0 (shifted tap pairs), wrapped coefficient rows and columns, several strips / segments,
+    the crop of the analysis backward."""
+    from pytorch_wavelets_amd import filters, ops
+    from pytorch_wavelets_amd.dwt import lowlevel as ll
+    from oracle import wavelet_oracle as wo
+    rng = np.random.RandomState(7)
+    g0, g1 = filters.dwt_synthesis_taps(wave)
+    N, C, Kh, Kw = cshape
+    lo, hi = rng.randn(N, C, Kh, Kw).astype(np.float32), rng.randn(N, C, 3, Kh, Kw).astype(np.float32)
+    tg = [torch.tensor(np.asarray(v), dtype=torch.float32) for v in (g0, g1, g0, g1)]
+    with emu_backend.emulated():
+        res = ops.sfb2d_stream(torch.tensor(lo), torch.tensor(hi), *tg, ll.mode_to_int(mode), out_hw=out_hw, force=True)
+        assert res is not None and 'WlSfbStrip' in pw.last_kernel()
+    o = wo.sfb2d_level(lo.astype(np.float64), hi.astype(np.float64), g0, g1, g0, g1, mode)
+    if out_hw is not None:
+        o = o[..., :out_hw[0], :out_hw[1]]
+    assert res.shape == o.shape and np.abs(res.numpy() - o).max() < 2e-6 * np.abs(o).max()
+
+
+def test_strip_synthesis_float16_modules_and_declines(monkeypatch):
+    from pytorch_wavelets_amd import filters, ops
+    from oracle import wavelet_oracle as wo
+    rng = np.random.RandomState(8)
+    g0, g1 = filters.dwt_synthesis_taps('db8')
+    tg = [torch.tensor(np.asarray(v), dtype=torch.float32) for v in (g0, g1, g0, g1)]
+    lo, hi = torch.tensor(rng.randn(1, 2, 24, 1024)).half(), torch.tensor(rng.randn(1, 2, 3, 24, 1024)).half()
+    with emu_backend.emulated():
+        res = ops.sfb2d_stream(lo, hi, *tg, 2, force=True)              # config-5 geometry
+        assert res is not None and res.dtype == torch.float16
+        o = wo.sfb2d_level(lo.double().numpy(), hi.double().numpy(), g0, g1, g0, g1, 'periodization')
+        assert np.abs(res.double().numpy() - o).max() < 2e-3 * np.abs(o).max()
+        f32 = torch.float32
+        assert ops.sfb2d_stream(torch.randn(1, 1, 16, 30, dtype=f32), torch.randn(1, 1, 3, 16, 30, dtype=f32), *tg, 1, force=True) is None   # rows not whole pieces
+        assert ops.sfb2d_stream(torch.randn(1, 1, 16, 32, dtype=f32), None, *tg, 1, force=True) is None                                       # no highs
+        assert ops.sfb2d_stream(torch.randn(1, 1, 16, 32, dtype=f32), torch.randn(1, 1, 3, 16, 32, dtype=f32), *tg, 2) is None                # policy: narrow
+        # modules: DWTInverse (periodization, 16 taps: the fused kernel declines) on the strip kernel = the tile path, and the
+        # reference's backward of DWTForward (a synthesis with the analysis taps + crop) as well
+        torch.manual_seed(2)
+        x = torch.randn(2, 1, 64, 512, dtype=f32)
+        xfm, ifm = pw.DWTForward(J=2, wave='db8', mode='periodization').float(), pw.DWTInverse(wave='db8', mode='periodization').float()
+        monkeypatch.setattr(ops, 'STREAM_FORCE', True)
+        xa = x.clone().requires_grad_(True)
+        yl, yh = xfm(xa)
+        rec = ifm((yl, yh))
+        assert 'WlSfbStrip' in pw.last_kernel()
+        (rec * x).sum().backward()
+        monkeypatch.setattr(ops, 'STREAM_FORCE', False)
+        monkeypatch.setattr(ops, 'sfb2d_stream', lambda *a, **k: None)
+        monkeypatch.setattr(ops, 'afb2d_stream', lambda *a, **k: None)
+        xb = x.clone().requires_grad_(True)
+        yl2, yh2 = xfm(xb)
+        rec2 = ifm((yl2, yh2))
+        (rec2 * x).sum().backward()
+    assert float((rec - rec2).abs().max()) < 1e-5 and float((rec - x).abs().max()) < 1e-4
+    assert float((xa.grad - xb.grad).abs().max()) < 1e-4
