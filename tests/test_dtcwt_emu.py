@@ -126,3 +126,32 @@ def test_dtcwt_half_precision_tile_kernels():
         assert float((a.float() - b).abs().max()) < 4e-3 * float(b.abs().max())
     rec = pw.DTCWTInverse().half()((yl, yh))
     assert float((rec.float() - x).abs().max()) < 1e-2 * float(x.abs().max())
+
+
+@pytest.mark.parametrize('shape,biort,mode,dtype', [((1, 2, 24, 256), 'near_sym_a', 'symmetric', torch.float32),
+                                                    ((2, 1, 37, 260), 'near_sym_a', 'symmetric', torch.float32),
+                                                    ((1, 1, 130, 1024), 'near_sym_a', 'symmetric', torch.float32),
+                                                    ((1, 2, 40, 512), 'near_sym_a', 'zero', torch.float32),
+                                                    ((2, 1, 33, 272), 'antonini', 'symmetric', torch.float32),
+                                                    ((2, 1, 32, 256), 'legall', 'symmetric', torch.float32),
+                                                    ((1, 2, 32, 512), 'near_sym_a', 'symmetric', torch.float16)])
+def test_streaming_level1_forward_equals_tile_kernel(shape, biort, mode, dtype):
+    """The streaming level-1 forward over column strips (csrc/wl_dtcwt_strip.h: LDS-DMA rows, staged mirrored halo, register
+    windows, q2c epilogue shared with the tile kernel) against the tile kernel it replaces for wide float32 / float16
+    planes: odd heights (replicated last row), several strips and row segments, zero padding, three filter pairs."""
+    torch.manual_seed(0)
+    x = torch.randn(*shape, dtype=dtype)
+    h = emu_backend.handle()
+    with emu_backend.emulated():
+        xfm = pw.DTCWTForward(J=1, biort=biort, mode=mode).to(dtype)
+        try:
+            yl, yh = xfm(x)
+            assert 'WlDtFwd1Strip' in pw.last_kernel(), pw.last_kernel()
+            h.wl_set_option(b'no_stream', 1)
+            yl2, yh2 = xfm(x)
+            assert 'WlDtFwd1Tile' in pw.last_kernel(), pw.last_kernel()
+        finally:
+            h.wl_set_option(b'no_stream', 0)
+    tol = 5e-3 if dtype == torch.float16 else 2e-6
+    assert float((yl.float() - yl2.float()).abs().max()) <= tol * float(yl2.float().abs().max())
+    assert float((yh[0].float() - yh2[0].float()).abs().max()) <= tol * float(yh2[0].float().abs().max())

@@ -103,3 +103,36 @@ def test_specialised_equals_generic_random_shapes_gpu(seed, monkeypatch):
         for a, b in zip(out['0'], out['1']):
             assert a.shape == b.shape
             assert float((a - b).abs().max()) <= 3e-5 * (float(b.abs().max()) + 1e-30), (biort, qshift, H, W, J)
+
+
+@pytest.mark.parametrize('shape,biort,mode,dtype', [((64, 3, 512, 512), 'near_sym_a', 'symmetric', torch.float32),
+                                                    ((9, 2, 257, 1024), 'near_sym_a', 'symmetric', torch.float32),
+                                                    ((40, 1, 300, 260), 'antonini', 'zero', torch.float32),
+                                                    ((33, 1, 129, 512), 'legall', 'symmetric', torch.float16)])
+def test_streaming_level1_forward(shape, biort, mode, dtype):
+    """The streaming level-1 forward over column strips (the engine's choice for wide planes that fill the chip) against
+    the tile kernel (wl_set_option no_stream) on every plane and against the oracle on sampled planes; backward of the
+    module through it as well."""
+    from pytorch_wavelets_amd import _lib
+    torch.manual_seed(1)
+    x = torch.randn(*shape, device=DEV).to(dtype)
+    xfm = pw.DTCWTForward(J=1, biort=biort, mode=mode).to(DEV).to(dtype)
+    lib = _lib.get()
+    try:
+        yl, yh = xfm(x)
+        assert 'WlDtFwd1Strip' in pw.last_kernel(), pw.last_kernel()
+        lib.wl_set_option(b'no_stream', 1)
+        yl2, yh2 = xfm(x)
+        assert 'WlDtFwd1Tile' in pw.last_kernel(), pw.last_kernel()
+    finally:
+        lib.wl_set_option(b'no_stream', 0)
+    tol = 5e-3 if dtype == torch.float16 else 2e-6
+    assert float((yl.float() - yl2.float()).abs().max()) <= tol * float(yl2.float().abs().max())
+    assert float((yh[0].float() - yh2[0].float()).abs().max()) <= tol * float(yh2[0].float().abs().max())
+    hb = F.dtcwt_forward_taps(biort, 'qshift_a')
+    for n, c in ((0, 0), (shape[0] - 1, shape[1] - 1)):
+        oyl, oyh = wo.dtcwt_forward(x[n:n + 1, c:c + 1].double().cpu().numpy(), 1, *hb, mode=mode)
+        a = yl[n:n + 1, c:c + 1].double().cpu().numpy()
+        assert np.abs(a - oyl).max() <= (5e-3 if dtype == torch.float16 else 1e-5) * np.abs(oyl).max()
+        b = yh[0][n:n + 1, c:c + 1].double().cpu().numpy()
+        assert np.abs(b - oyh[0]).max() <= (5e-3 if dtype == torch.float16 else 1e-5) * np.abs(oyh[0]).max()
