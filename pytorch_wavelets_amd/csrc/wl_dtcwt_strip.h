@@ -268,3 +268,256 @@ struct WlDtFwd1Strip {
         }
     }
 };
+
+// =================================================================================================================
+// Streaming level-1 DTCWT inverse over column strips: inv_j1 (reference dtcwt/transform_funcs.py:152-184 = c2q x 3,
+// 4 colfilter, 2 rowfilter, 3 adds) with both inputs present.  The separable filters commute, so
+//     y = C_g0 (R_g0 ll + R_g1 hl) + C_g1 (R_g0 lh + R_g1 hh)          (R: along rows, C: along columns)
+// is evaluated row filter first: a compute lane owns the two columns of a quad column, keeps circular windows of the
+// row-filtered pair (A, B) = (R_g0 ll + R_g1 hl, R_g0 lh + R_g1 hh) in registers and emits an output row M rows later.
+//   * half-batch = one quad row.  Every lane of the four stager waves owns ONE quad of it: it loads the quad's eight
+//     sources (2 x 2 ll pixels, 6 orientation (re, im) pairs: 8-byte loads, consecutive lanes on consecutive addresses)
+//     straight into registers one half-batch ahead, runs c2q, and writes the quad's four pixels as (ll, lh, hl, hh)
+//     16-byte cells into the staged rows - plus the mirrored copies of the pixels it owns (symmetric extension; rows
+//     above / below the plane are whole quad rows flipped) - so that a compute lane reads a pixel's four channels as ONE
+//     aligned word whose halves are the packed operands of the row filter.  (A first version brought the rows in by
+//     LDS-DMA like the other strip kernels: with 16 bytes read per output pixel, and DMA instructions that cost the CU the
+//     same ~100 cycles full or nearly empty, it was bound by the DMA instruction rate at 0.44 of the HBM peak.)
+// =================================================================================================================
+template <typename T>
+struct WlDtIStripArgs {
+    WlDtInv1Args<T> f;             // tensors, taps, sizes
+    int64_t nblocks;
+    int nstrips, strip_quads, nseg, seg_rows;
+    int st_off, st_pitch, lds_bytes;
+};
+
+template <typename T, int L0, int L1>
+struct WlDtInv1Strip {
+    typedef WlDtIStripArgs<T> Args;
+    static const int CW = 4;                           // compute waves: up to 256 quad columns per strip
+    static const int kWaves = CW + 4;
+    static const int kThreads = 64 * kWaves;
+    static const int kMinWaves = 4;
+    static const int SZ = (int)sizeof(T);
+    static const int M0 = L0 / 2, M1 = L1 / 2, M = M0 > M1 ? M0 : M1, ME = (M + 1) & ~1;
+    static const int LW = 2 * M + 2;                   // window slots (even): rotation by the 2 rows of a half-batch
+    static const int PERIOD = LW / 2;
+    static const int NPX = 2 + 2 * M;                  // pixels a lane reads per row
+
+    struct Strip {
+        int q0, q1;            // quad columns [q0, q1) -> output pixel columns [2 q0, 2 q1)
+        int e_lo, px0;         // first extended pixel column a lane reads (2 q0 - M); pixel column of staged cell 0 (even)
+        int Qa, nq;            // quads [Qa, Qa + nq) are staged (those inside the plane), one per stager lane
+        int r_lo, r_hi, e_first, nhb;
+    };
+    static WL_HD Strip geometry(const Args& a, int strip, int seg) {
+        Strip s;
+        const int W2 = a.f.W / 2;
+        s.q0 = strip * a.strip_quads;
+        s.q1 = s.q0 + a.strip_quads < W2 ? s.q0 + a.strip_quads : W2;
+        s.e_lo = 2 * s.q0 - M;
+        const int e_hi = 2 * s.q1 - 1 + M;
+        s.px0 = s.e_lo >= 0 ? s.e_lo & ~1 : -((-s.e_lo + 1) & ~1);
+        int qa = s.px0 / 2, qb = e_hi / 2;
+        if (qa < 0) qa = 0;
+        if (qb > W2 - 1) qb = W2 - 1;
+        s.Qa = qa; s.nq = qb - qa + 1;
+        s.r_lo = seg * a.seg_rows;
+        s.r_hi = s.r_lo + a.seg_rows < a.f.H ? s.r_lo + a.seg_rows : a.f.H;
+        s.e_first = s.r_lo - ME;
+        s.nhb = (s.r_hi - 1 + M - s.e_first) / 2 + 1;
+        return s;
+    }
+    // extended quad row (pair of extended pixel rows 2 eq, 2 eq + 1) -> source quad row; flip: its two rows swap
+    // (symmetric extension of an even number of rows mirrors whole quad rows); -1: zeros
+    static WL_HD int src_quad_row(int eq, int H2, int ext, bool& flip) {
+        flip = false;
+        if ((unsigned)eq < (unsigned)H2) return eq;
+        if (ext == WL_EXT_ZERO) return -1;
+        flip = true;
+        int m = eq < 0 ? -1 - eq : 2 * H2 - 1 - eq;
+        return m < 0 ? 0 : (m >= H2 ? H2 - 1 : m);     // (one fold: the launcher requires H2 > M)
+    }
+
+    typedef T Pair2 __attribute__((ext_vector_type(2), may_alias));
+    struct Quad { Pair2 l0, l1, b[6]; };               // the eight sources of one quad, as loaded
+
+    static WL_DEV void stager(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int lane, int sidx) {
+        const WlDtInv1Args<T>& f = a.f;
+        const int H2 = f.H / 2, W2 = f.W / 2;
+        const size_t qplane = (size_t)H2 * W2;
+        const int j = 64 * sidx + lane;                       // this lane's quad of every quad row
+        const int Q = s.Qa + j;
+        const bool qon = j < s.nq;
+        const T* llp = f.ll + (size_t)plane * f.ll_plane_stride + 2 * Q;
+        const T* hp = f.highs + (size_t)plane * 6 * qplane * 2 + 2 * Q;
+        // staged cells (16 bytes per pixel) of its two pixel columns, and of their mirror images inside the strip's range
+        const int e_hi = 2 * s.q1 - 1 + M;
+        int cdst[2], mdst[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int p = 2 * Q + c;
+            cdst[c] = (p - s.px0) * 16;
+            int e = -1000000;
+            if (f.ext != WL_EXT_ZERO && qon) {
+                if (p < M && -1 - p >= s.e_lo) e = -1 - p;
+                if (p >= f.W - M && 2 * f.W - 1 - p <= e_hi) e = 2 * f.W - 1 - p;
+            }
+            mdst[c] = e == -1000000 ? -1 : (e - s.px0) * 16;
+        }
+        auto load = [&](int h, Quad& qd) {
+            bool flip;
+            int sq = src_quad_row(s.e_first / 2 + h, H2, f.ext, flip);
+            sq = sq < 0 ? 0 : sq;
+            if (!qon) return;
+            qd.l0 = *reinterpret_cast<const Pair2*>(llp + (size_t)(2 * sq) * f.ll_row_stride);
+            qd.l1 = *reinterpret_cast<const Pair2*>(llp + (size_t)(2 * sq + 1) * f.ll_row_stride);
+#pragma unroll
+            for (int o = 0; o < 6; ++o) qd.b[o] = *reinterpret_cast<const Pair2*>(hp + ((size_t)o * qplane + (size_t)sq * W2) * 2);
+        };
+        const float k = (float)WL_SQRT1_2;
+        auto stage = [&](int hb, const Quad& qd) {
+            bool flip;
+            const int sq = src_quad_row(s.e_first / 2 + hb, H2, f.ext, flip);
+            char* sslot = ctx.smem + a.st_off + (hb & 1) * 2 * a.st_pitch;
+            if (!qon) return;
+            float re[6], im[6];
+#pragma unroll
+            for (int o = 0; o < 6; ++o) { re[o] = (float)qd.b[o].x; im[o] = (float)qd.b[o].y; }
+            // c2q (dtcwt/lowlevel.py:263-295): orientation pairs (0,5) -> lh, (2,3) -> hl, (1,4) -> hh
+            float v[2][2][4];                                 // [row][col][channel]
+#pragma unroll
+            for (int ch = 1; ch < 4; ++ch) {
+                const int o1 = ch == 1 ? 0 : (ch == 2 ? 2 : 1), o2 = ch == 1 ? 5 : (ch == 2 ? 3 : 4);
+                v[0][0][ch] = (re[o1] + re[o2]) * k; v[0][1][ch] = (im[o1] + im[o2]) * k;
+                v[1][0][ch] = (im[o1] - im[o2]) * k; v[1][1][ch] = (re[o2] - re[o1]) * k;
+            }
+            v[0][0][0] = (float)qd.l0.x; v[0][1][0] = (float)qd.l0.y; v[1][0][0] = (float)qd.l1.x; v[1][1][0] = (float)qd.l1.y;
+            const bool zero = sq < 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                char* drow = sslot + (flip ? 1 - i : i) * a.st_pitch;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    wl_vf4 w;
+                    w.x = zero ? 0.f : v[i][c][0]; w.y = zero ? 0.f : v[i][c][1];
+                    w.z = zero ? 0.f : v[i][c][2]; w.w = zero ? 0.f : v[i][c][3];
+                    *reinterpret_cast<wl_vf4*>(drow + cdst[c]) = w;
+                    if (mdst[c] >= 0) *reinterpret_cast<wl_vf4*>(drow + mdst[c]) = w;
+                }
+            }
+        };
+        // software pipeline in registers: the loads of half-batch hb + 1 are in flight while hb is staged
+        Quad qa, qb;
+        load(0, qa);
+        for (int hb = 0; hb < s.nhb; hb += 2) {
+            if (hb + 1 < s.nhb) load(hb + 1, qb);
+            stage(hb, qa);
+            ctx.sync();
+            if (hb + 1 >= s.nhb) break;
+            if (hb + 2 < s.nhb) load(hb + 2, qa);
+            stage(hb + 1, qb);
+            ctx.sync();
+        }
+    }
+
+    struct Wave {
+        wl_v2 r0[L0], r1[L1];      // row-filter taps, duplicated: (g0[t], g0[t]) meets (ll, lh), (g1[t], g1[t]) meets (hl, hh)
+        wl_v2 cc[2 * M + 1];       // column-filter tap pairs (g0[t], g1[t]), both centred in 2M+1 slots
+    };
+    // (A, B) of output column `COL` of the quad from the lane's pixels px[0..NPX): (x, y) = (ll, lh), (z, w) = (hl, hh)
+    template <int COL> static WL_DEV wl_v2 row_filter(const Wave& R, const wl_vf4 (&px)[NPX]) {
+        wl_v2 a0 = wl_pk_mul_vs(wl_v2{px[COL + M - M0].x, px[COL + M - M0].y}, R.r0[0]);
+        wl_v2 a1 = wl_pk_mul_vs(wl_v2{px[COL + M - M1].z, px[COL + M - M1].w}, R.r1[0]);
+#pragma unroll
+        for (int t = 1; t < L0; ++t) wl_pk_fma_vs(a0, wl_v2{px[COL + M - M0 + t].x, px[COL + M - M0 + t].y}, R.r0[t]);
+#pragma unroll
+        for (int t = 1; t < L1; ++t) wl_pk_fma_vs(a1, wl_v2{px[COL + M - M1 + t].z, px[COL + M - M1 + t].w}, R.r1[t]);
+        return a0 + a1;
+    }
+    // output sample of the row centred on slot c
+    static WL_DEV float col_filter(const Wave& R, const wl_v2 (&w)[LW], int c) {
+        wl_v2 acc = wl_pk_mul_vs(w[(c + LW - M) % LW], R.cc[0]);
+#pragma unroll
+        for (int t = 1; t < 2 * M + 1; ++t) wl_pk_fma_vs(acc, w[(c + LW - M + t) % LW], R.cc[t]);
+        return acc.x + acc.y;
+    }
+
+    static WL_DEV void compute(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int cw, int lane) {
+        const WlDtInv1Args<T>& f = a.f;
+        const int q = s.q0 + 64 * cw + lane;
+        const bool active = q < s.q1;
+        Wave R;
+#pragma unroll
+        for (int t = 0; t < L0; ++t) R.r0[t] = wl_uniform_v2(wl_v2{(float)f.g0[t], (float)f.g0[t]});
+#pragma unroll
+        for (int t = 0; t < L1; ++t) R.r1[t] = wl_uniform_v2(wl_v2{(float)f.g1[t], (float)f.g1[t]});
+#pragma unroll
+        for (int t = 0; t < 2 * M + 1; ++t) {
+            const int t0 = t - (M - M0), t1 = t - (M - M1);
+            const float v0 = t0 >= 0 && t0 < L0 ? (float)f.g0[t0 >= 0 && t0 < L0 ? t0 : 0] : 0.f;
+            const float v1 = t1 >= 0 && t1 < L1 ? (float)f.g1[t1 >= 0 && t1 < L1 ? t1 : 0] : 0.f;
+            R.cc[t] = wl_uniform_v2(wl_v2{v0, v1});
+        }
+        const int soff = (s.e_lo - s.px0 + 2 * (active ? q - s.q0 : 0)) * 16;
+        char* const yp = reinterpret_cast<char*>(f.y + (size_t)plane * f.H * f.W);
+        const unsigned rowb = (unsigned)f.W * SZ, colb = (unsigned)(2 * q) * SZ;
+        wl_v2 wa[LW], wb[LW];
+#pragma unroll
+        for (int t = 0; t < LW; ++t) wa[t] = wb[t] = wl_v2{0.f, 0.f};
+        char* const smem = ctx.smem;
+        for (int hb0 = 0; hb0 < s.nhb; hb0 += PERIOD) {
+#pragma unroll
+            for (int ph = 0; ph < PERIOD; ++ph) {
+                const int hb = hb0 + ph;
+                if (hb >= s.nhb) break;
+                ctx.sync();
+                if (!active) continue;
+                const char* slot = smem + a.st_off + (hb & 1) * 2 * a.st_pitch + soff;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    wl_vf4 px[NPX];
+#pragma unroll
+                    for (int u = 0; u < NPX; ++u) px[u] = *reinterpret_cast<const wl_vf4*>(slot + i * a.st_pitch + 16 * u);
+                    const int w = (2 * ph + i) % LW;          // slot of the new row e = e_first + 2 hb + i
+                    wa[w] = row_filter<0>(R, px);
+                    wb[w] = row_filter<1>(R, px);
+                    const int o = s.e_first + 2 * hb + i - M;   // the row that is complete now
+                    const float ya = col_filter(R, wa, (w + LW - M) % LW), yb = col_filter(R, wb, (w + LW - M) % LW);
+                    if (o >= s.r_lo && o < s.r_hi) {
+                        typedef T Vec2 __attribute__((ext_vector_type(2)));
+                        Vec2 v = {(T)ya, (T)yb};
+                        *reinterpret_cast<Vec2*>(yp + (unsigned)o * rowb + colb) = v;
+                    }
+                }
+            }
+        }
+    }
+
+    static WL_DEV void run(const Args& a, const WlCtx& ctx) {
+        const int tid = ctx.tid;
+        const int wave = wl_uniform(tid >> 6), lane = tid & 63;
+        const int64_t lbid = wl_xcd_remap(ctx.bid, a.nblocks);
+        const int per_plane = a.nstrips * a.nseg;
+        const int64_t plane = lbid / per_plane;
+        const int rem = (int)(lbid - plane * per_plane);
+        const int seg = rem / a.nstrips, strip = rem - seg * a.nstrips;
+        const Strip s = geometry(a, strip, seg);
+        for (int i = tid * 16; i < a.lds_bytes; i += kThreads * 16) {
+            wl_f4 z; z.x = z.y = z.z = z.w = 0.f;
+            *reinterpret_cast<wl_f4*>(ctx.smem + i) = z;
+        }
+        ctx.sync();
+        if (wave >= CW) {
+#if defined(__HIPCC__)
+            __builtin_amdgcn_s_setprio(2);
+#endif
+            stager(a, s, ctx, plane, lane, wave - CW);
+        } else if (64 * wave < s.q1 - s.q0) {
+            compute(a, s, ctx, plane, wave, lane);
+        } else {
+            for (int hb = 0; hb < s.nhb; ++hb) ctx.sync();
+        }
+    }
+};

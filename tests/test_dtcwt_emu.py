@@ -155,3 +155,46 @@ def test_streaming_level1_forward_equals_tile_kernel(shape, biort, mode, dtype):
     tol = 5e-3 if dtype == torch.float16 else 2e-6
     assert float((yl.float() - yl2.float()).abs().max()) <= tol * float(yl2.float().abs().max())
     assert float((yh[0].float() - yh2[0].float()).abs().max()) <= tol * float(yh2[0].float().abs().max())
+
+
+@pytest.mark.parametrize('shape,biort,mode,dtype', [((1, 2, 24, 256), 'near_sym_a', 'symmetric', torch.float32),
+                                                    ((2, 1, 38, 260), 'near_sym_a', 'symmetric', torch.float32),
+                                                    ((1, 1, 132, 1024), 'near_sym_a', 'symmetric', torch.float32),
+                                                    ((1, 2, 40, 512), 'near_sym_a', 'zero', torch.float32),
+                                                    ((2, 1, 34, 272), 'antonini', 'symmetric', torch.float32),
+                                                    ((2, 1, 32, 256), 'legall', 'symmetric', torch.float32),
+                                                    ((1, 2, 32, 512), 'near_sym_a', 'symmetric', torch.float16)])
+def test_streaming_level1_inverse_equals_tile_kernel(shape, biort, mode, dtype):
+    """The streaming level-1 inverse over column strips (csrc/wl_dtcwt_strip.h: one quad per stager lane - register loads,
+    c2q, (ll, lh, hl, hh) cells with mirrored copies - row filter from LDS, column filter from register windows) against
+    the tile kernel: mirrored / zero rows and columns, several strips and segments, three filter pairs, float16; and its
+    use as the backward of the level-1 forward."""
+    torch.manual_seed(0)
+    x = torch.randn(*shape, dtype=dtype)
+    h = emu_backend.handle()
+    with emu_backend.emulated():
+        xfm = pw.DTCWTForward(J=1, biort=biort, mode=mode).to(dtype)
+        ifm = pw.DTCWTInverse(biort=biort, mode=mode).to(dtype)
+        yl, yh = xfm(x)
+        yl, yh = yl + 0.1 * torch.randn_like(yl), [yh[0] + 0.1 * torch.randn_like(yh[0])]
+        try:
+            r1 = ifm((yl, yh))
+            assert 'WlDtInv1Strip' in pw.last_kernel(), pw.last_kernel()
+            xg = x.clone().float().requires_grad_(True)
+            if dtype == torch.float32:
+                a, b = xfm(xg)
+                ((a * yl).sum() + (b[0] * yh[0]).sum()).backward()
+                assert 'WlDtInv1Strip' in pw.last_kernel(), pw.last_kernel()
+                g1 = xg.grad.clone()
+            h.wl_set_option(b'no_stream', 1)
+            r2 = ifm((yl, yh))
+            assert 'WlDtInv1Tile' in pw.last_kernel(), pw.last_kernel()
+            if dtype == torch.float32:
+                xg.grad = None
+                a, b = xfm(xg)
+                ((a * yl).sum() + (b[0] * yh[0]).sum()).backward()
+                assert float((g1 - xg.grad).abs().max()) <= 2e-6 * float(xg.grad.abs().max())
+        finally:
+            h.wl_set_option(b'no_stream', 0)
+    tol = 5e-3 if dtype == torch.float16 else 2e-6
+    assert float((r1.float() - r2.float()).abs().max()) <= tol * float(r2.float().abs().max())

@@ -136,3 +136,44 @@ def test_streaming_level1_forward(shape, biort, mode, dtype):
         assert np.abs(a - oyl).max() <= (5e-3 if dtype == torch.float16 else 1e-5) * np.abs(oyl).max()
         b = yh[0][n:n + 1, c:c + 1].double().cpu().numpy()
         assert np.abs(b - oyh[0]).max() <= (5e-3 if dtype == torch.float16 else 1e-5) * np.abs(oyh[0]).max()
+
+
+@pytest.mark.parametrize('shape,biort,mode,dtype', [((64, 3, 512, 512), 'near_sym_a', 'symmetric', torch.float32),
+                                                    ((9, 2, 258, 1024), 'near_sym_a', 'symmetric', torch.float32),
+                                                    ((40, 1, 300, 260), 'antonini', 'zero', torch.float32),
+                                                    ((33, 1, 130, 512), 'legall', 'symmetric', torch.float16)])
+def test_streaming_level1_inverse(shape, biort, mode, dtype):
+    """The streaming level-1 inverse over column strips against the tile kernel (wl_set_option no_stream) on every plane,
+    the round trip through both streaming kernels, and the module's backward (an inverse with the forward taps)."""
+    from pytorch_wavelets_amd import _lib
+    torch.manual_seed(2)
+    x = torch.randn(*shape, device=DEV).to(dtype)
+    xfm = pw.DTCWTForward(J=1, biort=biort, mode=mode).to(DEV).to(dtype)
+    ifm = pw.DTCWTInverse(biort=biort, mode=mode).to(DEV).to(dtype)
+    lib = _lib.get()
+    yl, yh = xfm(x)
+    try:
+        r1 = ifm((yl, yh))
+        assert 'WlDtInv1Strip' in pw.last_kernel(), pw.last_kernel()
+        lib.wl_set_option(b'no_stream', 1)
+        r2 = ifm((yl, yh))
+        assert 'WlDtInv1Tile' in pw.last_kernel(), pw.last_kernel()
+    finally:
+        lib.wl_set_option(b'no_stream', 0)
+    tol = 5e-3 if dtype == torch.float16 else 2e-6
+    assert float((r1.float() - r2.float()).abs().max()) <= tol * float(r2.float().abs().max())
+    if mode == 'symmetric':   # perfect reconstruction
+        assert float((r1.float() - x.float()).abs().max()) <= (2e-2 if dtype == torch.float16 else 2e-5) * float(x.float().abs().max())
+    if dtype == torch.float32:
+        xg = x.clone().requires_grad_(True)
+        a, b = xfm(xg)
+        ((a * yl).sum() + (b[0] * yh[0]).sum()).backward()
+        g1 = xg.grad.clone()
+        try:
+            lib.wl_set_option(b'no_stream', 1)
+            xg.grad = None
+            a, b = xfm(xg)
+            ((a * yl).sum() + (b[0] * yh[0]).sum()).backward()
+        finally:
+            lib.wl_set_option(b'no_stream', 0)
+        assert float((g1 - xg.grad).abs().max()) <= 2e-6 * float(xg.grad.abs().max())
