@@ -106,9 +106,9 @@ def test_specialised_equals_generic_random_shapes_gpu(seed, monkeypatch):
 
 
 @pytest.mark.parametrize('shape,biort,mode,dtype', [((64, 3, 512, 512), 'near_sym_a', 'symmetric', torch.float32),
-                                                    ((9, 2, 257, 1024), 'near_sym_a', 'symmetric', torch.float32),
-                                                    ((40, 1, 300, 260), 'antonini', 'zero', torch.float32),
-                                                    ((33, 1, 129, 512), 'legall', 'symmetric', torch.float16)])
+                                                    ((20, 3, 257, 1024), 'near_sym_a', 'symmetric', torch.float32),
+                                                    ((64, 1, 300, 260), 'antonini', 'zero', torch.float32),
+                                                    ((96, 1, 129, 512), 'legall', 'symmetric', torch.float16)])
 def test_streaming_level1_forward(shape, biort, mode, dtype):
     """The streaming level-1 forward over column strips (the engine's choice for wide planes that fill the chip) against
     the tile kernel (wl_set_option no_stream) on every plane and against the oracle on sampled planes; backward of the
@@ -139,9 +139,9 @@ def test_streaming_level1_forward(shape, biort, mode, dtype):
 
 
 @pytest.mark.parametrize('shape,biort,mode,dtype', [((64, 3, 512, 512), 'near_sym_a', 'symmetric', torch.float32),
-                                                    ((9, 2, 258, 1024), 'near_sym_a', 'symmetric', torch.float32),
-                                                    ((40, 1, 300, 260), 'antonini', 'zero', torch.float32),
-                                                    ((33, 1, 130, 512), 'legall', 'symmetric', torch.float16)])
+                                                    ((20, 3, 258, 1024), 'near_sym_a', 'symmetric', torch.float32),
+                                                    ((64, 1, 300, 260), 'antonini', 'zero', torch.float32),
+                                                    ((96, 1, 130, 512), 'legall', 'symmetric', torch.float16)])
 def test_streaming_level1_inverse(shape, biort, mode, dtype):
     """The streaming level-1 inverse over column strips against the tile kernel (wl_set_option no_stream) on every plane,
     the round trip through both streaming kernels, and the module's backward (an inverse with the forward taps)."""
