@@ -39,6 +39,9 @@
 #ifndef WL_STRIP_ABLATE
 #define WL_STRIP_ABLATE 0       // measurement builds only (tools/build_ab_strip.sh): 1 = no arithmetic / stores in the compute
 #endif                          // waves, 2 = the stagers load but do not stage
+#ifndef WL_STRIP_DIRECT
+#define WL_STRIP_DIRECT 1        // stagers load straight into registers (0: through an LDS-DMA ring, the first version; A/B builds)
+#endif
 #ifndef WL_STRIP_D
 #define WL_STRIP_D 3            // half-batches of LDS-DMA in flight = slots of the DMA ring
 #endif
@@ -288,6 +291,122 @@ struct WlAfbStrip {
         }
     }
 
+    // ---- stager wave, direct form: row `sidx` of every half-batch ------------------------------------------------------
+    // The stager needs every sample in a register anyway (conversion, alignment): instead of LDS-DMA into a ring and an
+    // LDS read, the lane loads its 4-cell groups straight from global memory (8 / 16 bytes per lane, consecutive lanes on
+    // consecutive addresses, wrapped columns resolved once per lane) one half-batch ahead, into one of two register
+    // sets, and stages the other.  No DMA ring in LDS, no counted waits (the compiler tracks ordinary loads), no DMA
+    // instruction issue - which cost a stager ~250 cycles apiece under load.
+    static const int MAXG = 6;             // 4-cell groups per lane and row: strips of up to 6 x 64 x 4 cells
+    typedef T Quad4 __attribute__((ext_vector_type(4), may_alias));
+    struct RowRegs { Quad4 g[MAXG]; T h[2]; };
+    template <int DM, int NGL>
+    static WL_DEV void stage_regs(const RowRegs& rr, char* drow, int imin, int imax, bool zero) {
+#pragma unroll
+        for (int i = 0; i < NGL; ++i) {
+            if (i < imin || i >= imax) continue;
+            float v0 = (float)rr.g[i].x, v1 = (float)rr.g[i].y, v2 = (float)rr.g[i].z, v3 = (float)rr.g[i].w;
+            if (zero) v0 = v1 = v2 = v3 = 0.f;
+            float* dst = reinterpret_cast<float*>(drow + i * 1024);
+            if (DM == 0) {
+                wl_vf4 w; w.x = v0; w.y = v1; w.z = v2; w.w = v3;
+                *reinterpret_cast<wl_vf4*>(dst) = w;
+            } else if (DM == 2) {
+                wl_f2 w0, w1; w0.x = v0; w0.y = v1; w1.x = v2; w1.y = v3;
+                *reinterpret_cast<wl_f2*>(dst) = w0; *reinterpret_cast<wl_f2*>(dst + 2) = w1;
+            } else {                                          // odd: the middle two cells are 8-byte aligned
+                wl_f2 w; w.x = v1; w.y = v2;
+                dst[0] = v0; *reinterpret_cast<wl_f2*>(dst + 1) = w; dst[3] = v3;
+            }
+        }
+    }
+    // NGL = groups per lane and row (compile-time, so that every load of a half-batch is unconditional: the compiler
+    // can then count them and wait for exactly the older register set; with predicated loads it waits for all of them,
+    // i.e. for the loads it has just issued - measured 36 % slower)
+    template <int NGL>
+    static WL_DEV void stager_direct(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int lane, int sidx) {
+        static_assert(LROWS == 1, "the direct stager takes one row per wave and half-batch");
+        const char* xp = reinterpret_cast<const char*>(a.x + (size_t)plane * a.x_ps);
+        const int row_stride = a.x_rs * SZ;
+        const bool wrap = wraps(a.ext);
+        const int e_first = a.base + 2 * s.o_lo;
+        const int e_last = a.base + 2 * (s.o_lo + s.nfeeds) - 1;
+        // this lane's groups lane + 64 i: source byte inside a row (wrapped), valid range [imin, imax)
+        int goff[MAXG];
+        int imin, imax;
+        {
+            int g_lo = 0, g_hi = s.ng;
+            if (!wrap) {
+                if (s.c0a < 0) g_lo = (-s.c0a + 3) / 4;
+                const int lim = (a.W - s.c0a) / 4;
+                if (lim < g_hi) g_hi = lim;
+            }
+            imin = g_lo > lane ? (g_lo - lane + 63) / 64 : 0;
+            imax = g_hi > lane ? (g_hi - lane + 63) / 64 : 0;
+#pragma unroll
+            for (int i = 0; i < MAXG; ++i) {
+                int col = s.c0a + 4 * (lane + 64 * i);
+                if (wrap) col = wl_pmod(col, a.W);
+                goff[i] = (i >= imin && i < imax) ? col * SZ : 0;
+            }
+        }
+        // mirrored cells (symmetric / reflect, strips at either edge): a lane handles cells lane and lane + 64
+        int hdst[2], hoff[2];
+        {
+            const int e_hi = 2 * (s.k1 - 1) + a.base + LT - 1 + 2;
+            const int nl = s.e_lo < 0 ? -s.e_lo : 0, nr = e_hi > a.W - 1 ? e_hi - (a.W - 1) : 0;
+            const int NH = (a.ext == WL_EXT_SYM || a.ext == WL_EXT_REFL) ? nl + nr : 0;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c = lane + 64 * u;
+                hdst[u] = -1; hoff[u] = 0;
+                if (c < NH) {
+                    const int e = c < nl ? s.e_lo + c : a.W + (c - nl);
+                    hdst[u] = staged_of(s, e - s.c0a) * 4;
+                    hoff[u] = wl_ext(e, a.W, a.ext) * SZ;
+                }
+            }
+        }
+        auto src_row = [&](int h) {
+            int e = e_first + 4 * h + sidx;
+            e = e < e_last ? e : e_last;
+            return (unsigned)e < (unsigned)a.H ? e : wl_ext(e, a.H, a.ext);   // -1: a row of zeros
+        };
+        auto load = [&](int h, RowRegs& rr) {
+            int r = src_row(h);
+            r = r < 0 ? 0 : r;
+            const char* grow = xp + (size_t)r * row_stride;
+#pragma unroll
+            for (int i = 0; i < NGL; ++i) rr.g[i] = *reinterpret_cast<const Quad4*>(grow + goff[i]);   // (off lanes: the row's first group)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) rr.h[u] = *reinterpret_cast<const T*>(grow + hoff[u]);
+        };
+        auto stage = [&](int hb, const RowRegs& rr) {
+            char* srow0 = ctx.smem + a.st_off + ((hb & 1) * 4 + sidx) * a.st_pitch;
+            char* drow = srow0 + lane * 16 + (4 - s.dm) * 4;
+            const bool zero = src_row(hb) < 0;
+            if (!(WL_STRIP_ABLATE & 2)) {
+                if (s.dm == 0) stage_regs<0, NGL>(rr, drow, imin, imax, zero);
+                else if (s.dm == 2) stage_regs<2, NGL>(rr, drow, imin, imax, zero);
+                else stage_regs<1, NGL>(rr, drow, imin, imax, zero);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (hdst[u] >= 0) *reinterpret_cast<float*>(srow0 + hdst[u]) = zero ? 0.f : (float)rr.h[u];
+            }
+        };
+        RowRegs ra, rb;
+        load(0, ra);
+        for (int hb = 0; hb < s.nhb; hb += 2) {
+            if (hb + 1 < s.nhb) load(hb + 1, rb);
+            stage(hb, ra);
+            ctx.sync();
+            if (hb + 1 >= s.nhb) break;
+            if (hb + 2 < s.nhb) load(hb + 2, ra);
+            stage(hb + 1, rb);
+            ctx.sync();
+        }
+    }
+
     // ---- compute wave ---------------------------------------------------------------------------------------------
     struct Wave {
         wl_v2 tw[LT], th[LT];      // (lo,hi) tap pairs along W / along H (wave-uniform: scalar registers)
@@ -447,7 +566,17 @@ struct WlAfbStrip {
 #if defined(__HIPCC__)
             __builtin_amdgcn_s_setprio(2);   // every compute wave waits for the stagers at the barrier
 #endif
-            stager(a, s, ctx, plane, lane, wave - WL_STRIP_CWAVES);
+            const int sidx = wave - WL_STRIP_CWAVES;
+            if (WL_STRIP_DIRECT) {
+                switch ((s.ng + 63) >> 6) {
+                    case 1: stager_direct<1>(a, s, ctx, plane, lane, sidx); break;
+                    case 2: stager_direct<2>(a, s, ctx, plane, lane, sidx); break;
+                    case 3: stager_direct<3>(a, s, ctx, plane, lane, sidx); break;
+                    case 4: stager_direct<4>(a, s, ctx, plane, lane, sidx); break;
+                    case 5: stager_direct<5>(a, s, ctx, plane, lane, sidx); break;
+                    default: stager_direct<6>(a, s, ctx, plane, lane, sidx); break;
+                }
+            } else stager(a, s, ctx, plane, lane, sidx);
         } else if (64 * 2 * wave < s.k1 - s.k0) {
             compute(a, s, ctx, plane, wave, lane);
         } else {

@@ -161,6 +161,79 @@ struct WlSfbStrip {
         wl_wait_vm<0>();
     }
 
+    // ---- stager wave, direct form (see wl_dwt_strip.h): source b, two coefficient rows per half-batch, loaded straight
+    // into registers one half-batch ahead; NGL = 4-cell groups per lane and row (compile-time: static load counts)
+    static const int MAXG = 6;
+    typedef T Quad4 __attribute__((ext_vector_type(4), may_alias));
+    template <int NGL> struct RowRegs { Quad4 g[2][NGL]; };
+    template <int NGL>
+    static WL_DEV void stager_direct(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int lane, int b) {
+        const char* bp = b == 0 ? reinterpret_cast<const char*>(a.ll + (size_t)plane * a.ll_ps)
+                                : reinterpret_cast<const char*>(a.highs + ((size_t)plane * 3 + (b - 1)) * ((size_t)a.Kh * a.Kw));
+        const int row_stride = (b == 0 ? a.ll_rs : a.Kw) * SZ;
+        const int e_last = s.e_first + s.nfeeds - 1;
+        int goff[NGL];
+        int imin, imax;
+        {
+            int g_lo = 0, g_hi = s.ng;
+            if (!a.per) {
+                if (s.c0a < 0) g_lo = (-s.c0a + 3) / 4;
+                const int lim = (a.Kw - s.c0a) / 4;
+                if (lim < g_hi) g_hi = lim;
+            }
+            imin = g_lo > lane ? (g_lo - lane + 63) / 64 : 0;
+            imax = g_hi > lane ? (g_hi - lane + 63) / 64 : 0;
+#pragma unroll
+            for (int i = 0; i < NGL; ++i) {
+                int col = s.c0a + 4 * (lane + 64 * i);
+                if (a.per) col = wl_pmod(col, a.Kw);
+                goff[i] = (i >= imin && i < imax) ? col * SZ : 0;
+            }
+        }
+        auto load = [&](int h, RowRegs<NGL>& rr) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                int e = s.e_first + 2 * h + r;
+                e = e < e_last ? e : e_last;
+                const int row = a.per ? wl_pmod(e, a.Kh) : e;
+                const char* grow = bp + (size_t)row * row_stride;
+#pragma unroll
+                for (int i = 0; i < NGL; ++i) rr.g[r][i] = *reinterpret_cast<const Quad4*>(grow + goff[i]);
+            }
+        };
+        auto stage = [&](int hb, const RowRegs<NGL>& rr) {
+            char* sslot = ctx.smem + a.st_off + (hb & 1) * 8 * a.st_pitch + 2 * b * a.st_pitch;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                char* drow = sslot + r * a.st_pitch + lane * 16 + s.dm * 4;
+#pragma unroll
+                for (int i = 0; i < NGL; ++i) {
+                    if (i < imin || i >= imax) continue;
+                    const float v0 = (float)rr.g[r][i].x, v1 = (float)rr.g[r][i].y, v2 = (float)rr.g[r][i].z, v3 = (float)rr.g[r][i].w;
+                    float* dst = reinterpret_cast<float*>(drow + i * 1024);
+                    if (s.dm == 0) {
+                        wl_vf4 w; w.x = v0; w.y = v1; w.z = v2; w.w = v3;
+                        *reinterpret_cast<wl_vf4*>(dst) = w;
+                    } else {
+                        wl_f2 w; w.x = v1; w.y = v2;
+                        dst[0] = v0; *reinterpret_cast<wl_f2*>(dst + 1) = w; dst[3] = v3;
+                    }
+                }
+            }
+        };
+        RowRegs<NGL> ra, rb;
+        load(0, ra);
+        for (int hb = 0; hb < s.nhb; hb += 2) {
+            if (hb + 1 < s.nhb) load(hb + 1, rb);
+            stage(hb, ra);
+            ctx.sync();
+            if (hb + 1 >= s.nhb) break;
+            if (hb + 2 < s.nhb) load(hb + 2, ra);
+            stage(hb + 1, rb);
+            ctx.sync();
+        }
+    }
+
     // ---- compute wave ---------------------------------------------------------------------------------------------
     struct Wave {
         wl_v2 twl[NT], twh[NT];    // row-synthesis tap pairs of the W-low / W-high bank (shifted by one for SODD)
@@ -318,7 +391,17 @@ struct WlSfbStrip {
 #if defined(__HIPCC__)
             __builtin_amdgcn_s_setprio(2);
 #endif
-            stager(a, s, ctx, plane, lane, wave - WL_STRIP_CWAVES);
+            const int b = wave - WL_STRIP_CWAVES;
+            if (WL_STRIP_DIRECT) {
+                switch ((s.ng + 63) >> 6) {
+                    case 1: stager_direct<1>(a, s, ctx, plane, lane, b); break;
+                    case 2: stager_direct<2>(a, s, ctx, plane, lane, b); break;
+                    case 3: stager_direct<3>(a, s, ctx, plane, lane, b); break;
+                    case 4: stager_direct<4>(a, s, ctx, plane, lane, b); break;
+                    case 5: stager_direct<5>(a, s, ctx, plane, lane, b); break;
+                    default: stager_direct<6>(a, s, ctx, plane, lane, b); break;
+                }
+            } else stager(a, s, ctx, plane, lane, b);
         } else if (64 * wave < s.u1 - s.u0) {
             compute(a, s, ctx, plane, wave, lane);
         } else {

@@ -1,7 +1,7 @@
 #!/bin/bash
-OUT=gpurun_out/r03f; mkdir -p $OUT
-WL_LIB=ab/libwl_time.so timeout 120 python tools/gpu_strip_time.py 2>>$OUT/err.log | tee -a $OUT/time.jsonl
-for v in base nostage nocomp; do
+OUT=gpurun_out/r03p; mkdir -p $OUT
+
+for v in base dma; do
   if [ $v = base ]; then L=""; else L="ab/libwl_$v.so"; fi
   WL_LIB=$L PROBE=short timeout 300 python tools/gpu_strip_probe.py 2>>$OUT/err.log | python -c "
 import sys, json
