@@ -32,6 +32,7 @@ with torch.no_grad():
         x = torch.randn(*shape, device=dev)
         out = {'case': tag}
         res = {}
+        lib.wl_set_option(b'scat_stream', 1)
         for ns in (0, 1):
             lib.wl_set_option(b'no_stream', ns)
             y = m(x)
