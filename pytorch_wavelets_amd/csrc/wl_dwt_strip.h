@@ -298,7 +298,8 @@ struct WlAfbStrip {
     // sets, and stages the other.  No DMA ring in LDS, no counted waits (the compiler tracks ordinary loads), no DMA
     // instruction issue - which cost a stager ~250 cycles apiece under load.
     static const int MAXG = 6;             // 4-cell groups per lane and row: strips of up to 6 x 64 x 4 cells
-    typedef T Quad4 __attribute__((ext_vector_type(4), may_alias));
+    // (element-aligned: rows of any width and pitch; gfx950 takes unaligned vector loads)
+    typedef T Quad4 __attribute__((ext_vector_type(4), aligned(sizeof(T)), may_alias));
     struct RowRegs { Quad4 g[MAXG]; T h[2]; };
     template <int DM, int NGL>
     static WL_DEV void stage_regs(const RowRegs& rr, char* drow, int imin, int imax, bool zero) {
@@ -350,12 +351,15 @@ struct WlAfbStrip {
                 goff[i] = (i >= imin && i < imax) ? col * SZ : 0;
             }
         }
-        // mirrored cells (symmetric / reflect, strips at either edge): a lane handles cells lane and lane + 64
+        // single cells: the mirrored halo (symmetric / reflect, strips at either edge) and the last 1-3 columns of a row
+        // whose width is not a multiple of four (the whole groups stop before them); a lane handles cells lane, lane + 64
         int hdst[2], hoff[2];
         {
             const int e_hi = 2 * (s.k1 - 1) + a.base + LT - 1 + 2;
             const int nl = s.e_lo < 0 ? -s.e_lo : 0, nr = e_hi > a.W - 1 ? e_hi - (a.W - 1) : 0;
             const int NH = (a.ext == WL_EXT_SYM || a.ext == WL_EXT_REFL) ? nl + nr : 0;
+            const int t0 = s.c0a + (a.W - s.c0a) / 4 * 4;              // first column behind the whole groups
+            const int NT = (!wrap && t0 <= e_hi && t0 < a.W) ? a.W - t0 : 0;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int c = lane + 64 * u;
@@ -364,6 +368,10 @@ struct WlAfbStrip {
                     const int e = c < nl ? s.e_lo + c : a.W + (c - nl);
                     hdst[u] = staged_of(s, e - s.c0a) * 4;
                     hoff[u] = wl_ext(e, a.W, a.ext) * SZ;
+                } else if (c < NH + NT) {
+                    const int e = t0 + (c - NH);
+                    hdst[u] = staged_of(s, e - s.c0a) * 4;
+                    hoff[u] = e * SZ;
                 }
             }
         }

@@ -164,8 +164,8 @@ struct WlSfbStrip {
     // ---- stager wave, direct form (see wl_dwt_strip.h): source b, two coefficient rows per half-batch, loaded straight
     // into registers one half-batch ahead; NGL = 4-cell groups per lane and row (compile-time: static load counts)
     static const int MAXG = 6;
-    typedef T Quad4 __attribute__((ext_vector_type(4), may_alias));
-    template <int NGL> struct RowRegs { Quad4 g[2][NGL]; };
+    typedef T Quad4 __attribute__((ext_vector_type(4), aligned(sizeof(T)), may_alias));   // element-aligned: any row width / pitch
+    template <int NGL> struct RowRegs { Quad4 g[2][NGL]; T t[2]; };
     template <int NGL>
     static WL_DEV void stager_direct(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int lane, int b) {
         const char* bp = b == 0 ? reinterpret_cast<const char*>(a.ll + (size_t)plane * a.ll_ps)
@@ -190,6 +190,15 @@ struct WlSfbStrip {
                 goff[i] = (i >= imin && i < imax) ? col * SZ : 0;
             }
         }
+        // the last 1-3 coefficients of a row whose width is not a multiple of four (the whole groups stop before them):
+        // lane c < NT takes cell t0 + c of both rows
+        int tdst = -1, toff = 0;
+        {
+            const int q_hi = 2 * (s.u1 - 1) + (a.sw + SODD) / 2 + 1;
+            const int t0 = s.c0a + (a.Kw - s.c0a) / 4 * 4;
+            const int NTL = (!a.per && t0 <= q_hi && t0 < a.Kw) ? a.Kw - t0 : 0;
+            if (lane < NTL) { tdst = (t0 + lane - s.c0a + s.dm) * 4; toff = (t0 + lane) * SZ; }
+        }
         auto load = [&](int h, RowRegs<NGL>& rr) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -199,6 +208,7 @@ struct WlSfbStrip {
                 const char* grow = bp + (size_t)row * row_stride;
 #pragma unroll
                 for (int i = 0; i < NGL; ++i) rr.g[r][i] = *reinterpret_cast<const Quad4*>(grow + goff[i]);
+                rr.t[r] = *reinterpret_cast<const T*>(grow + toff);
             }
         };
         auto stage = [&](int hb, const RowRegs<NGL>& rr) {
@@ -219,6 +229,7 @@ struct WlSfbStrip {
                         dst[0] = v0; *reinterpret_cast<wl_f2*>(dst + 1) = w; dst[3] = v3;
                     }
                 }
+                if (tdst >= 0) *reinterpret_cast<float*>(sslot + r * a.st_pitch + tdst) = (float)rr.t[r];
             }
         };
         RowRegs<NGL> ra, rb;

@@ -280,14 +280,14 @@ def afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=False):
     N, C, H, W = x.shape
     L = h_w_lo.numel()
     es = x.element_size()
-    if (x.dtype == torch.float64 or h_h_lo.numel() != L or L % 2 or L > 20 or (W * es) % 16 or W < 2 * L or H < 2
-            or x.numel() == 0 or (mode == 2 and (H + (H & 1) < L - 1 or W + (W & 1) < L - 1))):
+    if (x.dtype == torch.float64 or h_h_lo.numel() != L or L % 2 or L > 20 or W < 2 * L or H < 2 or x.numel() == 0
+            or (mode in (2, 6) and W % 4) or (mode == 2 and (H + (H & 1) < L - 1 or W + (W & 1) < L - 1))):
         return None
     if not force and W * es < 2048:
         return None                      # the engine's policy: narrower rows stay on the tile kernels
     x, x_ps, x_rs = _planes(x)
     key = ('afbs', x.device, x.dtype, N * C, H, W, x_ps, x_rs, L, mode, bool(force))
-    if key in _FUSED_DECLINED or x.data_ptr() % 16 or (x_rs * es) % 16 or (x_ps * es) % 16:
+    if key in _FUSED_DECLINED:
         return None
     hwl, hwh, hhl, hhh = (_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi))
     Kh, Kw = coeff_len(H, L, mode), coeff_len(W, L, mode)
@@ -313,7 +313,7 @@ def sfb2d_stream(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None, f
     N, C, Kh, Kw = ll.shape
     L = g_w_lo.numel()
     es = ll.element_size()
-    if (g_h_lo.numel() != L or L % 2 or L > 20 or (Kw * es) % 16 or Kw < L or Kh < L // 2 or ll.numel() == 0
+    if (g_h_lo.numel() != L or L % 2 or L > 20 or (mode == 2 and Kw % 4) or Kw < L or Kh < L // 2 or ll.numel() == 0
             or tuple(highs.shape) != (N, C, 3, Kh, Kw) or highs.dtype != ll.dtype
             or (mode == 2 and (2 * Kh < L - 2 or 2 * Kw < L - 2))):
         return None
@@ -327,7 +327,7 @@ def sfb2d_stream(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None, f
     highs = highs.contiguous()
     _same_device(ll, highs)
     key = ('sfbs', ll.device, ll.dtype, N * C, Kh, Kw, ll_ps, ll_rs, OH, OW, L, mode, bool(force))
-    if (key in _FUSED_DECLINED or ll.data_ptr() % 16 or highs.data_ptr() % 16 or (ll_rs * es) % 16 or (ll_ps * es) % 16):
+    if key in _FUSED_DECLINED:
         return None
     gwl, gwh, ghl, ghh = (_taps(g, ll) for g in (g_w_lo, g_w_hi, g_h_lo, g_h_hi))
     y = torch.empty((N, C, OH, OW), dtype=ll.dtype, device=ll.device)

@@ -431,8 +431,17 @@ def test_strip_kernel_float16_and_strided_input_and_declines():
         r2 = ops.afb2d_stream(xv, *th, 1, force=True)
         o2 = wo.dwt_forward(xv.double().numpy(), 1, h0, h1, h0, h1, 'symmetric')
         assert r2 is not None and np.abs(r2[0].numpy() - o2[0]).max() < 2e-6 * np.abs(o2[0]).max()
-        # outside the envelope: odd width (rows that are not whole 16-byte pieces), float64, the engine's own policy
-        assert ops.afb2d_stream(torch.randn(1, 1, 32, 63, dtype=torch.float32), *th, 1, force=True) is None
+        # odd widths and pitches, an offset base pointer: element-aligned loads (the last 1-3 columns go as single cells)
+        xo = torch.zeros(1, 2, 40, 262, dtype=torch.float32)
+        xw = xo[..., 1:260]
+        xw.copy_(torch.tensor(rng.randn(1, 2, 40, 259), dtype=torch.float32))
+        r3 = ops.afb2d_stream(xw, *th, 1, force=True)
+        o3 = wo.dwt_forward(xw.double().numpy(), 1, h0, h1, h0, h1, 'symmetric')
+        assert r3 is not None and np.abs(r3[0].numpy() - o3[0]).max() < 2e-6 * np.abs(o3[0]).max()
+        assert np.abs(r3[1].numpy() - o3[1][0]).max() < 2e-6 * np.abs(o3[1][0]).max()
+        # outside the envelope: wrapped groups must be whole (periodization of a width that is not a multiple of 4),
+        # float64, the engine's own policy
+        assert ops.afb2d_stream(torch.randn(1, 1, 32, 62, dtype=torch.float32), *th, 2, force=True) is None
         assert ops.afb2d_stream(torch.randn(1, 1, 32, 64).double(), *th, 1, force=True) is None
         assert ops.afb2d_stream(torch.randn(1, 1, 32, 64, dtype=torch.float32), *th, 1) is None   # rows under 2 KiB: tile kernels
         assert ops.afb2d_stream(torch.randn(1, 1, 32, 64, dtype=torch.float32), *th, 1, force=True) is not None
@@ -503,7 +512,11 @@ def test_strip_synthesis_float16_modules_and_declines(monkeypatch):
         o = wo.sfb2d_level(lo.double().numpy(), hi.double().numpy(), g0, g1, g0, g1, 'periodization')
         assert np.abs(res.double().numpy() - o).max() < 2e-3 * np.abs(o).max()
         f32 = torch.float32
-        assert ops.sfb2d_stream(torch.randn(1, 1, 16, 30, dtype=f32), torch.randn(1, 1, 3, 16, 30, dtype=f32), *tg, 1, force=True) is None   # rows not whole pieces
+        assert ops.sfb2d_stream(torch.randn(1, 1, 16, 30, dtype=f32), torch.randn(1, 1, 3, 16, 30, dtype=f32), *tg, 2, force=True) is None   # wrapped groups not whole
+        lo3, hi3 = torch.tensor(rng.randn(1, 2, 36, 259), dtype=f32), torch.tensor(rng.randn(1, 2, 3, 36, 259), dtype=f32)
+        r3 = ops.sfb2d_stream(lo3, hi3, *tg, 1, force=True)             # odd coefficient width: element-aligned loads
+        o3 = wo.sfb2d_level(lo3.double().numpy(), hi3.double().numpy(), g0, g1, g0, g1, 'symmetric')
+        assert r3 is not None and np.abs(r3.numpy() - o3).max() < 2e-6 * np.abs(o3).max()
         assert ops.sfb2d_stream(torch.randn(1, 1, 16, 32, dtype=f32), None, *tg, 1, force=True) is None                                       # no highs
         assert ops.sfb2d_stream(torch.randn(1, 1, 16, 32, dtype=f32), torch.randn(1, 1, 3, 16, 32, dtype=f32), *tg, 2) is None                # policy: narrow
         # modules: DWTInverse (periodization, 16 taps: the fused kernel declines) on the strip kernel = the tile path, and the

@@ -32,9 +32,13 @@ cases = [('cfg5 L1', 'db8', 'periodization', (32, 16, 1024, 1024), torch.float16
          ('1024 db4 per', 'db4', 'periodization', (16, 3, 512, 512), torch.float32),
          ('512 db4 per', 'db4', 'periodization', (128, 3, 256, 256), torch.float32),
          ('1024 db8 sym', 'db8', 'symmetric', (16, 3, 520, 520), torch.float32),
-         ('2048 db2 zero fp16', 'db2', 'zero', (8, 3, 1032, 1032), torch.float16)]
+         ('2048 db2 zero fp16', 'db2', 'zero', (8, 3, 1032, 1032), torch.float16),
+         ('512 db8 sym', 'db8', 'symmetric', (128, 3, 263, 263), torch.float32), ('512 db4 sym', 'db4', 'symmetric', (128, 3, 259, 259), torch.float32),
+         ('1024 db4 sym', 'db4', 'symmetric', (16, 3, 515, 515), torch.float32), ('1024 db4 sym L2', 'db4', 'symmetric', (16, 3, 261, 261), torch.float32)]
 if os.environ.get('PROBE') == 'short':
     cases = cases[:2]
+if os.environ.get('PROBE') == 'odd':
+    cases = cases[-4:]
 for tag, wave, mode, cshape, dt in cases:
     g0, g1 = filters.dwt_synthesis_taps(wave)
     tg = [torch.tensor(v, dtype=torch.float32, device=dev) for v in (g0, g1, g0, g1)]

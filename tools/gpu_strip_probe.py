@@ -36,7 +36,11 @@ cases = [('cfg5 L1', 'db8', 'periodization', (32, 16, 2048, 2048), torch.float16
          ('512 db4 L1', 'db4', 'symmetric', (128, 3, 512, 512), torch.float32),
          ('2048 db4 fp32', 'db4', 'symmetric', (8, 3, 2048, 2048), torch.float32),
          ('512 db4 per', 'db4', 'periodization', (128, 3, 512, 512), torch.float32),
-         ('4096 db2 fp16', 'db2', 'zero', (4, 3, 4096, 4096), torch.float16)]
+         ('4096 db2 fp16', 'db2', 'zero', (4, 3, 4096, 4096), torch.float16),
+         ('1024 db4 L2 odd', 'db4', 'symmetric', (16, 3, 515, 515), torch.float32), ('512 db4 L2 odd', 'db4', 'symmetric', (128, 3, 259, 259), torch.float32),
+         ('2048 db4 L2 odd', 'db4', 'symmetric', (8, 3, 1027, 1027), torch.float32)]
+if os.environ.get('PROBE') == 'odd':
+    cases = cases[-3:]
 if os.environ.get('PROBE') == 'short':
     cases = [c for c in cases if c[0] in ('cfg5 L1', 'cfg5 L3', '512 db8 L1', '1024 db4 L1')]
 for tag, wave, mode, shape, dt in cases:
