@@ -84,7 +84,8 @@ def cpu_baseline(args):
         tried[str(nt)] = round(mp, 2)
         if best is None or mp > best[1]:
             best = (nt, mp, reps)
-    out = {'value': round(best[1], 2), 'unit': 'Mpixels/s', 'cores': best[0], 'kind': 'restated-torch',
+    out = {'value': round(best[1], 2), 'unit': 'Mpixels/s', 'cores': best[0], 'kind': 'port',
+           'port_of': 'the reference\'s own formulation restated on PyTorch-CPU (oracle/torch_cpu.py)',
            'host_cores': ncores, 'mpix_s_by_torch_threads': tried,
            'sample': 'oracle/torch_cpu.py (the reference\'s conv2d / conv_transpose2d formulation on PyTorch-CPU, fp32), '
                      'fwd+inv J=3 db4 symmetric on %dx3x512x512, %d reps at the best thread count; the real reference '

@@ -42,7 +42,9 @@ int wl_version(void);
 const char* wl_backend(void);
 
 /* Diagnostics.  wl_set_option("generic_only", 1) routes every operator to the runtime-L generic kernels (the test-suite
- * compares the two kernel families); the initial value is read once from $WL_GENERIC_ONLY.  Returns 0, or
+ * compares the two kernel families); the initial value is read once from $WL_GENERIC_ONLY.  ("no_stream", 1) keeps the
+ * level-1 DTCWT entry points off their strip kernels (tile kernels instead);
+ * ("scat_stream", 1) lets wl_scat_fwd_level1 try the strip kernel (measured no faster: off by default).  Returns 0, or
  * WL_ERR_UNSUPPORTED for an unknown name.  wl_last_kernel(): name of the kernel functor launched last by any thread of
  * the process (static storage; autograd runs backward passes on its own threads), so that a benchmark can label its numbers with the dispatch actually taken. */
 int wl_set_option(const char* name, int value);
