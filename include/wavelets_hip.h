@@ -143,6 +143,18 @@ int wl_dtcwt_fwd_level1(const void* x, void* ll, void* highs, int dtype, int64_t
 int wl_dtcwt_fwd_level2(const void* x, void* ll, void* highs, int dtype, int64_t planes, int H, int W,
                         const void* h0a, const void* h0b, const void* h1a, const void* h1b, int L, void* stream);
 
+/* Levels 1 AND 2 of the forward in ONE launch (csrc/wl_dtcwt_fused.h) = FWD_J1.forward followed by FWD_J2PLUS.forward the
+ * way DTCWTForward.forward chains them (dtcwt/transform2d.py:121-141), the level-1 lowpass staying on chip: x (planes,H,W)
+ * -> highs1 (planes,6,H/2,W/2,2), ll2 (planes,H/2,W/2), highs2 (planes,6,H/4,W/4,2).  Symmetric mode (1), H and W
+ * multiples of 4, float32 / float16, the (5,7) and (5,3) level-1 pairs with 10-tap level-2 filters; the level-1 LOWPASS
+ * FILTER MUST BE SYMMETRIC (h0o[t] == h0o[L0-1-t], true of every biorthogonal table of the reference: the rows above /
+ * below the plane that level 2 reads are computed from the extended input instead of mirrored).  policy 0 = the engine
+ * decides whether the launch pays, 1 = force.  Returns WL_ERR_UNSUPPORTED outside its envelope: callers then chain
+ * wl_dtcwt_fwd_level1 and wl_dtcwt_fwd_level2. */
+int wl_dtcwt_fwd_level12(const void* x, void* highs1, void* ll2, void* highs2, int dtype, int64_t planes, int H, int W,
+                         const void* h0o, int L0, const void* h1o, int L1, const void* h0a, const void* h0b,
+                         const void* h1a, const void* h1b, int LQ, int mode, int policy, void* stream);
+
 /* Level-1 inverse = INV_J1.forward -> inv_j1 (transform_funcs.py:152-184, :419-431): c2q x 3, 4 colfilter,
  * 2 rowfilter, 3 adds.  ll (planes,H,W) through strides (so the 1-px crop of transform_funcs.py:171-176 is a
  * view) or NULL; highs (planes,6,H/2,W/2,2) or NULL; y (planes,H,W). */

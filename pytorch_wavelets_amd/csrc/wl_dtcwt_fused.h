@@ -1,0 +1,423 @@
+// Levels 1 AND 2 of the DTCWT forward in one streaming launch: fwd_j1 followed by fwd_j2plus (reference
+// dtcwt/transform_funcs.py:98-121 and :226-249 = coldfilt / rowdfilt of dtcwt/lowlevel.py:99-151), the way
+// DTCWTForward.forward chains them (dtcwt/transform2d.py:121-141) - without the level-1 lowpass ever leaving the chip.
+// Level 1 is undecimated, so LL1 is as large as the image: written and read back it is 8 of the 28 bytes per pixel the
+// two levels move.  Here it lives in a two-slot LDS ring of four rows.
+//
+// A workgroup owns one (plane, strip of quad columns, segment of 4-row groups) and streams down it, four rows per
+// half-batch, with three kinds of waves:
+//   * 4 stager waves: one input row each per half-batch, loaded as 4-cell groups straight into registers one half-batch
+//     ahead (wl_dwt_strip.h), converted to float32 and staged with the mirrored cells of the plane's edges materialised;
+//   * 4 level-1 waves: the lanes of WlDtFwd1Strip (a lane owns the two columns of a quad column, row filter pair into
+//     circular register windows, column filter pair, q2c, the level-1 band-pass stores).  The lowpass goes into the LL1
+//     ring instead of memory - including, at the plane's left / right edge, the mirrored copies level 2 will read;
+//   * 2 level-2 waves, one half-batch behind: a lane owns FOUR LL1 columns = two half-resolution columns.  Per LL1 row
+//     it reads the 2 LQ samples around them from the ring and runs the dual-tree row filters (even samples meet
+//     (h0b, h1b), odd ones (h0a, h1a): one packed FMA per sample), keeps the last 2 LQ row-filtered rows in a lane-private
+//     LDS window (no synchronisation: nobody else reads them), and every four rows runs the column filters over the
+//     window: a 2 x 2 block of LL2 and, through q2c, one coefficient of each of the six level-2 orientations.
+// Rows and columns outside a segment / strip that level 2 needs (LQ - 2 = 8 either side) are computed, not exchanged:
+// the level-1 lanes run over them without storing their band-pass outputs.  Above / below the PLANE the same happens on
+// the symmetrically extended input; because the level-1 lowpass filter is symmetric (odd length, linear phase: every
+// biorthogonal table of the reference) the result IS the symmetric extension of LL1 that coldfilt applies - the caller
+// vouches for the symmetry (the Python layer checks the filter table on the host when the module is built).
+#pragma once
+#include "wl_dtcwt_strip.h"
+
+// acc += tap * s.x / s.y (both halves), the tap pair in vector registers (per-lane taps)
+#if defined(__HIPCC__)
+WL_DEV void wl_pk_fma_x_v(wl_v2& acc, wl_v2 tap, wl_v2 s) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(tap), "v"(s));
+}
+WL_DEV void wl_pk_fma_y_v(wl_v2& acc, wl_v2 tap, wl_v2 s) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(tap), "v"(s));
+}
+#else
+inline void wl_pk_fma_x_v(wl_v2& acc, wl_v2 tap, wl_v2 s) { wl_pk_fma_x(acc, tap, s); }
+inline void wl_pk_fma_y_v(wl_v2& acc, wl_v2 tap, wl_v2 s) { wl_pk_fma_y(acc, tap, s); }
+#endif
+
+#if defined(WL_DT12_TIME) && defined(__HIPCC__)
+#define WL_DT12_TICK() __builtin_readcyclecounter()
+#else
+#define WL_DT12_TICK() 0ull
+#endif
+// (timing builds: workgroup 0 leaves (total, barrier) kilocycles of one wave per role in ll2[16..21])
+#define WL_DT12_SYNC() { const unsigned long long t_ = WL_DT12_TICK(); ctx.sync(); tbar += WL_DT12_TICK() - t_; }
+#ifndef WL_DT12_ABLATE
+#define WL_DT12_ABLATE 0        // A/B builds: 1 = level-2 waves idle, 2 = no level-1 band-pass stores, 4 = no level-2 stores, 8 = no level-1 arithmetic
+#endif
+
+template <typename T>
+struct WlDtFusedArgs {
+    WlDtFwd1Args<T> f;             // level 1: x, highs (ll = z = nullptr), taps, H = He, W = We (multiples of 4), ext = symmetric
+    T* ll2;                        // (NC, H/2, W/2)
+    T* highs2;                     // (NC, 6, H/4, W/4, 2)
+    const float* h0a; const float* h0b; const float* h1a; const float* h1b;   // LQ taps each
+    int64_t nblocks;
+    int nstrips, strip_quads;      // own quad columns per strip (even); the last strip may be narrower
+    int nseg, seg_groups;          // own 4-row groups per segment
+    int st_off, st_pitch;          // staged input rows: 2 slots x 4 rows x st_pitch bytes (float32)
+    int l1_off, l1_pitch;          // LL1 ring: 2 slots x 4 rows x l1_pitch bytes
+    int w2_off;                    // level-2 windows: LQ rows x 256 lanes x 16 bytes
+    int lds_bytes;
+};
+
+template <typename T, int L0, int L1, int LQ>
+struct WlDtFwd12Strip {
+    typedef WlDtFusedArgs<T> Args;
+#ifndef WL_DT12_SW
+#define WL_DT12_SW 2
+#endif
+    static const int CW = 4, QW = 4, SW = WL_DT12_SW;  // level-1, level-2 and stager waves
+    static const int LROWS = 4 / SW;                   // rows of a half-batch per stager wave
+    static const int kWaves = CW + QW + SW;
+    static const int kThreads = 64 * kWaves;
+    static const int kMinWaves = SW == 2 ? 5 : 6;      // two workgroups of 10 (12) waves per CU: at most 96 (80) registers
+    static const int SZ = (int)sizeof(T);
+    static const int M0 = L0 / 2, M1 = L1 / 2, M = M0 > M1 ? M0 : M1;
+    static const int LW = (2 * M + 1 + 3) / 4 * 4;
+    static const int PERIOD = LW / 4;
+    static const int NS = 2 + 2 * M;
+    static const int NC2 = NS / 2;
+    static const int HQ = LQ - 2;                      // LL1 columns / rows level 2 reads beyond its own, either side
+    static const int HG = HQ / 4;                      // the same in 4-row groups
+    static const int NW2 = 2 * LQ;                     // rows of the level-2 window
+    static const int NG2 = NW2 / 4;
+    static const int WARM1 = (2 * M + 3) / 4;          // half-batches before the first LL1 row of a segment is complete
+    static const int MAXG = 3;                         // 4-cell groups per stager lane and row
+#ifndef WL_DT12_PF
+#define WL_DT12_PF 2
+#endif
+    static const int PF = WL_DT12_PF;                  // register sets of a stager = half-batches a row is requested ahead
+    static_assert(HQ % 4 == 0, "level-2 filters of 10, 14 or 18 taps");
+    typedef WlDtFwd1Strip<T, L0, L1> K1;               // row / column filters of the level-1 lanes
+
+    struct Strip {
+        int q0, q1;            // own quad columns
+        int qa, qb;            // quad columns the level-1 lanes run over (own + what level 2 needs of the neighbours)
+        int e_lo;              // first extended pixel column a level-1 lane reads = staged cell 4 (whole groups start up to 3 cells earlier)
+        int gc0, ng;           // first 4-column group loaded, number of groups
+        int nl, nr;            // mirrored cells left / right of the row
+        int g_lo, g_hi;        // own 4-row groups
+        int o_base;            // LL1 row of (half-batch 0, row 0): a multiple of 4
+        int nhb1, nhb;         // half-batches of level 1; barriers of the workgroup (level 2 runs one behind; a multiple of PF)
+    };
+    static WL_HD Strip geometry(const Args& a, int strip, int seg) {
+        Strip s;
+        const int Q = a.f.W / 2;
+        s.q0 = strip * a.strip_quads;
+        s.q1 = s.q0 + a.strip_quads < Q ? s.q0 + a.strip_quads : Q;
+        s.qa = s.q0 > 0 ? s.q0 - HQ / 2 : 0;
+        s.qb = s.q1 < Q ? s.q1 + HQ / 2 : Q;
+        s.e_lo = 2 * s.qa - M;
+        const int e_hi = 2 * s.qb - 1 + M;
+        s.nl = s.e_lo < 0 ? -s.e_lo : 0;
+        s.nr = e_hi > a.f.W - 1 ? e_hi - (a.f.W - 1) : 0;
+        s.gc0 = (s.e_lo < 0 ? 0 : s.e_lo) / 4;
+        s.ng = (e_hi > a.f.W - 1 ? a.f.W - 1 : e_hi) / 4 - s.gc0 + 1;
+        const int G = a.f.H / 4;
+        s.g_lo = seg * a.seg_groups;
+        s.g_hi = s.g_lo + a.seg_groups < G ? s.g_lo + a.seg_groups : G;
+        s.o_base = 4 * (s.g_lo - HG - WARM1);
+        s.nhb1 = WARM1 + (s.g_hi - s.g_lo) + 2 * HG;
+        s.nhb = (s.nhb1 + 1 + PF - 1) / PF * PF;
+        return s;
+    }
+
+    static WL_DEV void report(const Args& a, const WlCtx& ctx, int lane, bool first, int slot, unsigned long long t0, unsigned long long tbar) {
+#if defined(WL_DT12_TIME) && defined(__HIPCC__)
+        if (ctx.bid == 0 && first && lane == 0) {
+            a.ll2[16 + slot] = (T)(float)((WL_DT12_TICK() - t0) >> 10);
+            a.ll2[17 + slot] = (T)(float)(tbar >> 10);
+        }
+#endif
+    }
+
+    // ---- stager wave: row `sidx` of every half-batch --------------------------------------------------------------------
+    typedef T Quad4 __attribute__((ext_vector_type(4), aligned(sizeof(T)), may_alias));
+    struct RowRegs { Quad4 g[LROWS][MAXG]; T h[LROWS]; };
+    template <int NGL>
+    static WL_DEV void stager(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int lane, int sidx) {
+        const WlDtFwd1Args<T>& f = a.f;
+        const char* xp = reinterpret_cast<const char*>(f.x + (size_t)plane * f.H * f.W);
+        const int row_stride = f.W * SZ;
+        int goff[MAXG], gdst[MAXG];
+#pragma unroll
+        for (int i = 0; i < MAXG; ++i) {
+            const int g = lane + 64 * i;
+            const int col = 4 * (s.gc0 + g);
+            goff[i] = g < s.ng ? col * SZ : 0;
+            gdst[i] = g < s.ng ? (col - s.e_lo + 4) * 4 : -1;
+        }
+        int hdst = -1, hoff = 0;                               // one mirrored cell per lane
+        if (lane < s.nl + s.nr) {
+            const int e = lane < s.nl ? s.e_lo + lane : f.W + (lane - s.nl);
+            hdst = (e - s.e_lo + 4) * 4;
+            hoff = wl_ext(e, f.W, WL_EXT_SYM) * SZ;
+        }
+        auto load = [&](int h, RowRegs& rr) {
+#pragma unroll
+            for (int r4 = 0; r4 < LROWS; ++r4) {
+                const int r = wl_ext(s.o_base + M + 4 * h + LROWS * sidx + r4, f.H, WL_EXT_SYM);   // input row e = o + M
+                const char* grow = xp + (size_t)r * row_stride;
+#pragma unroll
+                for (int i = 0; i < NGL; ++i) rr.g[r4][i] = *reinterpret_cast<const Quad4*>(grow + goff[i]);
+                rr.h[r4] = *reinterpret_cast<const T*>(grow + hoff);
+            }
+        };
+        auto stage = [&](int hb, const RowRegs& rr) {
+#pragma unroll
+            for (int r4 = 0; r4 < LROWS; ++r4) {
+                char* srow = ctx.smem + a.st_off + ((hb & 1) * 4 + LROWS * sidx + r4) * a.st_pitch;
+#pragma unroll
+                for (int i = 0; i < NGL; ++i) {
+                    if (gdst[i] < 0) continue;
+                    const float v0 = (float)rr.g[r4][i].x, v1 = (float)rr.g[r4][i].y, v2 = (float)rr.g[r4][i].z, v3 = (float)rr.g[r4][i].w;
+                    float* dst = reinterpret_cast<float*>(srow + gdst[i]);
+                    if ((M & 3) == 0) {                        // (the cell of a group's first column = 4 g + 4 + M - 2 qa, qa even)
+                        wl_vf4 w; w.x = v0; w.y = v1; w.z = v2; w.w = v3;
+                        *reinterpret_cast<wl_vf4*>(dst) = w;
+                    } else if ((M & 1) == 0) {
+                        wl_f2 w0, w1; w0.x = v0; w0.y = v1; w1.x = v2; w1.y = v3;
+                        *reinterpret_cast<wl_f2*>(dst) = w0; *reinterpret_cast<wl_f2*>(dst + 2) = w1;
+                    } else {
+                        wl_f2 w; w.x = v1; w.y = v2;
+                        dst[0] = v0; *reinterpret_cast<wl_f2*>(dst + 1) = w; dst[3] = v3;
+                    }
+                }
+                if (hdst >= 0) *reinterpret_cast<float*>(srow + hdst) = (float)rr.h[r4];
+            }
+        };
+        // PF register sets: a row is requested PF - 1 .. PF half-batches before it is staged (measured: 2 .. 5 sets make no
+        // difference - the loads are not what this kernel waits for).  The loads are unconditional (behind the last row: that
+        // row again) and the loop has no branch, so that the compiler can count them and wait for exactly the oldest set.
+        unsigned long long tbar = 0;
+        const unsigned long long tstart = WL_DT12_TICK();
+        RowRegs rr[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) load(u < s.nhb1 ? u : s.nhb1 - 1, rr[u]);
+        for (int hb = 0; hb < s.nhb; hb += PF) {              // (nhb is a multiple of PF: no branch inside the body)
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int h = hb + u;
+                stage(h, rr[u]);                               // (behind level 1's last half-batch: into a slot nobody reads)
+                WL_DT12_SYNC();
+                load(h + PF < s.nhb1 ? h + PF : s.nhb1 - 1, rr[u]);
+            }
+        }
+        report(a, ctx, lane, sidx == 0, 4, tstart, tbar);
+    }
+
+    // ---- level-1 wave ---------------------------------------------------------------------------------------------------
+    static WL_DEV void level1(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int cw, int lane) {
+        const WlDtFwd1Args<T>& f = a.f;
+        const int q = s.qa + 64 * cw + lane;
+        const bool active = q < s.qb;
+        const bool own_q = q >= s.q0 && q < s.q1;
+        typename K1::Wave R;
+#pragma unroll
+        for (int t = 0; t < 2 * M + 1; ++t) {
+            const int t0 = t - (M - M0), t1 = t - (M - M1);
+            const float v0 = t0 >= 0 && t0 < L0 ? (float)f.h0[t0 >= 0 && t0 < L0 ? t0 : 0] : 0.f;
+            const float v1 = t1 >= 0 && t1 < L1 ? (float)f.h1[t1 >= 0 && t1 < L1 ? t1 : 0] : 0.f;
+            R.tr[t] = wl_uniform_v2(wl_v2{v0, v1});
+        }
+#pragma unroll
+        for (int t = 0; t < L0; ++t) R.c0[t] = wl_uniform_v2(wl_v2{(float)f.h0[t], (float)f.h0[t]});
+#pragma unroll
+        for (int t = 0; t < L1; ++t) R.c1[t] = wl_uniform_v2(wl_v2{(float)f.h1[t], (float)f.h1[t]});
+        const int soff = 16 + 8 * (active ? q - s.qa : 0);
+        // LL1 ring: cell 0 = pixel column 2 q0 - HQ.  At the plane's edges the mirrored copies go out with the pixel pair.
+        const int Q = f.W / 2;
+        const int l1c = 2 * q - (2 * s.q0 - HQ);
+        int l1m = -1;                                           // cell of the mirrored pair (its columns swapped)
+        if (q < HQ / 2 && s.q0 == 0) l1m = -2 - 2 * q + HQ;
+        if (q >= Q - HQ / 2 && s.q1 == Q) l1m = 4 * Q - 2 - 2 * q - (2 * s.q0 - HQ);
+        const int r_lo = 4 * s.g_lo, r_hi = 4 * s.g_hi;
+        wl_v2 wa[LW], wb[LW];
+#pragma unroll
+        for (int t = 0; t < LW; ++t) wa[t] = wb[t] = wl_v2{0.f, 0.f};
+        float msum[6];
+        char* const smem = ctx.smem;
+        unsigned long long tbar = 0;
+        const unsigned long long tstart = WL_DT12_TICK();
+        for (int hb0 = 0; hb0 < s.nhb; hb0 += PERIOD) {
+#pragma unroll
+            for (int ph = 0; ph < PERIOD; ++ph) {
+                const int hb = hb0 + ph;
+                if (hb >= s.nhb) break;
+                WL_DT12_SYNC();
+                if (!active || hb >= s.nhb1 || (WL_DT12_ABLATE & 8)) continue;
+                const char* slot = smem + a.st_off + (hb & 1) * 4 * a.st_pitch + soff;
+                char* l1slot = smem + a.l1_off + (hb & 1) * 4 * a.l1_pitch;
+                wl_v2 sr[4][NC2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int u = 0; u < NC2; ++u) {
+                        const wl_f2 t = *reinterpret_cast<const wl_f2*>(slot + i * a.st_pitch + 8 * u);
+                        sr[i][u] = wl_v2{t.x, t.y};
+                    }
+                float ll[4], lh[4], hl[4], hh[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int w = (4 * ph + i) % LW;           // slot of the new input row e = o + M
+                    wa[w] = K1::template row_filter<0>(R, sr[i]);
+                    wb[w] = K1::template row_filter<1>(R, sr[i]);
+                    const int o = s.o_base + 4 * hb + i;       // the row that is complete now: row i of LL1 group o_base / 4 + hb
+                    wl_v2 aL, aH, bL, bH;
+                    K1::col_filter(R, wa, (w + LW - M) % LW, aL, aH);
+                    K1::col_filter(R, wb, (w + LW - M) % LW, bL, bH);
+                    {
+                        wl_f2 p; p.x = aL.x; p.y = bL.x;
+                        *reinterpret_cast<wl_f2*>(l1slot + i * a.l1_pitch + l1c * 4) = p;
+                        if (l1m >= 0) {
+                            wl_f2 m; m.x = bL.x; m.y = aL.x;
+                            *reinterpret_cast<wl_f2*>(l1slot + i * a.l1_pitch + l1m * 4) = m;
+                        }
+                    }
+                    const int p = 2 * (i & 1);                 // (o is even exactly when i is)
+                    ll[p] = aL.x; hl[p] = aL.y; lh[p] = aH.x; hh[p] = aH.y;
+                    ll[p + 1] = bL.x; hl[p + 1] = bL.y; lh[p + 1] = bH.x; hh[p + 1] = bH.y;
+                    if ((i & 1) && own_q && o - 1 >= r_lo && o < r_hi && !(WL_DT12_ABLATE & 2))
+                        wl_dtfwd1_quad_out<T, 0>(f, plane, 0, o - 1, 2 * q, ll, lh, hl, hh, msum);
+                }
+            }
+        }
+        report(a, ctx, lane, cw == 0, 0, tstart, tbar);
+    }
+
+    // ---- level-2 wave ---------------------------------------------------------------------------------------------------
+    // Lanes 0-31 of a wave own the EVEN rows of 32 column groups, lanes 32-63 the ODD rows of the same groups: a row of LL1
+    // meets only the even-row taps (h0b, h1b) or only the odd-row taps (h0a, h1a) of the column filters, so the two halves
+    // share nothing until the epilogue, where q2c mixes them (six values cross the wave by ds_bpermute).  Half the chain
+    // per lane: the level-2 waves were what every barrier waited for (in-kernel counters: busy 89 % of the workgroup's time
+    // with one lane per column group).
+    static WL_DEV void level2(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int qw, int lane) {
+        const WlDtFwd1Args<T>& f = a.f;
+        const int half = lane >> 5;                            // 0: even rows, 1: odd rows
+        const int j0 = 32 * qw + (lane & 31);                  // LL1 columns 2 q0 + 4 j .. + 3
+        const bool active = 2 * j0 < s.q1 - s.q0;
+        const int j = active ? j0 : 0;                         // (idle lanes run along on group 0: the shuffles need every lane)
+        wl_v2 tE[LQ], tO[LQ];                                  // row filters: even samples meet (h0b, h1b), odd ones (h0a, h1a)
+#pragma unroll
+        for (int t = 0; t < LQ; ++t) {
+            tE[t] = wl_uniform_v2(wl_v2{a.h0b[t], a.h1b[t]});
+            tO[t] = wl_uniform_v2(wl_v2{a.h0a[t], a.h1a[t]});
+        }
+        wl_v2 tC[LQ];                                          // column filter of my rows' parity (per lane: vector registers)
+#pragma unroll
+        for (int t = 0; t < LQ; ++t) tC[t] = half ? wl_v2{a.h0a[t], a.h1a[t]} : wl_v2{a.h0b[t], a.h1b[t]};
+        char* const smem = ctx.smem;
+        // my window: LQ rows of one parity, row r at win[r * 64 QW]
+        wl_vf4* const win = reinterpret_cast<wl_vf4*>(smem + a.w2_off) + 64 * qw + lane;
+        const int h2 = f.H / 2, w2 = f.W / 2, w4 = f.W / 4;
+        const size_t qplane = (size_t)(f.H / 4) * w4;
+        typedef WlPair<T> Pair;
+        unsigned long long tbar = 0;
+        const unsigned long long tstart = WL_DT12_TICK();
+        // Ring slot (hb - 1) & 1 holds the four rows of LL1 group G = o_base / 4 + hb - 1.  Mine (rows half, half + 2) are
+        // row-filtered and pushed into the window (row o in slot (o >> 1) mod LQ: afterwards exactly the rows of the window
+        // of group G - HG are there).
+        for (int hb = 0; hb < s.nhb; ++hb) {
+            WL_DT12_SYNC();
+            if (hb < 1 || hb > s.nhb1 || (WL_DT12_ABLATE & 1)) continue;
+            const int G = s.o_base / 4 + hb - 1;
+            if (G < s.g_lo - HG) continue;                                     // rows of the level-1 warm-up
+            const char* l1slot = smem + a.l1_off + (((hb - 1) & 1) * 4 + half) * a.l1_pitch + 16 * j;
+            const int wr = wl_pmod(2 * G, LQ);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                // dual-tree row filters of the 2 LQ samples X[4k + 2 - LQ ..]: k = my column group
+                wl_v2 aE = {0.f, 0.f}, aO = {0.f, 0.f};                        // (lo[2k], hi[2k+1]), (lo[2k+1], hi[2k])
+#pragma unroll
+                for (int u = 0; u < LQ / 2; ++u) {
+                    const wl_vf4 x4 = *reinterpret_cast<const wl_vf4*>(l1slot + 2 * i * a.l1_pitch + 16 * u);
+                    const wl_v2 s0 = {x4.x, x4.y}, s1 = {x4.z, x4.w};
+                    wl_pk_fma_x(aE, tE[2 * u], s0); wl_pk_fma_y(aO, tO[2 * u], s0);
+                    wl_pk_fma_x(aE, tE[2 * u + 1], s1); wl_pk_fma_y(aO, tO[2 * u + 1], s1);
+                }
+                wl_vf4 w; w.x = aE.x; w.y = aE.y; w.z = aO.x; w.w = aO.y;
+                const int r = wr + i >= LQ ? wr + i - LQ : wr + i;
+                win[r * (64 * QW)] = w;
+            }
+            const int kr = G - HG;                                             // its window: rows 4 kr - HQ .. 4 kr + HQ + 3
+            if (kr < s.g_lo || kr >= s.g_hi) continue;
+            // column filters over my LQ rows: xL? = (row 2 kr + half of the lowpass-H plane, ..), xH? likewise highpass-H
+            wl_v2 xL0 = {0.f, 0.f}, xL1 = {0.f, 0.f}, xH0 = {0.f, 0.f}, xH1 = {0.f, 0.f};
+            const int r0 = wl_pmod(2 * kr - HQ / 2, LQ);
+#pragma unroll
+            for (int t = 0; t < LQ; ++t) {
+                const int r = r0 + t >= LQ ? r0 + t - LQ : r0 + t;
+                const wl_vf4 v = win[r * (64 * QW)];
+                const wl_v2 vE = {v.x, v.y}, vO = {v.z, v.w};                  // (lo0, hi1), (lo1, hi0) of the row
+                wl_pk_fma_x_v(xL0, tC[t], vE); wl_pk_fma_y_v(xH1, tC[t], vE);
+                wl_pk_fma_x_v(xL1, tC[t], vO); wl_pk_fma_y_v(xH0, tC[t], vO);
+            }
+            if ((WL_DT12_ABLATE & 4) && xL0.x != 12345.f) continue;
+            const int R = 2 * kr, Cc = s.q0 + 2 * j;                           // half-resolution row / column
+            if (active) {
+                T* lp = a.ll2 + (size_t)plane * h2 * w2 + (size_t)(R + half) * w2 + Cc;
+                Pair p0;
+                p0.a = (T)xL0.x; p0.b = (T)xL1.x;
+                *reinterpret_cast<Pair*>(lp) = p0;
+            }
+            // q2c needs both parities: e? = the even-row lane's x?, o? = the odd-row lane's
+            const int partner = lane ^ 32;
+            const float pL0y = wl_shfl(xL0.y, partner), pL1y = wl_shfl(xL1.y, partner);
+            const float pH0x = wl_shfl(xH0.x, partner), pH1x = wl_shfl(xH1.x, partner);
+            const float pH0y = wl_shfl(xH0.y, partner), pH1y = wl_shfl(xH1.y, partner);
+            const float eL0y = half ? pL0y : xL0.y, eL1y = half ? pL1y : xL1.y, oL0y = half ? xL0.y : pL0y, oL1y = half ? xL1.y : pL1y;
+            const float eH0x = half ? pH0x : xH0.x, eH1x = half ? pH1x : xH1.x, oH0x = half ? xH0.x : pH0x, oH1x = half ? xH1.x : pH1x;
+            const float eH0y = half ? pH0y : xH0.y, eH1y = half ? pH1y : xH1.y, oH0y = half ? xH0.y : pH0y, oH1y = half ? xH1.y : pH1y;
+            const float lh[4] = {oL0y, oL1y, eL0y, eL1y};
+            const float hl[4] = {eH0x, eH1x, oH0x, oH1x};
+            const float hh[4] = {oH0y, oH1y, eH0y, eH1y};
+            // the even-row lane stores orientations 0, 1, 2 (15, 45, 75 degrees), the odd-row lane 5, 4, 3
+            const float k = (float)WL_SQRT1_2;
+            float re[3], im[3];
+            if (half == 0) {
+                re[0] = (lh[0] - lh[3]) * k; im[0] = (lh[1] + lh[2]) * k;
+                re[1] = (hh[0] - hh[3]) * k; im[1] = (hh[1] + hh[2]) * k;
+                re[2] = (hl[0] - hl[3]) * k; im[2] = (hl[1] + hl[2]) * k;
+            } else {
+                re[0] = (lh[0] + lh[3]) * k; im[0] = (lh[1] - lh[2]) * k;
+                re[1] = (hh[0] + hh[3]) * k; im[1] = (hh[1] - hh[2]) * k;
+                re[2] = (hl[0] + hl[3]) * k; im[2] = (hl[1] - hl[2]) * k;
+            }
+            if (active) {
+                const size_t qi = (size_t)(R / 2) * w4 + (Cc / 2);
+                T* hp = a.highs2 + (size_t)plane * 12 * qplane;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int o6 = half ? 5 - u : u;
+                    Pair p; p.a = (T)re[u]; p.b = (T)im[u];
+                    *reinterpret_cast<Pair*>(hp + ((size_t)o6 * qplane + qi) * 2) = p;
+                }
+            }
+        }
+        report(a, ctx, lane, qw == 0, 2, tstart, tbar);
+    }
+
+    static WL_DEV void run(const Args& a, const WlCtx& ctx) {
+        const int tid = ctx.tid;
+        const int wave = wl_uniform(tid >> 6), lane = tid & 63;
+        const int64_t lbid = wl_xcd_remap(ctx.bid, a.nblocks);
+        const int per_plane = a.nstrips * a.nseg;
+        const int64_t plane = lbid / per_plane;
+        const int rem = (int)(lbid - plane * per_plane);
+        const int seg = rem / a.nstrips, strip = rem - seg * a.nstrips;
+        const Strip s = geometry(a, strip, seg);
+        if (wave >= CW + QW) {
+            const int ngl = (s.ng + 63) >> 6;
+            if (ngl <= 1) stager<1>(a, s, ctx, plane, lane, wave - CW - QW);
+            else if (ngl == 2) stager<2>(a, s, ctx, plane, lane, wave - CW - QW);
+            else stager<3>(a, s, ctx, plane, lane, wave - CW - QW);
+        } else if (wave >= CW) {
+            level2(a, s, ctx, plane, wave - CW, lane);
+        } else {
+            level1(a, s, ctx, plane, wave, lane);
+        }
+    }
+};

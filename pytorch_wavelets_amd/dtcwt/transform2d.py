@@ -1,5 +1,6 @@
 """DTCWTForward / DTCWTInverse with the reference's constructor signatures, buffer names and (yl, yh)
 layout (pytorch_wavelets/dtcwt/transform2d.py:20-254), running on the gfx950 engine."""
+import numpy as np
 import torch
 import torch.nn as nn
 from numpy import ndarray
@@ -7,7 +8,7 @@ from numpy import ndarray
 from ..dwt.lowlevel import mode_to_int
 from ..filters import biort as _biort, qshift as _qshift
 from .lowlevel import prep_filt
-from .transform_funcs import FWD_J1, FWD_J2PLUS, INV_J1, INV_J2PLUS, _perm_from_default
+from .transform_funcs import FWD_J1, FWD_J12, FWD_J2PLUS, INV_J1, INV_J2PLUS, _perm_from_default
 
 
 def _is_empty(t):
@@ -32,6 +33,12 @@ class DTCWTForward(nn.Module):
             h0o, h1o = biort[0], biort[1]
         self.register_buffer('h0o', prep_filt(h0o, 1))
         self.register_buffer('h1o', prep_filt(h1o, 1))
+        # a symmetric level-1 lowpass (every biorthogonal table) lets levels 1 and 2 run as one fused launch (FWD_J12)
+        try:
+            h0o_flat = np.asarray(h0o, dtype=np.float64).ravel()
+            self._h0o_symmetric = bool(np.allclose(h0o_flat, h0o_flat[::-1], rtol=0, atol=1e-10))
+        except Exception:   # (taps handed over as something numpy cannot read on the host)
+            self._h0o_symmetric = False
         if isinstance(qshift, str):
             h0a, h0b, _, _, h1a, h1b, _, _ = _qshift(qshift)[:8]
         else:
@@ -52,11 +59,20 @@ class DTCWTForward(nn.Module):
             return x, None
         # odd sizes are extended by edge replication and sizes that are not multiples of 4 by one row /
         # column on both sides (reference :116-135): both happen inside the kernels
-        low, h = FWD_J1.apply(x, self.h0o, self.h1o, self.skip_hps[0], self.o_dim, self.ri_dim, mode)
-        highs[0] = h
-        if self.include_scale[0]:
-            scales[0] = low
-        for j in range(1, self.J):
+        first = 1
+        if (self.J >= 2 and self._h0o_symmetric and not self.skip_hps[0] and not self.skip_hps[1]
+                and not self.include_scale[0]):
+            low, highs[0], highs[1] = FWD_J12.apply(x, self.h0o, self.h1o, self.h0a, self.h1a, self.h0b, self.h1b,
+                                                    self.o_dim, self.ri_dim, mode)
+            if self.include_scale[1]:
+                scales[1] = low
+            first = 2
+        else:
+            low, h = FWD_J1.apply(x, self.h0o, self.h1o, self.skip_hps[0], self.o_dim, self.ri_dim, mode)
+            highs[0] = h
+            if self.include_scale[0]:
+                scales[0] = low
+        for j in range(first, self.J):
             low, h = FWD_J2PLUS.apply(low, self.h0a, self.h1a, self.h0b, self.h1b, self.skip_hps[j],
                                       self.o_dim, self.ri_dim, mode)
             highs[j] = h

@@ -154,6 +154,45 @@ class FWD_J2PLUS(Function):
         return dx, None, None, None, None, None, None, None, None
 
 
+class FWD_J12(Function):
+    """Levels 1 and 2 of the forward as ONE operator: ``FWD_J12.apply(x, h0o, h1o, h0a, h1a, h0b, h1b, o_dim, ri_dim,
+    mode_int) -> (ll2, highs1, highs2)`` = FWD_J1 followed by FWD_J2PLUS (reference dtcwt/transform2d.py:121-141) without
+    the level-1 lowpass in between.  One launch of the fused streaming kernel where the engine takes it (the caller
+    vouches for a symmetric ``h0o``), the two per-level launches otherwise; the backward is the chain of the two
+    per-level backward passes (reference transform_funcs.py:361-374, :395-413)."""
+
+    @staticmethod
+    def forward(ctx, x, h0o, h1o, h0a, h1a, h0b, h1b, o_dim, ri_dim, mode):
+        int_to_mode(mode)
+        ctx.mode = mode
+        ctx.save_for_backward(h0o, h1o, h0a, h1a, h0b, h1b)
+        ctx.dims = (o_dim, ri_dim)
+        ctx.in_hw = tuple(x.shape[-2:])
+        res = ops.dtcwt_fwd12(x, h0o, h1o, h0a, h0b, h1a, h1b, mode)
+        if res is None:
+            ll1, highs1 = ops.dtcwt_fwd1(x, h0o, h1o, mode, False)
+            ll2, highs2 = ops.dtcwt_fwd2(ll1, h0a, h0b, h1a, h1b, False)
+            ctx.mid_hw = tuple(ll1.shape[-2:])
+        else:
+            highs1, ll2, highs2 = res
+            ctx.mid_hw = ctx.in_hw
+        return ll2, to_layout(highs1, o_dim, ri_dim), to_layout(highs2, o_dim, ri_dim)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dl2, dh1, dh2):
+        dx = None
+        if ctx.needs_input_grad[0]:
+            h0o, h1o, h0a, h1a, h0b, h1b = ctx.saved_tensors
+            dh1 = None if _is_empty(dh1) else from_layout(dh1, *ctx.dims)
+            dh2 = None if _is_empty(dh2) else from_layout(dh2, *ctx.dims)
+            dl1 = ops.dtcwt_inv2(dl2, dh2, h0b, h0a, h1b, h1a)          # swapped trees, as in FWD_J2PLUS.backward
+            dl1 = _unpad_grad_both(dl1, ctx.mid_hw)
+            dx = ops.dtcwt_inv1(dl1, dh1, h0o, h1o, ctx.mode)
+            dx = _unpad_grad_odd(dx, ctx.in_hw)
+        return (dx,) + (None,) * 9
+
+
 class INV_J1(Function):
     """Level-1 inverse.  ``INV_J1.apply(lows, highs, g0, g1, o_dim, ri_dim, mode_int) -> y``; ``lows`` or
     ``highs`` may be None / 0-dim (zeros)."""

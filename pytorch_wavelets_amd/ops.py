@@ -547,6 +547,35 @@ def dtcwt_fwd1(x, h0, h1, mode, skip_hps=False):
     return ll, highs
 
 
+def dtcwt_fwd12(x, h0o, h1o, h0a, h0b, h1a, h1b, mode, force=False):
+    """Levels 1 and 2 of the forward in one launch (wl_dtcwt_fwd_level12: the level-1 lowpass stays on chip):
+    x (N,C,H,W) -> (highs1 (N,C,6,H/2,W/2,2), ll2 (N,C,H/2,W/2), highs2 (N,C,6,H/4,W/4,2)), or None when the engine
+    declines (callers chain dtcwt_fwd1 / dtcwt_fwd2).  The caller vouches for a symmetric h0o."""
+    _check_tensor(x, 'x')
+    N, C, H, W = x.shape
+    if mode != 1 or H % 4 or W % 4 or x.dtype not in (torch.float32, torch.float16):
+        return None
+    force = force or STREAM_FORCE
+    key = ('dt12', x.dtype, N * C, H, W, h0o.numel(), h1o.numel(), h0a.numel(), x.device.index)
+    if not force and key in _FUSED_DECLINED:
+        return None
+    x = x.contiguous()
+    t0, t1 = _taps(h0o, x), _taps(h1o, x)
+    ta, tb, tc, td = (_taps(h, x) for h in (h0a, h0b, h1a, h1b))
+    highs1 = torch.empty((N, C, 6, H // 2, W // 2, 2), dtype=x.dtype, device=x.device)
+    ll2 = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
+    highs2 = torch.empty((N, C, 6, H // 4, W // 4, 2), dtype=x.dtype, device=x.device)
+    rc = _call('wl_dtcwt_fwd_level12', x, x.data_ptr(), highs1.data_ptr(), ll2.data_ptr(), highs2.data_ptr(),
+               _DTYPES[x.dtype], N * C, H, W, t0.data_ptr(), t0.numel(), t1.data_ptr(), t1.numel(), ta.data_ptr(),
+               tb.data_ptr(), tc.data_ptr(), td.data_ptr(), ta.numel(), mode, 1 if force else 0, _stream(x))
+    if rc == -3:   # WL_ERR_UNSUPPORTED
+        if not force:
+            _FUSED_DECLINED.add(key)
+        return None
+    _lib.check(rc, 'wl_dtcwt_fwd_level12')
+    return highs1, ll2, highs2
+
+
 def dtcwt_fwd2(x, h0a, h0b, h1a, h1b, skip_hps=False):
     """Level>=2 forward: x (N,C,H,W), H,W even -> ll (N,C,He/2,We/2), highs (N,C,6,He/4,We/4,2) or None."""
     _check_tensor(x, 'x')

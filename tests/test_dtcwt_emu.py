@@ -198,3 +198,60 @@ def test_streaming_level1_inverse_equals_tile_kernel(shape, biort, mode, dtype):
             h.wl_set_option(b'no_stream', 0)
     tol = 5e-3 if dtype == torch.float16 else 2e-6
     assert float((r1.float() - r2.float()).abs().max()) <= tol * float(r2.float().abs().max())
+
+
+@pytest.mark.parametrize('shape,biort,dtype', [((1, 2, 32, 256), 'near_sym_a', torch.float32),
+                                               ((2, 1, 136, 256), 'near_sym_a', torch.float32),
+                                               ((2, 1, 64, 1024), 'near_sym_a', torch.float32),
+                                               ((2, 1, 36, 520), 'near_sym_a', torch.float32),
+                                               ((2, 1, 32, 256), 'legall', torch.float32),
+                                               ((1, 2, 32, 512), 'near_sym_a', torch.float16)])
+def test_fused_levels_1_and_2_equal_the_per_level_kernels(shape, biort, dtype):
+    """Levels 1 + 2 of the forward in one launch (csrc/wl_dtcwt_fused.h: LL1 in an LDS ring, level-2 waves one half-batch
+    behind, halo rows / columns computed on the extended input) against the two per-level launches: plane edges on all four
+    sides, several strips (interior halos) and row segments, float16, and the gradient through the fused Function."""
+    torch.manual_seed(0)
+    x = torch.randn(*shape, dtype=dtype)
+    h = emu_backend.handle()
+    with emu_backend.emulated():
+        xfm = pw.DTCWTForward(J=2, biort=biort).to(dtype)
+        try:
+            yl, yh = xfm(x)
+            assert 'WlDtFwd12Strip' in pw.last_kernel(), pw.last_kernel()
+            if dtype == torch.float32:
+                xg = x.clone().requires_grad_(True)
+                a, b = xfm(xg)
+                ((a * yl).sum() + (b[0] * yh[0]).sum() + (b[1] * yh[1]).sum()).backward()
+                g1 = xg.grad.clone()
+            h.wl_set_option(b'no_stream', 1)
+            yl2, yh2 = xfm(x)
+            assert 'WlDtFwd2Tile' in pw.last_kernel(), pw.last_kernel()
+            if dtype == torch.float32:
+                xg.grad = None
+                a, b = xfm(xg)
+                ((a * yl).sum() + (b[0] * yh[0]).sum() + (b[1] * yh[1]).sum()).backward()
+                assert float((g1 - xg.grad).abs().max()) <= 2e-6 * float(xg.grad.abs().max())
+        finally:
+            h.wl_set_option(b'no_stream', 0)
+    tol = 5e-3 if dtype == torch.float16 else 3e-6
+    assert yl.shape == yl2.shape and yh[0].shape == yh2[0].shape and yh[1].shape == yh2[1].shape
+    assert float((yl.float() - yl2.float()).abs().max()) <= tol * float(yl2.float().abs().max())
+    for u, v in zip(yh, yh2):
+        assert float((u.float() - v.float()).abs().max()) <= tol * float(v.float().abs().max())
+
+
+def test_golden_through_the_forced_fused_kernel(monkeypatch):
+    """The reference's own golden (outputs and input gradient) with levels 1 + 2 forced onto the fused kernel, whatever the
+    engine's policy says about so small a plane."""
+    from pytorch_wavelets_amd import ops
+    took = []
+    orig = ops.dtcwt_fwd12
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        took.append(r is not None)
+        return r
+    monkeypatch.setattr(ops, 'STREAM_FORCE', True)
+    monkeypatch.setattr(ops, 'dtcwt_fwd12', spy)
+    D.check_dtcwt_case('dtcwt_00', 'cpu', torch.float32, 1e-5)
+    assert took and all(took)

@@ -177,3 +177,63 @@ def test_streaming_level1_inverse(shape, biort, mode, dtype):
         finally:
             lib.wl_set_option(b'no_stream', 0)
         assert float((g1 - xg.grad).abs().max()) <= 2e-6 * float(xg.grad.abs().max())
+
+
+@pytest.mark.parametrize('shape,biort,dtype', [((64, 3, 512, 512), 'near_sym_a', torch.float32),
+                                               ((20, 3, 260, 1024), 'near_sym_a', torch.float32),
+                                               ((128, 1, 256, 264), 'legall', torch.float32),
+                                               ((160, 1, 128, 512), 'near_sym_a', torch.float16)])
+def test_fused_levels_1_and_2(shape, biort, dtype):
+    """Levels 1 + 2 of the forward in one launch (csrc/wl_dtcwt_fused.h) against the two per-level launches
+    (wl_set_option no_stream) on every plane, against the oracle on sampled planes, and the gradient through it."""
+    from pytorch_wavelets_amd import _lib
+    torch.manual_seed(1)
+    x = torch.randn(*shape, device=DEV).to(dtype)
+    xfm = pw.DTCWTForward(J=2, biort=biort).to(DEV).to(dtype)
+    lib = _lib.get()
+    try:
+        yl, yh = xfm(x)
+        assert 'WlDtFwd12Strip' in pw.last_kernel(), pw.last_kernel()
+        if dtype == torch.float32:
+            xg = x.clone().requires_grad_(True)
+            a, b = xfm(xg)
+            ((a * yl).sum() + (b[0] * yh[0]).sum() + (b[1] * yh[1]).sum()).backward()
+            g1 = xg.grad.clone()
+        lib.wl_set_option(b'no_stream', 1)
+        yl2, yh2 = xfm(x)
+        assert 'WlDtFwd2Tile' in pw.last_kernel(), pw.last_kernel()
+        if dtype == torch.float32:
+            xg.grad = None
+            a, b = xfm(xg)
+            ((a * yl).sum() + (b[0] * yh[0]).sum() + (b[1] * yh[1]).sum()).backward()
+            assert float((g1 - xg.grad).abs().max()) <= 1e-5 * float(xg.grad.abs().max())
+    finally:
+        lib.wl_set_option(b'no_stream', 0)
+    tol = 5e-3 if dtype == torch.float16 else 3e-6
+    assert float((yl.float() - yl2.float()).abs().max()) <= tol * float(yl2.float().abs().max())
+    for u, v in zip(yh, yh2):
+        assert float((u.float() - v.float()).abs().max()) <= tol * float(v.float().abs().max())
+    hb = F.dtcwt_forward_taps(biort, 'qshift_a')
+    otol = 5e-3 if dtype == torch.float16 else 1e-5
+    for n, c in ((0, 0), (shape[0] - 1, shape[1] - 1)):
+        oyl, oyh = wo.dtcwt_forward(x[n:n + 1, c:c + 1].double().cpu().numpy(), 2, *hb, mode='symmetric')
+        assert np.abs(yl[n:n + 1, c:c + 1].double().cpu().numpy() - oyl).max() <= otol * np.abs(oyl).max()
+        for j in range(2):
+            assert np.abs(yh[j][n:n + 1, c:c + 1].double().cpu().numpy() - oyh[j]).max() <= otol * np.abs(oyh[j]).max()
+
+
+def test_goldens_through_the_forced_fused_kernel(monkeypatch):
+    """The reference's goldens (outputs, reconstruction, input gradient) with levels 1 + 2 forced onto the fused kernel."""
+    from pytorch_wavelets_amd import ops
+    took = []
+    orig = ops.dtcwt_fwd12
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        took.append(r is not None)
+        return r
+    monkeypatch.setattr(ops, 'STREAM_FORCE', True)
+    monkeypatch.setattr(ops, 'dtcwt_fwd12', spy)
+    for name in ('dtcwt_00', 'dtcwt_01'):
+        D.check_dtcwt_case(name, DEV, torch.float32, 1e-5)
+    assert took and all(took)
