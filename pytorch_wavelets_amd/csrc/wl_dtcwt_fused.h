@@ -67,7 +67,7 @@ template <typename T, int L0, int L1, int LQ>
 struct WlDtFwd12Strip {
     typedef WlDtFusedArgs<T> Args;
 #ifndef WL_DT12_SW
-#define WL_DT12_SW 2
+#define WL_DT12_SW 4
 #endif
     static const int CW = 4, QW = 4, SW = WL_DT12_SW;  // level-1, level-2 and stager waves
     static const int LROWS = 4 / SW;                   // rows of a half-batch per stager wave
@@ -91,7 +91,6 @@ struct WlDtFwd12Strip {
 #endif
     static const int PF = WL_DT12_PF;                  // register sets of a stager = half-batches a row is requested ahead
     static_assert(HQ % 4 == 0, "level-2 filters of 10, 14 or 18 taps");
-    typedef WlDtFwd1Strip<T, L0, L1> K1;               // row / column filters of the level-1 lanes
 
     struct Strip {
         int q0, q1;            // own quad columns
@@ -159,7 +158,7 @@ struct WlDtFwd12Strip {
         auto load = [&](int h, RowRegs& rr) {
 #pragma unroll
             for (int r4 = 0; r4 < LROWS; ++r4) {
-                const int r = wl_ext(s.o_base + M + 4 * h + LROWS * sidx + r4, f.H, WL_EXT_SYM);   // input row e = o + M
+                const int r = wl_ext1(s.o_base + M + 4 * h + LROWS * sidx + r4, f.H, WL_EXT_SYM);  // input row e = o + M (one fold: H >= 32)
                 const char* grow = xp + (size_t)r * row_stride;
 #pragma unroll
                 for (int i = 0; i < NGL; ++i) rr.g[r4][i] = *reinterpret_cast<const Quad4*>(grow + goff[i]);
@@ -210,12 +209,56 @@ struct WlDtFwd12Strip {
     }
 
     // ---- level-1 wave ---------------------------------------------------------------------------------------------------
+    // column filter with the taps packed two to a scalar pair: acc += w * (c, c), c = the pair's low / high half
+    template <int HI> static WL_DEV void fma_cc(wl_v2& acc, wl_v2 w, wl_v2 pair) {
+#if defined(__HIPCC__)
+        if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "s"(pair));
+        else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w), "s"(pair));
+#else
+        const float c = HI ? pair.y : pair.x;
+        acc.x = __builtin_fmaf(w.x, c, acc.x); acc.y = __builtin_fmaf(w.y, c, acc.y);
+#endif
+    }
+    struct Taps1 {
+        wl_v2 tr[2 * M + 1];               // row-filter tap pairs (h0[t], h1[t]), both centred in 2M+1 slots (zeros outside)
+        wl_v2 c0[(L0 + 1) / 2];            // column taps, two to a pair: (h0[2u], h0[2u+1])
+        wl_v2 c1[(L1 + 1) / 2];
+    };
+    // row filter pair of column COL of the quad: samples COL .. COL + 2M of the lane's NS -> (lo, hi)
+    template <int COL> static WL_DEV wl_v2 row_filter(const Taps1& R, const wl_v2 (&s)[NC2]) {
+        wl_v2 a0 = (COL & 1) ? wl_pk_mul_y(R.tr[0], s[0]) : wl_pk_mul_x(R.tr[0], s[0]);
+        wl_v2 a1 = ((COL + 1) & 1) ? wl_pk_mul_y(R.tr[1], s[(COL + 1) / 2]) : wl_pk_mul_x(R.tr[1], s[(COL + 1) / 2]);
+#pragma unroll
+        for (int t = 2; t < 2 * M + 1; ++t) {
+            wl_v2& acc = (t & 1) ? a1 : a0;
+            if ((COL + t) & 1) wl_pk_fma_y(acc, R.tr[t], s[(COL + t) / 2]); else wl_pk_fma_x(acc, R.tr[t], s[(COL + t) / 2]);
+        }
+        return a0 + a1;
+    }
+    // column filters of the row whose window is centred on slot `c`: aL = (ll, hl), aH = (lh, hh)
+    static WL_DEV void col_filter(const Taps1& R, const wl_v2 (&w)[LW], int c, wl_v2& aL, wl_v2& aH) {
+        aL = wl_v2{0.f, 0.f}; aH = wl_v2{0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < L0; ++t) {
+            if (t & 1) fma_cc<1>(aL, w[(c + LW - M0 + t) % LW], R.c0[t / 2]); else fma_cc<0>(aL, w[(c + LW - M0 + t) % LW], R.c0[t / 2]);
+        }
+#pragma unroll
+        for (int t = 0; t < L1; ++t) {
+            if (t & 1) fma_cc<1>(aH, w[(c + LW - M1 + t) % LW], R.c1[t / 2]); else fma_cc<0>(aH, w[(c + LW - M1 + t) % LW], R.c1[t / 2]);
+        }
+    }
+
+    // ---- level-1 wave ---------------------------------------------------------------------------------------------------
+    // What bounds this kernel is each wave's own instruction stream (a wave issues at most one instruction per four cycles),
+    // so the epilogue is written for few instructions: the addresses of the twelve band-pass stores of a quad row are one
+    // scalar base per orientation plus ONE 32-bit lane offset, the column taps sit two to a scalar pair (the scalar file is
+    // what overflows first: spilled taps come back through v_readlane + wait states).
     static WL_DEV void level1(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int cw, int lane) {
         const WlDtFwd1Args<T>& f = a.f;
         const int q = s.qa + 64 * cw + lane;
         const bool active = q < s.qb;
         const bool own_q = q >= s.q0 && q < s.q1;
-        typename K1::Wave R;
+        Taps1 R;
 #pragma unroll
         for (int t = 0; t < 2 * M + 1; ++t) {
             const int t0 = t - (M - M0), t1 = t - (M - M1);
@@ -224,9 +267,9 @@ struct WlDtFwd12Strip {
             R.tr[t] = wl_uniform_v2(wl_v2{v0, v1});
         }
 #pragma unroll
-        for (int t = 0; t < L0; ++t) R.c0[t] = wl_uniform_v2(wl_v2{(float)f.h0[t], (float)f.h0[t]});
+        for (int u = 0; u < (L0 + 1) / 2; ++u) R.c0[u] = wl_uniform_v2(wl_v2{(float)f.h0[2 * u], 2 * u + 1 < L0 ? (float)f.h0[2 * u + 1 < L0 ? 2 * u + 1 : 0] : 0.f});
 #pragma unroll
-        for (int t = 0; t < L1; ++t) R.c1[t] = wl_uniform_v2(wl_v2{(float)f.h1[t], (float)f.h1[t]});
+        for (int u = 0; u < (L1 + 1) / 2; ++u) R.c1[u] = wl_uniform_v2(wl_v2{(float)f.h1[2 * u], 2 * u + 1 < L1 ? (float)f.h1[2 * u + 1 < L1 ? 2 * u + 1 : 0] : 0.f});
         const int soff = 16 + 8 * (active ? q - s.qa : 0);
         // LL1 ring: cell 0 = pixel column 2 q0 - HQ.  At the plane's edges the mirrored copies go out with the pixel pair.
         const int Q = f.W / 2;
@@ -235,10 +278,14 @@ struct WlDtFwd12Strip {
         if (q < HQ / 2 && s.q0 == 0) l1m = -2 - 2 * q + HQ;
         if (q >= Q - HQ / 2 && s.q1 == Q) l1m = 4 * Q - 2 - 2 * q - (2 * s.q0 - HQ);
         const int r_lo = 4 * s.g_lo, r_hi = 4 * s.g_hi;
+        // band-pass stores: (re, im) of orientation o6 of quad (qr, q) at  hbase + ((o6 qplane + qr Q + q) 2) elements
+        const unsigned qplane2 = (unsigned)(f.H / 2) * (unsigned)Q * 2u * SZ;      // bytes of one orientation plane (< 2^31: the launcher checks)
+        char* const hbase = reinterpret_cast<char*>(f.highs + (size_t)plane * 12 * ((size_t)(f.H / 2) * Q));
+        const unsigned voff = (unsigned)q * 2u * SZ;
+        typedef WlPair<T> Pair;
         wl_v2 wa[LW], wb[LW];
 #pragma unroll
         for (int t = 0; t < LW; ++t) wa[t] = wb[t] = wl_v2{0.f, 0.f};
-        float msum[6];
         char* const smem = ctx.smem;
         unsigned long long tbar = 0;
         const unsigned long long tstart = WL_DT12_TICK();
@@ -259,16 +306,16 @@ struct WlDtFwd12Strip {
                         const wl_f2 t = *reinterpret_cast<const wl_f2*>(slot + i * a.st_pitch + 8 * u);
                         sr[i][u] = wl_v2{t.x, t.y};
                     }
-                float ll[4], lh[4], hl[4], hh[4];
+                const int o0 = s.o_base + 4 * hb;              // LL1 rows o0 .. o0 + 3 are completed in this half-batch
+                wl_v2 pL[2], pH[2];                            // the quad's upper row: (ll, hl), (lh, hh) of its two columns
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int w = (4 * ph + i) % LW;           // slot of the new input row e = o + M
-                    wa[w] = K1::template row_filter<0>(R, sr[i]);
-                    wb[w] = K1::template row_filter<1>(R, sr[i]);
-                    const int o = s.o_base + 4 * hb + i;       // the row that is complete now: row i of LL1 group o_base / 4 + hb
+                    wa[w] = row_filter<0>(R, sr[i]);
+                    wb[w] = row_filter<1>(R, sr[i]);
                     wl_v2 aL, aH, bL, bH;
-                    K1::col_filter(R, wa, (w + LW - M) % LW, aL, aH);
-                    K1::col_filter(R, wb, (w + LW - M) % LW, bL, bH);
+                    col_filter(R, wa, (w + LW - M) % LW, aL, aH);
+                    col_filter(R, wb, (w + LW - M) % LW, bL, bH);
                     {
                         wl_f2 p; p.x = aL.x; p.y = bL.x;
                         *reinterpret_cast<wl_f2*>(l1slot + i * a.l1_pitch + l1c * 4) = p;
@@ -277,11 +324,23 @@ struct WlDtFwd12Strip {
                             *reinterpret_cast<wl_f2*>(l1slot + i * a.l1_pitch + l1m * 4) = m;
                         }
                     }
-                    const int p = 2 * (i & 1);                 // (o is even exactly when i is)
-                    ll[p] = aL.x; hl[p] = aL.y; lh[p] = aH.x; hh[p] = aH.y;
-                    ll[p + 1] = bL.x; hl[p + 1] = bL.y; lh[p + 1] = bH.x; hh[p + 1] = bH.y;
-                    if ((i & 1) && own_q && o - 1 >= r_lo && o < r_hi && !(WL_DT12_ABLATE & 2))
-                        wl_dtfwd1_quad_out<T, 0>(f, plane, 0, o - 1, 2 * q, ll, lh, hl, hh, msum);
+                    if (!(i & 1)) { pL[0] = aL; pL[1] = bL; pH[0] = aH; pH[1] = bH; continue; }
+                    // the quad (rows o - 1, o; columns 2q, 2q + 1) is complete: q2c of lh, hh, hl (reference
+                    // transform_funcs.py:61-72: p = (upper left, upper right, lower left, lower right))
+                    const int o = o0 + i;
+                    if (!(own_q && o - 1 >= r_lo && o < r_hi) || (WL_DT12_ABLATE & 2)) continue;
+                    const float k = (float)WL_SQRT1_2;
+                    const float lh0 = pH[0].x, lh1 = pH[1].x, lh2 = aH.x, lh3 = bH.x;
+                    const float hh0 = pH[0].y, hh1 = pH[1].y, hh2 = aH.y, hh3 = bH.y;
+                    const float hl0 = pL[0].y, hl1 = pL[1].y, hl2 = aL.y, hl3 = bL.y;
+                    char* const rowp = hbase + (size_t)((unsigned)((o - 1) / 2) * (unsigned)Q * 2u * SZ);   // (uniform)
+                    Pair z;
+                    z.a = (T)((lh0 - lh3) * k); z.b = (T)((lh1 + lh2) * k); *reinterpret_cast<Pair*>(rowp + voff) = z;
+                    z.a = (T)((hh0 - hh3) * k); z.b = (T)((hh1 + hh2) * k); *reinterpret_cast<Pair*>(rowp + (size_t)qplane2 + voff) = z;
+                    z.a = (T)((hl0 - hl3) * k); z.b = (T)((hl1 + hl2) * k); *reinterpret_cast<Pair*>(rowp + 2 * (size_t)qplane2 + voff) = z;
+                    z.a = (T)((hl0 + hl3) * k); z.b = (T)((hl1 - hl2) * k); *reinterpret_cast<Pair*>(rowp + 3 * (size_t)qplane2 + voff) = z;
+                    z.a = (T)((hh0 + hh3) * k); z.b = (T)((hh1 - hh2) * k); *reinterpret_cast<Pair*>(rowp + 4 * (size_t)qplane2 + voff) = z;
+                    z.a = (T)((lh0 + lh3) * k); z.b = (T)((lh1 - lh2) * k); *reinterpret_cast<Pair*>(rowp + 5 * (size_t)qplane2 + voff) = z;
                 }
             }
         }
@@ -310,90 +369,96 @@ struct WlDtFwd12Strip {
 #pragma unroll
         for (int t = 0; t < LQ; ++t) tC[t] = half ? wl_v2{a.h0a[t], a.h1a[t]} : wl_v2{a.h0b[t], a.h1b[t]};
         char* const smem = ctx.smem;
-        // my window: LQ rows of one parity, row r at win[r * 64 QW]
+        // my window: LQ rows of one parity, slot r at win[r * 64 QW].  The rows of half-batch hb go into slots
+        // 2 (hb mod P2) + {0, 1} (P2 = LQ / 2 half-batches fill the window once), and the loop is unrolled by P2 so that
+        // every slot is a compile-time offset: what bounds the kernel is the number of instructions a SIMD has to issue,
+        // scalar ones included.
         wl_vf4* const win = reinterpret_cast<wl_vf4*>(smem + a.w2_off) + 64 * qw + lane;
-        const int h2 = f.H / 2, w2 = f.W / 2, w4 = f.W / 4;
-        const size_t qplane = (size_t)(f.H / 4) * w4;
+        const int Q = f.W / 2, Q2 = f.W / 4;
+        // LL2 rows of my parity: (R + half) w2 + Cc elements; level-2 band-pass: ((o6 qplane + (R / 2) Q2 + Cc / 2) 2) elements
+        char* const lbase = reinterpret_cast<char*>(a.ll2 + (size_t)plane * (f.H / 2) * Q + (size_t)half * Q);
+        char* const hbase = reinterpret_cast<char*>(a.highs2 + (size_t)plane * 12 * ((size_t)(f.H / 4) * Q2));
+        const unsigned qplane2 = (unsigned)(f.H / 4) * (unsigned)Q2 * 2u * SZ;    // bytes of one orientation plane
+        const unsigned Cc = (unsigned)(s.q0 + 2 * j);
+        const unsigned lvoff = Cc * SZ, hvoff = (Cc / 2) * 2u * SZ + (half ? 5u * qplane2 : 0u);
+        const long hstep = half ? -(long)qplane2 : (long)qplane2;               // my three orientations: 0, 1, 2 or 5, 4, 3
         typedef WlPair<T> Pair;
+        const int l1lane = half * a.l1_pitch + 16 * j;
+        const int G0 = s.o_base / 4 - 1;                                       // LL1 group in the ring at half-batch hb: G0 + hb
         unsigned long long tbar = 0;
         const unsigned long long tstart = WL_DT12_TICK();
-        // Ring slot (hb - 1) & 1 holds the four rows of LL1 group G = o_base / 4 + hb - 1.  Mine (rows half, half + 2) are
-        // row-filtered and pushed into the window (row o in slot (o >> 1) mod LQ: afterwards exactly the rows of the window
-        // of group G - HG are there).
-        for (int hb = 0; hb < s.nhb; ++hb) {
-            WL_DT12_SYNC();
-            if (hb < 1 || hb > s.nhb1 || (WL_DT12_ABLATE & 1)) continue;
-            const int G = s.o_base / 4 + hb - 1;
-            if (G < s.g_lo - HG) continue;                                     // rows of the level-1 warm-up
-            const char* l1slot = smem + a.l1_off + (((hb - 1) & 1) * 4 + half) * a.l1_pitch + 16 * j;
-            const int wr = wl_pmod(2 * G, LQ);
+        static const int P2 = LQ / 2;
+        for (int hb0 = 0; hb0 < s.nhb; hb0 += P2) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                // dual-tree row filters of the 2 LQ samples X[4k + 2 - LQ ..]: k = my column group
-                wl_v2 aE = {0.f, 0.f}, aO = {0.f, 0.f};                        // (lo[2k], hi[2k+1]), (lo[2k+1], hi[2k])
+            for (int ph = 0; ph < P2; ++ph) {
+                const int hb = hb0 + ph;
+                if (hb >= s.nhb) break;
+                WL_DT12_SYNC();
+                if (hb < 1 || hb > s.nhb1 || (WL_DT12_ABLATE & 1)) continue;
+                const int G = G0 + hb;
+                if (G < s.g_lo - HG) continue;                                 // rows of the level-1 warm-up
+                const char* l1slot = smem + a.l1_off + ((hb - 1) & 1) * 4 * a.l1_pitch + l1lane;
 #pragma unroll
-                for (int u = 0; u < LQ / 2; ++u) {
-                    const wl_vf4 x4 = *reinterpret_cast<const wl_vf4*>(l1slot + 2 * i * a.l1_pitch + 16 * u);
-                    const wl_v2 s0 = {x4.x, x4.y}, s1 = {x4.z, x4.w};
-                    wl_pk_fma_x(aE, tE[2 * u], s0); wl_pk_fma_y(aO, tO[2 * u], s0);
-                    wl_pk_fma_x(aE, tE[2 * u + 1], s1); wl_pk_fma_y(aO, tO[2 * u + 1], s1);
+                for (int i = 0; i < 2; ++i) {
+                    // dual-tree row filters of the 2 LQ samples X[4k + 2 - LQ ..]: k = my column group
+                    wl_v2 aE = {0.f, 0.f}, aO = {0.f, 0.f};                    // (lo[2k], hi[2k+1]), (lo[2k+1], hi[2k])
+#pragma unroll
+                    for (int u = 0; u < LQ / 2; ++u) {
+                        const wl_vf4 x4 = *reinterpret_cast<const wl_vf4*>(l1slot + 2 * i * a.l1_pitch + 16 * u);
+                        const wl_v2 s0 = {x4.x, x4.y}, s1 = {x4.z, x4.w};
+                        wl_pk_fma_x(aE, tE[2 * u], s0); wl_pk_fma_y(aO, tO[2 * u], s0);
+                        wl_pk_fma_x(aE, tE[2 * u + 1], s1); wl_pk_fma_y(aO, tO[2 * u + 1], s1);
+                    }
+                    wl_vf4 w; w.x = aE.x; w.y = aE.y; w.z = aO.x; w.w = aO.y;
+                    win[(2 * ph + i) * (64 * QW)] = w;
                 }
-                wl_vf4 w; w.x = aE.x; w.y = aE.y; w.z = aO.x; w.w = aO.y;
-                const int r = wr + i >= LQ ? wr + i - LQ : wr + i;
-                win[r * (64 * QW)] = w;
-            }
-            const int kr = G - HG;                                             // its window: rows 4 kr - HQ .. 4 kr + HQ + 3
-            if (kr < s.g_lo || kr >= s.g_hi) continue;
-            // column filters over my LQ rows: xL? = (row 2 kr + half of the lowpass-H plane, ..), xH? likewise highpass-H
-            wl_v2 xL0 = {0.f, 0.f}, xL1 = {0.f, 0.f}, xH0 = {0.f, 0.f}, xH1 = {0.f, 0.f};
-            const int r0 = wl_pmod(2 * kr - HQ / 2, LQ);
+                const int kr = G - HG;                                         // its window: rows 4 kr - HQ .. 4 kr + HQ + 3
+                if (kr < s.g_lo || kr >= s.g_hi) continue;
+                // column filters over my LQ rows, oldest first (slot 2 (ph + 1) mod LQ): xL? of the lowpass-H plane, xH? highpass-H
+                wl_v2 xL0 = {0.f, 0.f}, xL1 = {0.f, 0.f}, xH0 = {0.f, 0.f}, xH1 = {0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < LQ; ++t) {
-                const int r = r0 + t >= LQ ? r0 + t - LQ : r0 + t;
-                const wl_vf4 v = win[r * (64 * QW)];
-                const wl_v2 vE = {v.x, v.y}, vO = {v.z, v.w};                  // (lo0, hi1), (lo1, hi0) of the row
-                wl_pk_fma_x_v(xL0, tC[t], vE); wl_pk_fma_y_v(xH1, tC[t], vE);
-                wl_pk_fma_x_v(xL1, tC[t], vO); wl_pk_fma_y_v(xH0, tC[t], vO);
-            }
-            if ((WL_DT12_ABLATE & 4) && xL0.x != 12345.f) continue;
-            const int R = 2 * kr, Cc = s.q0 + 2 * j;                           // half-resolution row / column
-            if (active) {
-                T* lp = a.ll2 + (size_t)plane * h2 * w2 + (size_t)(R + half) * w2 + Cc;
-                Pair p0;
-                p0.a = (T)xL0.x; p0.b = (T)xL1.x;
-                *reinterpret_cast<Pair*>(lp) = p0;
-            }
-            // q2c needs both parities: e? = the even-row lane's x?, o? = the odd-row lane's
-            const int partner = lane ^ 32;
-            const float pL0y = wl_shfl(xL0.y, partner), pL1y = wl_shfl(xL1.y, partner);
-            const float pH0x = wl_shfl(xH0.x, partner), pH1x = wl_shfl(xH1.x, partner);
-            const float pH0y = wl_shfl(xH0.y, partner), pH1y = wl_shfl(xH1.y, partner);
-            const float eL0y = half ? pL0y : xL0.y, eL1y = half ? pL1y : xL1.y, oL0y = half ? xL0.y : pL0y, oL1y = half ? xL1.y : pL1y;
-            const float eH0x = half ? pH0x : xH0.x, eH1x = half ? pH1x : xH1.x, oH0x = half ? xH0.x : pH0x, oH1x = half ? xH1.x : pH1x;
-            const float eH0y = half ? pH0y : xH0.y, eH1y = half ? pH1y : xH1.y, oH0y = half ? xH0.y : pH0y, oH1y = half ? xH1.y : pH1y;
-            const float lh[4] = {oL0y, oL1y, eL0y, eL1y};
-            const float hl[4] = {eH0x, eH1x, oH0x, oH1x};
-            const float hh[4] = {oH0y, oH1y, eH0y, eH1y};
-            // the even-row lane stores orientations 0, 1, 2 (15, 45, 75 degrees), the odd-row lane 5, 4, 3
-            const float k = (float)WL_SQRT1_2;
-            float re[3], im[3];
-            if (half == 0) {
-                re[0] = (lh[0] - lh[3]) * k; im[0] = (lh[1] + lh[2]) * k;
-                re[1] = (hh[0] - hh[3]) * k; im[1] = (hh[1] + hh[2]) * k;
-                re[2] = (hl[0] - hl[3]) * k; im[2] = (hl[1] + hl[2]) * k;
-            } else {
-                re[0] = (lh[0] + lh[3]) * k; im[0] = (lh[1] - lh[2]) * k;
-                re[1] = (hh[0] + hh[3]) * k; im[1] = (hh[1] - hh[2]) * k;
-                re[2] = (hl[0] + hl[3]) * k; im[2] = (hl[1] - hl[2]) * k;
-            }
-            if (active) {
-                const size_t qi = (size_t)(R / 2) * w4 + (Cc / 2);
-                T* hp = a.highs2 + (size_t)plane * 12 * qplane;
+                for (int t = 0; t < LQ; ++t) {
+                    const wl_vf4 v = win[((2 * (ph + 1) + t) % LQ) * (64 * QW)];
+                    const wl_v2 vE = {v.x, v.y}, vO = {v.z, v.w};              // (lo0, hi1), (lo1, hi0) of the row
+                    wl_pk_fma_x_v(xL0, tC[t], vE); wl_pk_fma_y_v(xH1, tC[t], vE);
+                    wl_pk_fma_x_v(xL1, tC[t], vO); wl_pk_fma_y_v(xH0, tC[t], vO);
+                }
+                if ((WL_DT12_ABLATE & 4) && xL0.x != 12345.f) continue;
+                if (active) {
+                    Pair p0;
+                    p0.a = (T)xL0.x; p0.b = (T)xL1.x;
+                    *reinterpret_cast<Pair*>(lbase + (size_t)((unsigned)(2 * kr) * (unsigned)Q * SZ) + lvoff) = p0;
+                }
+                // q2c needs both parities: e? = the even-row lane's x?, o? = the odd-row lane's
+                const int partner = lane ^ 32;
+                const float pL0y = wl_shfl(xL0.y, partner), pL1y = wl_shfl(xL1.y, partner);
+                const float pH0x = wl_shfl(xH0.x, partner), pH1x = wl_shfl(xH1.x, partner);
+                const float pH0y = wl_shfl(xH0.y, partner), pH1y = wl_shfl(xH1.y, partner);
+                // lh = {oL0y, oL1y, eL0y, eL1y}, hl = {eH0x, eH1x, oH0x, oH1x}, hh = {oH0y, oH1y, eH0y, eH1y} (e = even-row lane);
+                // the even-row lane forms (v0 - v3, v1 + v2) = orientations 0, 1, 2, the odd-row lane (v0 + v3, v1 - v2) = 5, 4, 3
+                const float sg = half ? 1.f : -1.f;
+                const float k = (float)WL_SQRT1_2;
+                float re[3], im[3];
+                {   // lh: v0 = oL0y, v1 = oL1y, v2 = eL0y, v3 = eL1y
+                    const float v0 = half ? xL0.y : pL0y, v1 = half ? xL1.y : pL1y, v2 = half ? pL0y : xL0.y, v3 = half ? pL1y : xL1.y;
+                    re[0] = (v0 + sg * v3) * k; im[0] = (v1 - sg * v2) * k;
+                }
+                {   // hh: v0 = oH0y, v1 = oH1y, v2 = eH0y, v3 = eH1y
+                    const float v0 = half ? xH0.y : pH0y, v1 = half ? xH1.y : pH1y, v2 = half ? pH0y : xH0.y, v3 = half ? pH1y : xH1.y;
+                    re[1] = (v0 + sg * v3) * k; im[1] = (v1 - sg * v2) * k;
+                }
+                {   // hl: v0 = eH0x, v1 = eH1x, v2 = oH0x, v3 = oH1x
+                    const float v0 = half ? pH0x : xH0.x, v1 = half ? pH1x : xH1.x, v2 = half ? xH0.x : pH0x, v3 = half ? xH1.x : pH1x;
+                    re[2] = (v0 + sg * v3) * k; im[2] = (v1 - sg * v2) * k;
+                }
+                if (active) {
+                    char* hp = hbase + (size_t)((unsigned)kr * (unsigned)Q2 * 2u * SZ) + hvoff;
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const int o6 = half ? 5 - u : u;
-                    Pair p; p.a = (T)re[u]; p.b = (T)im[u];
-                    *reinterpret_cast<Pair*>(hp + ((size_t)o6 * qplane + qi) * 2) = p;
+                    for (int u = 0; u < 3; ++u) {
+                        Pair p; p.a = (T)re[u]; p.b = (T)im[u];
+                        *reinterpret_cast<Pair*>(hp) = p;
+                        hp += hstep;
+                    }
                 }
             }
         }
