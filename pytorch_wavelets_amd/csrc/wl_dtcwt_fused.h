@@ -63,24 +63,34 @@ struct WlDtFusedArgs {
     int lds_bytes;
 };
 
-template <typename T, int L0, int L1, int LQ>
+// MODE 2: levels 1 + 2 (above).  The same stagers and level-1 lanes without the level-2 waves are the lean level-1 kernels:
+// MODE 0: fwd_j1 alone (lowpass and band-pass coefficients to memory), MODE 1: ScatLayerj1_f.forward (scatternet/lowlevel.py:
+// 76-111: the 2x2-averaged lowpass and the six smoothed magnitudes sqrt(re^2 + im^2 + b^2) - b, optionally (re, im) / r for
+// the backward pass and the full-resolution lowpass for ScatLayerj2).
+template <typename T, int L0, int L1, int LQ, int MODE = 2, int CW_ = 4>
 struct WlDtFwd12Strip {
     typedef WlDtFusedArgs<T> Args;
 #ifndef WL_DT12_SW
 #define WL_DT12_SW 4
 #endif
-    static const int CW = 4, QW = 4, SW = WL_DT12_SW;  // level-1, level-2 and stager waves
+    // level-1, level-2 and stager waves (CW_ = 2: planes of up to 256 columns, two stagers of two rows each: one wave of the
+    // workgroup per SIMD)
+    static const int CW = CW_, QW = MODE == 2 ? CW_ : 0, SW = CW_ == 2 ? 2 : WL_DT12_SW;
     static const int LROWS = 4 / SW;                   // rows of a half-batch per stager wave
     static const int kWaves = CW + QW + SW;
     static const int kThreads = 64 * kWaves;
-    static const int kMinWaves = SW == 2 ? 5 : 6;      // two workgroups of 10 (12) waves per CU: at most 96 (80) registers
+#ifndef WL_DT12_MINW1
+#define WL_DT12_MINW1 6
+#endif
+    // two workgroups of 10 (12) waves per CU, or three of 8: at most 96 (80) registers
+    static const int kMinWaves = MODE == 1 ? WL_DT12_MINW1 : (SW == 2 && MODE == 2 ? 5 : 6);
     static const int SZ = (int)sizeof(T);
     static const int M0 = L0 / 2, M1 = L1 / 2, M = M0 > M1 ? M0 : M1;
     static const int LW = (2 * M + 1 + 3) / 4 * 4;
     static const int PERIOD = LW / 4;
     static const int NS = 2 + 2 * M;
     static const int NC2 = NS / 2;
-    static const int HQ = LQ - 2;                      // LL1 columns / rows level 2 reads beyond its own, either side
+    static const int HQ = MODE == 2 ? LQ - 2 : 0;      // LL1 columns / rows level 2 reads beyond its own, either side
     static const int HG = HQ / 4;                      // the same in 4-row groups
     static const int NW2 = 2 * LQ;                     // rows of the level-2 window
     static const int NG2 = NW2 / 4;
@@ -120,13 +130,13 @@ struct WlDtFwd12Strip {
         s.g_hi = s.g_lo + a.seg_groups < G ? s.g_lo + a.seg_groups : G;
         s.o_base = 4 * (s.g_lo - HG - WARM1);
         s.nhb1 = WARM1 + (s.g_hi - s.g_lo) + 2 * HG;
-        s.nhb = (s.nhb1 + 1 + PF - 1) / PF * PF;
+        s.nhb = (s.nhb1 + (MODE == 2 ? 1 : 0) + PF - 1) / PF * PF;
         return s;
     }
 
     static WL_DEV void report(const Args& a, const WlCtx& ctx, int lane, bool first, int slot, unsigned long long t0, unsigned long long tbar) {
 #if defined(WL_DT12_TIME) && defined(__HIPCC__)
-        if (ctx.bid == 0 && first && lane == 0) {
+        if (MODE == 2 && ctx.bid == 0 && first && lane == 0) {
             a.ll2[16 + slot] = (T)(float)((WL_DT12_TICK() - t0) >> 10);
             a.ll2[17 + slot] = (T)(float)(tbar >> 10);
         }
@@ -281,8 +291,16 @@ struct WlDtFwd12Strip {
         // band-pass stores: (re, im) of orientation o6 of quad (qr, q) at  hbase + ((o6 qplane + qr Q + q) 2) elements
         const unsigned qplane2 = (unsigned)(f.H / 2) * (unsigned)Q * 2u * SZ;      // bytes of one orientation plane (< 2^31: the launcher checks)
         char* const hbase = reinterpret_cast<char*>(f.highs + (size_t)plane * 12 * ((size_t)(f.H / 2) * Q));
-        const unsigned voff = (unsigned)q * 2u * SZ;
+        const unsigned voff = (unsigned)q * 2u * SZ, voff1 = (unsigned)q * SZ;
         typedef WlPair<T> Pair;
+        char* const lbase = reinterpret_cast<char*>(f.ll + (size_t)plane * f.H * f.W);
+        // ScatLayer output (N, 7, C, H/2, Q): my plane (n, c) of entry 0; entries 1 .. 6 follow C planes apart.  The saved
+        // (re, im) / r are (N, 6, C, H/2, Q)
+        const int64_t n_img = MODE == 1 ? plane / f.C : 0;
+        const int c_img = MODE == 1 ? (int)(plane - n_img * f.C) : 0;
+        const size_t zplane = (size_t)f.C * (f.H / 2) * Q * SZ;
+        char* const zbase = reinterpret_cast<char*>(f.z) + ((size_t)n_img * 7 * f.C + c_img) * ((size_t)(f.H / 2) * Q) * SZ;
+        const size_t dbase = ((size_t)n_img * 6 * f.C + c_img) * ((size_t)(f.H / 2) * Q) * SZ;
         wl_v2 wa[LW], wb[LW];
 #pragma unroll
         for (int t = 0; t < LW; ++t) wa[t] = wb[t] = wl_v2{0.f, 0.f};
@@ -316,7 +334,7 @@ struct WlDtFwd12Strip {
                     wl_v2 aL, aH, bL, bH;
                     col_filter(R, wa, (w + LW - M) % LW, aL, aH);
                     col_filter(R, wb, (w + LW - M) % LW, bL, bH);
-                    {
+                    if (MODE == 2) {
                         wl_f2 p; p.x = aL.x; p.y = bL.x;
                         *reinterpret_cast<wl_f2*>(l1slot + i * a.l1_pitch + l1c * 4) = p;
                         if (l1m >= 0) {
@@ -324,23 +342,56 @@ struct WlDtFwd12Strip {
                             *reinterpret_cast<wl_f2*>(l1slot + i * a.l1_pitch + l1m * 4) = m;
                         }
                     }
+                    const int o = o0 + i;
+                    const bool own = own_q && o >= r_lo && o < r_hi;
+                    if (MODE != 2 && f.ll && own) {            // full-resolution lowpass row o, columns 2q, 2q + 1
+                        Pair z; z.a = (T)aL.x; z.b = (T)bL.x;
+                        *reinterpret_cast<Pair*>(lbase + (size_t)((unsigned)o * (unsigned)f.W * SZ) + 2 * voff1) = z;
+                    }
                     if (!(i & 1)) { pL[0] = aL; pL[1] = bL; pH[0] = aH; pH[1] = bH; continue; }
                     // the quad (rows o - 1, o; columns 2q, 2q + 1) is complete: q2c of lh, hh, hl (reference
                     // transform_funcs.py:61-72: p = (upper left, upper right, lower left, lower right))
-                    const int o = o0 + i;
-                    if (!(own_q && o - 1 >= r_lo && o < r_hi) || (WL_DT12_ABLATE & 2)) continue;
+                    if (!own || (WL_DT12_ABLATE & 2)) continue;
                     const float k = (float)WL_SQRT1_2;
                     const float lh0 = pH[0].x, lh1 = pH[1].x, lh2 = aH.x, lh3 = bH.x;
                     const float hh0 = pH[0].y, hh1 = pH[1].y, hh2 = aH.y, hh3 = bH.y;
                     const float hl0 = pL[0].y, hl1 = pL[1].y, hl2 = aL.y, hl3 = bL.y;
-                    char* const rowp = hbase + (size_t)((unsigned)((o - 1) / 2) * (unsigned)Q * 2u * SZ);   // (uniform)
-                    Pair z;
-                    z.a = (T)((lh0 - lh3) * k); z.b = (T)((lh1 + lh2) * k); *reinterpret_cast<Pair*>(rowp + voff) = z;
-                    z.a = (T)((hh0 - hh3) * k); z.b = (T)((hh1 + hh2) * k); *reinterpret_cast<Pair*>(rowp + (size_t)qplane2 + voff) = z;
-                    z.a = (T)((hl0 - hl3) * k); z.b = (T)((hl1 + hl2) * k); *reinterpret_cast<Pair*>(rowp + 2 * (size_t)qplane2 + voff) = z;
-                    z.a = (T)((hl0 + hl3) * k); z.b = (T)((hl1 - hl2) * k); *reinterpret_cast<Pair*>(rowp + 3 * (size_t)qplane2 + voff) = z;
-                    z.a = (T)((hh0 + hh3) * k); z.b = (T)((hh1 - hh2) * k); *reinterpret_cast<Pair*>(rowp + 4 * (size_t)qplane2 + voff) = z;
-                    z.a = (T)((lh0 + lh3) * k); z.b = (T)((lh1 - lh2) * k); *reinterpret_cast<Pair*>(rowp + 5 * (size_t)qplane2 + voff) = z;
+                    const unsigned qrow = (unsigned)((o - 1) / 2) * (unsigned)Q;
+                    if (MODE != 1) {
+                        if (!f.highs) continue;
+                        char* const rowp = hbase + (size_t)(qrow * 2u * SZ);       // (uniform)
+                        Pair z;
+                        z.a = (T)((lh0 - lh3) * k); z.b = (T)((lh1 + lh2) * k); *reinterpret_cast<Pair*>(rowp + voff) = z;
+                        z.a = (T)((hh0 - hh3) * k); z.b = (T)((hh1 + hh2) * k); *reinterpret_cast<Pair*>(rowp + (size_t)qplane2 + voff) = z;
+                        z.a = (T)((hl0 - hl3) * k); z.b = (T)((hl1 + hl2) * k); *reinterpret_cast<Pair*>(rowp + 2 * (size_t)qplane2 + voff) = z;
+                        z.a = (T)((hl0 + hl3) * k); z.b = (T)((hl1 - hl2) * k); *reinterpret_cast<Pair*>(rowp + 3 * (size_t)qplane2 + voff) = z;
+                        z.a = (T)((hh0 + hh3) * k); z.b = (T)((hh1 - hh2) * k); *reinterpret_cast<Pair*>(rowp + 4 * (size_t)qplane2 + voff) = z;
+                        z.a = (T)((lh0 + lh3) * k); z.b = (T)((lh1 - lh2) * k); *reinterpret_cast<Pair*>(rowp + 5 * (size_t)qplane2 + voff) = z;
+                    } else {
+                        // ScatLayer: |z_o| smoothed.  re^2 + im^2 = ((v0 -+ v3)^2 + (v1 +- v2)^2) / 2
+                        const float b = (float)f.magbias, b2 = b * b;
+                        char* const zp = zbase + (size_t)(qrow * SZ) + voff1;       // (n, 0, c, qr, q)
+                        *reinterpret_cast<T*>(zp) = (T)((pL[0].x + pL[1].x + aL.x + bL.x) * 0.25f);
+                        const float v0[3] = {lh0, hh0, hl0}, v1[3] = {lh1, hh1, hl1}, v2[3] = {lh2, hh2, hl2}, v3[3] = {lh3, hh3, hl3};
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) {
+#pragma unroll
+                            for (int w2i = 0; w2i < 2; ++w2i) {
+                                const int o6 = w2i ? 5 - u : u;                     // lh: 0 / 5, hh: 1 / 4, hl: 2 / 3
+                                const float d = w2i ? v0[u] + v3[u] : v0[u] - v3[u];
+                                const float e = w2i ? v1[u] - v2[u] : v1[u] + v2[u];
+                                const float r = wl_sqrt(0.5f * (d * d + e * e) + b2);
+                                *reinterpret_cast<T*>(zp + (size_t)(o6 + 1) * zplane) = (T)(r - b);
+                                if (f.drdx) {
+                                    const float ir = k / r;
+                                    char* const dp = reinterpret_cast<char*>(f.drdx) + dbase + (size_t)o6 * zplane + (size_t)(qrow * SZ) + voff1;
+                                    char* const dq = reinterpret_cast<char*>(f.drdy) + dbase + (size_t)o6 * zplane + (size_t)(qrow * SZ) + voff1;
+                                    *reinterpret_cast<T*>(dp) = (T)(d * ir);
+                                    *reinterpret_cast<T*>(dq) = (T)(e * ir);
+                                }
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -479,7 +530,7 @@ struct WlDtFwd12Strip {
             if (ngl <= 1) stager<1>(a, s, ctx, plane, lane, wave - CW - QW);
             else if (ngl == 2) stager<2>(a, s, ctx, plane, lane, wave - CW - QW);
             else stager<3>(a, s, ctx, plane, lane, wave - CW - QW);
-        } else if (wave >= CW) {
+        } else if (MODE == 2 && wave >= CW) {
             level2(a, s, ctx, plane, wave - CW, lane);
         } else {
             level1(a, s, ctx, plane, wave, lane);

@@ -146,7 +146,7 @@ def test_streaming_level1_forward_equals_tile_kernel(shape, biort, mode, dtype):
         xfm = pw.DTCWTForward(J=1, biort=biort, mode=mode).to(dtype)
         try:
             yl, yh = xfm(x)
-            assert 'WlDtFwd1Strip' in pw.last_kernel(), pw.last_kernel()
+            assert 'WlDtFwd1Strip' in pw.last_kernel() or 'WlDtFwd12Strip' in pw.last_kernel(), pw.last_kernel()
             h.wl_set_option(b'no_stream', 1)
             yl2, yh2 = xfm(x)
             assert 'WlDtFwd1Tile' in pw.last_kernel(), pw.last_kernel()
@@ -255,3 +255,51 @@ def test_golden_through_the_forced_fused_kernel(monkeypatch):
     monkeypatch.setattr(ops, 'dtcwt_fwd12', spy)
     D.check_dtcwt_case('dtcwt_00', 'cpu', torch.float32, 1e-5)
     assert took and all(took)
+
+
+@pytest.mark.parametrize('shape,dtype,grad', [((2, 3, 32, 256), torch.float32, True), ((1, 2, 64, 512), torch.float32, False),
+                                              ((1, 2, 36, 1024), torch.float32, True), ((2, 2, 32, 512), torch.float16, False)])
+def test_lean_scatlayer_kernel_equals_tile_kernel(shape, dtype, grad):
+    """ScatLayer on the lean streaming kernel (wl_dtcwt_fused.h MODE 1: averaged lowpass, smoothed magnitudes, the saved
+    (re, im) / r when a gradient is wanted) against the tile kernel: narrow (two level-1 waves) and wide planes, several
+    strips and segments, float16; the backward consumes what the forward saved."""
+    torch.manual_seed(0)
+    x = torch.randn(*shape, dtype=dtype)
+    h = emu_backend.handle()
+    out = {}
+    with emu_backend.emulated():
+        sl = pw.ScatLayer().to(dtype)
+        try:
+            for ns in (0, 1):
+                h.wl_set_option(b'no_stream', ns)
+                xg = x.clone().requires_grad_(grad)
+                z = sl(xg)
+                out[ns] = [z.detach()]
+                if ns == 0:
+                    assert 'WlDtFwd12Strip' in pw.last_kernel() and ', 10, 1' in pw.last_kernel(), pw.last_kernel()
+                if grad:
+                    g, = torch.autograd.grad((z * z).sum(), xg)
+                    out[ns].append(g)
+        finally:
+            h.wl_set_option(b'no_stream', 0)
+    tol = 5e-3 if dtype == torch.float16 else 3e-6
+    for u, v in zip(out[0], out[1]):
+        assert u.shape == v.shape
+        assert float((u.float() - v.float()).abs().max()) <= tol * float(v.float().abs().max())
+
+
+def test_lean_scatlayerj2_lowpass():
+    """ScatLayerj2 asks the level-1 launch for the full-resolution lowpass as well (want_ll): lean kernel against tile kernel."""
+    torch.manual_seed(0)
+    x = torch.randn(2, 2, 64, 256, dtype=torch.float32)
+    h = emu_backend.handle()
+    out = {}
+    with emu_backend.emulated():
+        sl = pw.ScatLayerj2()
+        try:
+            for ns in (0, 1):
+                h.wl_set_option(b'no_stream', ns)
+                out[ns] = sl(x)
+        finally:
+            h.wl_set_option(b'no_stream', 0)
+    assert float((out[0] - out[1]).abs().max()) <= 3e-6 * float(out[1].abs().max())

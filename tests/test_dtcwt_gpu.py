@@ -120,7 +120,7 @@ def test_streaming_level1_forward(shape, biort, mode, dtype):
     lib = _lib.get()
     try:
         yl, yh = xfm(x)
-        assert 'WlDtFwd1Strip' in pw.last_kernel(), pw.last_kernel()
+        assert 'WlDtFwd1Strip' in pw.last_kernel() or 'WlDtFwd12Strip' in pw.last_kernel(), pw.last_kernel()
         lib.wl_set_option(b'no_stream', 1)
         yl2, yh2 = xfm(x)
         assert 'WlDtFwd1Tile' in pw.last_kernel(), pw.last_kernel()
@@ -237,3 +237,37 @@ def test_goldens_through_the_forced_fused_kernel(monkeypatch):
     for name in ('dtcwt_00', 'dtcwt_01'):
         D.check_dtcwt_case(name, DEV, torch.float32, 1e-5)
     assert took and all(took)
+
+
+@pytest.mark.parametrize('shape,dtype,grad', [((256, 3, 256, 256), torch.float32, False), ((64, 3, 512, 512), torch.float32, True),
+                                              ((20, 3, 260, 1024), torch.float32, True), ((128, 2, 128, 512), torch.float16, False)])
+def test_lean_scatlayer_kernel(shape, dtype, grad):
+    """ScatLayer on the lean streaming kernel (wl_dtcwt_fused.h MODE 1) against the tile kernel on every plane and against
+    the oracle on sampled planes; the backward consumes the (re, im) / r it saved."""
+    from pytorch_wavelets_amd import _lib
+    torch.manual_seed(2)
+    x = torch.randn(*shape, device=DEV).to(dtype)
+    sl = pw.ScatLayer().to(DEV).to(dtype)
+    lib = _lib.get()
+    out = {}
+    try:
+        for ns in (0, 1):
+            lib.wl_set_option(b'no_stream', ns)
+            xg = x.clone().requires_grad_(grad)
+            z = sl(xg)
+            if ns == 0:
+                assert 'WlDtFwd12Strip' in pw.last_kernel() and ', 10, 1' in pw.last_kernel(), pw.last_kernel()
+            out[ns] = [z.detach()]
+            if grad:
+                g, = torch.autograd.grad((z * z).sum(), xg)
+                out[ns].append(g)
+    finally:
+        lib.wl_set_option(b'no_stream', 0)
+    tol = 5e-3 if dtype == torch.float16 else 5e-6
+    for u, v in zip(out[0], out[1]):
+        assert float((u.float() - v.float()).abs().max()) <= tol * float(v.float().abs().max())
+    hb = F.dtcwt_forward_taps('near_sym_a', 'qshift_a')
+    for n in (0, shape[0] - 1):
+        ref = wo.scat_layer_forward(x[n:n + 1].double().cpu().numpy(), hb[0], hb[1])
+        got = out[0][0][n:n + 1].double().cpu().numpy()
+        assert np.abs(got - ref).max() <= (5e-3 if dtype == torch.float16 else 1e-5) * np.abs(ref).max()
