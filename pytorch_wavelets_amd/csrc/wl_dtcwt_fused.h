@@ -537,3 +537,259 @@ struct WlDtFwd12Strip {
         }
     }
 };
+
+// =================================================================================================================
+// Streaming level >= 2 DTCWT inverse over column strips: inv_j2plus (reference dtcwt/transform_funcs.py:279-307 = c2q x 3,
+// 4 colifilt, 4 rowifilt (dtcwt/lowlevel.py:154-239), 3 adds) for filters with an ODD half length m2 = L / 2 (10, 14,
+// 18 taps).  With quads of the half-resolution inputs (pair of samples 2j, 2j + 1 along an axis):
+//     Y[4q + s] = sum_{t < m2} h_s[e_s + 2t] X[2 (q - D2 + t) + p_s],   D2 = (m2 - 1) / 2,   e = (1, 1, 0, 0)[s]
+//   lowpass streams (ha, hb) = (g0b, g0a): s = 0, 2 take ha and the EVEN sample (p = 0), s = 1, 3 take hb and the ODD one;
+//   highpass streams (g1b, g1a): the parities are the other way round.
+// The separable operators commute: y = C_lp (R_lp ll + R_hp hl) + C_hp (R_lp lh + R_hp hh), row interpolation first.
+//   * half-batch = one input quad row = four output rows.  Every lane of the stager waves owns ONE input quad of the quad
+//     row (the loads, the c2q and the flipped / mirrored copies of WlDtInv1Strip) and stages it as two 32-byte cells
+//     (ll_e, ll_o, hl_e, hl_o | lh_e, lh_o, hh_e, hh_o), one per row;
+//   * a compute lane owns TWO of the four output columns of an input quad column: waves 0, 1 the columns 4q, 4q + 1
+//     (tap phase e = 1), waves 2, 3 the columns 4q + 2, 4q + 3 (e = 0) - so the taps are wave-uniform scalars.  The pair
+//     (even sample, odd sample) of a band meets the pair (ha[e + 2t], hb[e + 2t]) elementwise: one packed FMA gives both
+//     columns (the highpass streams read the pair swapped: op_sel).  (A, B) = (R ll + R hl, R lh + R hh) of its two
+//     columns go into circular register windows of m2 quad rows whose rotation is compile-time (loop unrolled by m2);
+//     the column interpolation of output rows 4 kr .. 4 kr + 3 runs over the window D2 quad rows later.
+// =================================================================================================================
+template <typename T>
+struct WlDtI2StripArgs {
+    WlDtInv2Args<T> f;             // tensors, taps, sizes (h, w: the half-resolution input)
+    int64_t nblocks;
+    int nstrips, strip_quads;      // input quad columns per strip
+    int nseg, seg_groups;          // input quad rows (= groups of 4 output rows) per segment
+    int st_off, st_pitch, lds_bytes;
+};
+
+template <typename T, int LQ>
+struct WlDtInv2Strip {
+    typedef WlDtI2StripArgs<T> Args;
+    static const int CW = 4, SW = 3;                   // compute waves (2 per column phase), stager waves
+    static const int kWaves = CW + SW;
+    static const int kThreads = 64 * kWaves;
+    static const int kMinWaves = LQ <= 10 ? 7 : 5;     // four (two) workgroups of 7 waves per CU: at most 72 (96) registers
+    static const int SZ = (int)sizeof(T);
+    static const int m2 = LQ / 2, D2 = (m2 - 1) / 2;
+    static_assert(m2 & 1, "odd half length: 10, 14 or 18 taps");
+    static const int QCAP = 32 * CW;                   // input quad columns per strip
+
+    struct Strip {
+        int q0, q1;            // input quad columns [q0, q1) -> output columns [4 q0, 4 q1)
+        int Qa, nq;            // quad columns [Qa, Qa + nq) inside the plane are loaded, one per stager lane
+        int c0;                // quad column of staged cell 0 = q0 - D2
+        int g_lo, g_hi;        // output groups (= input quad rows) of this segment
+        int nhb;
+    };
+    static WL_HD Strip geometry(const Args& a, int strip, int seg) {
+        Strip s;
+        const int W2 = a.f.w / 2, H2 = a.f.h / 2;
+        s.q0 = strip * a.strip_quads;
+        s.q1 = s.q0 + a.strip_quads < W2 ? s.q0 + a.strip_quads : W2;
+        s.c0 = s.q0 - D2;
+        int qa = s.c0 < 0 ? 0 : s.c0, qb = s.q1 - 1 + D2;
+        if (qb > W2 - 1) qb = W2 - 1;
+        s.Qa = qa; s.nq = qb - qa + 1;
+        s.g_lo = seg * a.seg_groups;
+        s.g_hi = s.g_lo + a.seg_groups < H2 ? s.g_lo + a.seg_groups : H2;
+        s.nhb = (s.g_hi - s.g_lo + 2 * D2 + 1) / 2 * 2;        // (even: the stagers alternate two register sets)
+        return s;
+    }
+    // extended quad row -> source quad row; flip: its two rows swap (symmetric extension of an even number of rows)
+    static WL_HD int src_quad_row(int eq, int H2, bool& flip) {
+        flip = false;
+        if ((unsigned)eq < (unsigned)H2) return eq;
+        flip = true;
+        const int m = eq < 0 ? -1 - eq : 2 * H2 - 1 - eq;
+        return m < 0 ? 0 : (m >= H2 ? H2 - 1 : m);             // (one fold: the launcher requires H2 > D2)
+    }
+
+    typedef T Pair2 __attribute__((ext_vector_type(2), may_alias));
+    struct Quad { Pair2 l0, l1, b[6]; };
+
+    static WL_DEV void stager(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int lane, int sidx) {
+        const WlDtInv2Args<T>& f = a.f;
+        const int H2 = f.h / 2, W2 = f.w / 2;
+        const size_t qplane = (size_t)H2 * W2;
+        const int j = 64 * sidx + lane;
+        const int Q = s.Qa + j;
+        const bool qon = j < s.nq;
+        const T* llp = f.ll + (size_t)plane * f.ll_plane_stride + 2 * Q;
+        const T* hp = f.highs + (size_t)plane * 6 * qplane * 2 + 2 * Q;
+        const int cdst = (Q - s.c0) * 32;
+        int mdst = -1;                                         // the mirrored quad column (its samples swapped), if the strip reads it
+        if (qon) {
+            if (Q < D2 && -1 - Q >= s.c0) mdst = (-1 - Q - s.c0) * 32;
+            if (Q >= W2 - D2 && 2 * W2 - 1 - Q <= s.q1 - 1 + D2) mdst = (2 * W2 - 1 - Q - s.c0) * 32;
+        }
+        const int eq0 = s.g_lo - D2;
+        auto load = [&](int h, Quad& qd) {
+            bool flip;
+            const int sq = src_quad_row(eq0 + h, H2, flip);
+            if (!qon) return;
+            qd.l0 = *reinterpret_cast<const Pair2*>(llp + (size_t)(2 * sq) * f.ll_row_stride);
+            qd.l1 = *reinterpret_cast<const Pair2*>(llp + (size_t)(2 * sq + 1) * f.ll_row_stride);
+#pragma unroll
+            for (int o = 0; o < 6; ++o) qd.b[o] = *reinterpret_cast<const Pair2*>(hp + ((size_t)o * qplane + (size_t)sq * W2) * 2);
+        };
+        const float k = (float)WL_SQRT1_2;
+        auto stage = [&](int hb, const Quad& qd) {
+            bool flip;
+            src_quad_row(eq0 + hb, H2, flip);
+            char* sslot = ctx.smem + a.st_off + (hb & 1) * 2 * a.st_pitch;
+            if (!qon) return;
+            float re[6], im[6];
+#pragma unroll
+            for (int o = 0; o < 6; ++o) { re[o] = (float)qd.b[o].x; im[o] = (float)qd.b[o].y; }
+            // c2q (dtcwt/lowlevel.py:263-295): orientation pairs (0,5) -> lh, (2,3) -> hl, (1,4) -> hh;  v[row][col][ll, hl, lh, hh]
+            float v[2][2][4];
+#pragma unroll
+            for (int ch = 1; ch < 4; ++ch) {
+                const int o1 = ch == 2 ? 0 : (ch == 1 ? 2 : 1), o2 = ch == 2 ? 5 : (ch == 1 ? 3 : 4);
+                v[0][0][ch] = (re[o1] + re[o2]) * k; v[0][1][ch] = (im[o1] + im[o2]) * k;
+                v[1][0][ch] = (im[o1] - im[o2]) * k; v[1][1][ch] = (re[o2] - re[o1]) * k;
+            }
+            v[0][0][0] = (float)qd.l0.x; v[0][1][0] = (float)qd.l0.y; v[1][0][0] = (float)qd.l1.x; v[1][1][0] = (float)qd.l1.y;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                char* drow = sslot + (flip ? 1 - i : i) * a.st_pitch;
+                wl_vf4 w0, w1;
+                w0.x = v[i][0][0]; w0.y = v[i][1][0]; w0.z = v[i][0][1]; w0.w = v[i][1][1];      // ll_e ll_o hl_e hl_o
+                w1.x = v[i][0][2]; w1.y = v[i][1][2]; w1.z = v[i][0][3]; w1.w = v[i][1][3];      // lh_e lh_o hh_e hh_o
+                *reinterpret_cast<wl_vf4*>(drow + cdst) = w0;
+                *reinterpret_cast<wl_vf4*>(drow + cdst + 16) = w1;
+                if (mdst >= 0) {
+                    wl_vf4 m0, m1;
+                    m0.x = w0.y; m0.y = w0.x; m0.z = w0.w; m0.w = w0.z;
+                    m1.x = w1.y; m1.y = w1.x; m1.z = w1.w; m1.w = w1.z;
+                    *reinterpret_cast<wl_vf4*>(drow + mdst) = m0;
+                    *reinterpret_cast<wl_vf4*>(drow + mdst + 16) = m1;
+                }
+            }
+        };
+        Quad qa, qb;
+        load(0, qa);
+        for (int hb = 0; hb < s.nhb; hb += 2) {                // (nhb is even)
+            load(hb + 1, qb);
+            stage(hb, qa);
+            ctx.sync();
+            load(hb + 2 < s.nhb ? hb + 2 : s.nhb - 1, qa);
+            stage(hb + 1, qb);
+            ctx.sync();
+        }
+    }
+
+    // acc += taps (.) v  /  acc += taps (.) (v.y, v.x): elementwise, the tap pair in scalar registers
+    static WL_DEV void fma_ee(wl_v2& acc, wl_v2 taps, wl_v2 v) {
+#if defined(__HIPCC__)
+        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "s"(taps), "v"(v));
+#else
+        acc.x = __builtin_fmaf(taps.x, v.x, acc.x); acc.y = __builtin_fmaf(taps.y, v.y, acc.y);
+#endif
+    }
+    static WL_DEV void fma_sw(wl_v2& acc, wl_v2 taps, wl_v2 v) {
+#if defined(__HIPCC__)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(taps), "v"(v));
+#else
+        acc.x = __builtin_fmaf(taps.x, v.y, acc.x); acc.y = __builtin_fmaf(taps.y, v.x, acc.y);
+#endif
+    }
+    // acc += w * (c, c), c = the scalar pair's low / high half
+    template <int HI> static WL_DEV void fma_cc(wl_v2& acc, wl_v2 w, wl_v2 pair) {
+#if defined(__HIPCC__)
+        if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "s"(pair));
+        else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w), "s"(pair));
+#else
+        const float c = HI ? pair.y : pair.x;
+        acc.x = __builtin_fmaf(w.x, c, acc.x); acc.y = __builtin_fmaf(w.y, c, acc.y);
+#endif
+    }
+
+    static WL_DEV void compute(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int cw, int lane) {
+        const WlDtInv2Args<T>& f = a.f;
+        const int ph_c = cw >> 1;                              // column phase: 0 -> output columns 4q, 4q+1 (e = 1); 1 -> 4q+2, 4q+3 (e = 0)
+        const int q = s.q0 + 64 * (cw & 1) + lane;
+        const bool active = q < s.q1;
+        // tap pairs (ha[e + 2t], hb[e + 2t]): lowpass (g0b, g0a), highpass (g1b, g1a); e = 1 and e = 0 sets (the column
+        // interpolation needs both, the row interpolation the one of my phase)
+        wl_v2 PL[2][m2], PH[2][m2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int t = 0; t < m2; ++t) {
+                PL[e][t] = wl_uniform_v2(wl_v2{(float)f.g0b[e + 2 * t], (float)f.g0a[e + 2 * t]});
+                PH[e][t] = wl_uniform_v2(wl_v2{(float)f.g1b[e + 2 * t], (float)f.g1a[e + 2 * t]});
+            }
+        const int er = 1 - ph_c;                               // my row-interpolation tap phase
+        const int soff = (active ? q - s.q0 : 0) * 32;         // cell of quad column q - D2
+        char* const yp = reinterpret_cast<char*>(f.y + (size_t)plane * (4 * (size_t)f.h * f.w));
+        const unsigned rowb = (unsigned)(2 * f.w) * SZ, colb = (unsigned)(4 * q + 2 * ph_c) * SZ;
+        wl_v2 wA[m2][2], wB[m2][2];                            // window: [quad row slot][row of the quad] = (col s0, col s1)
+#pragma unroll
+        for (int t = 0; t < m2; ++t) { wA[t][0] = wA[t][1] = wB[t][0] = wB[t][1] = wl_v2{0.f, 0.f}; }
+        char* const smem = ctx.smem;
+        for (int hb0 = 0; hb0 < s.nhb; hb0 += m2) {
+#pragma unroll
+            for (int ph = 0; ph < m2; ++ph) {
+                const int hb = hb0 + ph;
+                if (hb >= s.nhb) break;
+                ctx.sync();
+                if (!active) continue;
+                const char* slot = smem + a.st_off + (hb & 1) * 2 * a.st_pitch + soff;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    wl_v2 A = {0.f, 0.f}, B = {0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < m2; ++t) {
+                        const wl_vf4 c0 = *reinterpret_cast<const wl_vf4*>(slot + i * a.st_pitch + 32 * t);
+                        const wl_vf4 c1 = *reinterpret_cast<const wl_vf4*>(slot + i * a.st_pitch + 32 * t + 16);
+                        if (er) {
+                            fma_ee(A, PL[1][t], wl_v2{c0.x, c0.y}); fma_sw(A, PH[1][t], wl_v2{c0.z, c0.w});
+                            fma_ee(B, PL[1][t], wl_v2{c1.x, c1.y}); fma_sw(B, PH[1][t], wl_v2{c1.z, c1.w});
+                        } else {
+                            fma_ee(A, PL[0][t], wl_v2{c0.x, c0.y}); fma_sw(A, PH[0][t], wl_v2{c0.z, c0.w});
+                            fma_ee(B, PL[0][t], wl_v2{c1.x, c1.y}); fma_sw(B, PH[0][t], wl_v2{c1.z, c1.w});
+                        }
+                    }
+                    wA[ph][i] = A; wB[ph][i] = B;
+                }
+                // the window now holds input quad rows eq - m2 + 1 .. eq (eq = g_lo - D2 + hb), oldest in slot ph + 1:
+                // the output group kr = eq - D2
+                const int kr = s.g_lo - 2 * D2 + hb;
+                if (kr < s.g_lo || kr >= s.g_hi) continue;
+                wl_v2 y0 = {0.f, 0.f}, y1 = {0.f, 0.f}, y2 = {0.f, 0.f}, y3 = {0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < m2; ++t) {
+                    const int sl = (ph + 1 + t) % m2;
+                    // rows 4kr, 4kr+2: lowpass on the EVEN row of the quad row, highpass on the ODD one; 4kr+1, 4kr+3: the other way round
+                    fma_cc<0>(y0, wA[sl][0], PL[1][t]); fma_cc<0>(y0, wB[sl][1], PH[1][t]);
+                    fma_cc<1>(y1, wA[sl][1], PL[1][t]); fma_cc<1>(y1, wB[sl][0], PH[1][t]);
+                    fma_cc<0>(y2, wA[sl][0], PL[0][t]); fma_cc<0>(y2, wB[sl][1], PH[0][t]);
+                    fma_cc<1>(y3, wA[sl][1], PL[0][t]); fma_cc<1>(y3, wB[sl][0], PH[0][t]);
+                }
+                typedef T Vec2 __attribute__((ext_vector_type(2)));
+                char* const rp = yp + (size_t)((unsigned)(4 * kr) * rowb) + colb;
+                *reinterpret_cast<Vec2*>(rp) = Vec2{(T)y0.x, (T)y0.y};
+                *reinterpret_cast<Vec2*>(rp + rowb) = Vec2{(T)y1.x, (T)y1.y};
+                *reinterpret_cast<Vec2*>(rp + 2 * (size_t)rowb) = Vec2{(T)y2.x, (T)y2.y};
+                *reinterpret_cast<Vec2*>(rp + 3 * (size_t)rowb) = Vec2{(T)y3.x, (T)y3.y};
+            }
+        }
+    }
+
+    static WL_DEV void run(const Args& a, const WlCtx& ctx) {
+        const int tid = ctx.tid;
+        const int wave = wl_uniform(tid >> 6), lane = tid & 63;
+        const int64_t lbid = wl_xcd_remap(ctx.bid, a.nblocks);
+        const int per_plane = a.nstrips * a.nseg;
+        const int64_t plane = lbid / per_plane;
+        const int rem = (int)(lbid - plane * per_plane);
+        const int seg = rem / a.nstrips, strip = rem - seg * a.nstrips;
+        const Strip s = geometry(a, strip, seg);
+        if (wave >= CW) stager(a, s, ctx, plane, lane, wave - CW);
+        else compute(a, s, ctx, plane, wave, lane);
+    }
+};

@@ -303,3 +303,41 @@ def test_lean_scatlayerj2_lowpass():
         finally:
             h.wl_set_option(b'no_stream', 0)
     assert float((out[0] - out[1]).abs().max()) <= 3e-6 * float(out[1].abs().max())
+
+
+@pytest.mark.parametrize('shape,qshift,dtype', [((2, 1, 64, 256), 'qshift_a', torch.float32), ((1, 2, 72, 1024), 'qshift_a', torch.float32),
+                                                ((2, 1, 64, 256), 'qshift_b', torch.float32), ((2, 2, 64, 512), 'qshift_a', torch.float16)])
+def test_streaming_level2_inverse_equals_tile_kernel(shape, qshift, dtype):
+    """The streaming level-2 inverse over column strips (wl_dtcwt_fused.h WlDtInv2Strip: one input quad per stager lane, row
+    interpolation from 32-byte cells, column interpolation from register windows) against the tile kernel: flipped quad rows
+    at the top / bottom, mirrored quad columns, several strips and segments, 10 and 14 taps, float16; and as the backward of
+    the level-2 forward."""
+    torch.manual_seed(0)
+    x = torch.randn(*shape, dtype=dtype)
+    h = emu_backend.handle()
+    out = {}
+    with emu_backend.emulated():
+        xfm = pw.DTCWTForward(J=2, qshift=qshift).to(dtype)
+        ifm = pw.DTCWTInverse(qshift=qshift).to(dtype)
+        yl, yh = xfm(x)
+        yl, yh = yl + 0.1 * torch.randn_like(yl), [v + 0.1 * torch.randn_like(v) for v in yh]
+        ll1 = {}
+        try:
+            for ns in (0, 1):
+                h.wl_set_option(b'no_stream', ns)
+                from pytorch_wavelets_amd import ops
+                ll1[ns] = ops.dtcwt_inv2(yl, yh[1], ifm.g0a, ifm.g0b, ifm.g1a, ifm.g1b)
+                if ns == 0:
+                    assert 'WlDtInv2Strip' in pw.last_kernel(), pw.last_kernel()
+                out[ns] = [ifm((yl, yh))]
+                if dtype == torch.float32:
+                    xg = x.clone().requires_grad_(True)
+                    a, b = xfm(xg)
+                    ((a * yl).sum() + (b[0] * yh[0]).sum() + (b[1] * yh[1]).sum()).backward()
+                    out[ns].append(xg.grad.clone())
+        finally:
+            h.wl_set_option(b'no_stream', 0)
+    tol = 5e-3 if dtype == torch.float16 else 3e-6
+    assert float((ll1[0].float() - ll1[1].float()).abs().max()) <= tol * float(ll1[1].float().abs().max())
+    for u, v in zip(out[0], out[1]):
+        assert float((u.float() - v.float()).abs().max()) <= tol * float(v.float().abs().max())

@@ -271,3 +271,42 @@ def test_lean_scatlayer_kernel(shape, dtype, grad):
         ref = wo.scat_layer_forward(x[n:n + 1].double().cpu().numpy(), hb[0], hb[1])
         got = out[0][0][n:n + 1].double().cpu().numpy()
         assert np.abs(got - ref).max() <= (5e-3 if dtype == torch.float16 else 1e-5) * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('shape,qshift,dtype', [((64, 3, 512, 512), 'qshift_a', torch.float32), ((20, 3, 264, 1024), 'qshift_a', torch.float32),
+                                                ((128, 1, 256, 256), 'qshift_b', torch.float32), ((160, 1, 128, 512), 'qshift_a', torch.float16)])
+def test_streaming_level2_inverse(shape, qshift, dtype):
+    """The streaming level-2 inverse over column strips (WlDtInv2Strip) against the tile kernel (wl_set_option no_stream)
+    on every plane, the whole inverse against the oracle on sampled planes, and as the backward of the level-2 forward."""
+    from pytorch_wavelets_amd import _lib, ops
+    torch.manual_seed(1)
+    x = torch.randn(*shape, device=DEV).to(dtype)
+    xfm = pw.DTCWTForward(J=2, qshift=qshift).to(DEV).to(dtype)
+    ifm = pw.DTCWTInverse(qshift=qshift).to(DEV).to(dtype)
+    yl, yh = xfm(x)
+    yl, yh = yl + 0.1 * torch.randn_like(yl), [v + 0.1 * torch.randn_like(v) for v in yh]
+    lib = _lib.get()
+    out, ll1 = {}, {}
+    try:
+        for ns in (0, 1):
+            lib.wl_set_option(b'no_stream', ns)
+            ll1[ns] = ops.dtcwt_inv2(yl, yh[1], ifm.g0a, ifm.g0b, ifm.g1a, ifm.g1b)
+            if ns == 0:
+                assert 'WlDtInv2Strip' in pw.last_kernel(), pw.last_kernel()
+            out[ns] = [ifm((yl, yh))]
+            if dtype == torch.float32:
+                xg = x.clone().requires_grad_(True)
+                a, b = xfm(xg)
+                ((a * yl).sum() + (b[0] * yh[0]).sum() + (b[1] * yh[1]).sum()).backward()
+                out[ns].append(xg.grad.clone())
+    finally:
+        lib.wl_set_option(b'no_stream', 0)
+    tol = 5e-3 if dtype == torch.float16 else 5e-6
+    assert float((ll1[0].float() - ll1[1].float()).abs().max()) <= tol * float(ll1[1].float().abs().max())
+    for u, v in zip(out[0], out[1]):
+        assert float((u.float() - v.float()).abs().max()) <= tol * float(v.float().abs().max())
+    hb = F.dtcwt_inverse_taps('near_sym_a', qshift)
+    for n, c in ((0, 0), (shape[0] - 1, shape[1] - 1)):
+        ref = wo.dtcwt_inverse(yl[n:n + 1, c:c + 1].double().cpu().numpy(), [v[n:n + 1, c:c + 1].double().cpu().numpy() for v in yh], *hb)
+        got = out[0][0][n:n + 1, c:c + 1].double().cpu().numpy()
+        assert np.abs(got - ref).max() <= (5e-3 if dtype == torch.float16 else 1e-5) * np.abs(ref).max()
