@@ -619,11 +619,12 @@ struct WlDtInv2Strip {
         const bool qon = j < s.nq;
         const T* llp = f.ll + (size_t)plane * f.ll_plane_stride + 2 * Q;
         const T* hp = f.highs + (size_t)plane * 6 * qplane * 2 + 2 * Q;
-        const int cdst = (Q - s.c0) * 32;
+        const int cdst = (Q - s.c0) * 16;                      // (the two 16-byte halves of a cell live in the two halves of a row: lanes read consecutive words)
+        const int hp2 = a.st_pitch / 2;
         int mdst = -1;                                         // the mirrored quad column (its samples swapped), if the strip reads it
         if (qon) {
-            if (Q < D2 && -1 - Q >= s.c0) mdst = (-1 - Q - s.c0) * 32;
-            if (Q >= W2 - D2 && 2 * W2 - 1 - Q <= s.q1 - 1 + D2) mdst = (2 * W2 - 1 - Q - s.c0) * 32;
+            if (Q < D2 && -1 - Q >= s.c0) mdst = (-1 - Q - s.c0) * 16;
+            if (Q >= W2 - D2 && 2 * W2 - 1 - Q <= s.q1 - 1 + D2) mdst = (2 * W2 - 1 - Q - s.c0) * 16;
         }
         const int eq0 = s.g_lo - D2;
         auto load = [&](int h, Quad& qd) {
@@ -660,13 +661,13 @@ struct WlDtInv2Strip {
                 w0.x = v[i][0][0]; w0.y = v[i][1][0]; w0.z = v[i][0][1]; w0.w = v[i][1][1];      // ll_e ll_o hl_e hl_o
                 w1.x = v[i][0][2]; w1.y = v[i][1][2]; w1.z = v[i][0][3]; w1.w = v[i][1][3];      // lh_e lh_o hh_e hh_o
                 *reinterpret_cast<wl_vf4*>(drow + cdst) = w0;
-                *reinterpret_cast<wl_vf4*>(drow + cdst + 16) = w1;
+                *reinterpret_cast<wl_vf4*>(drow + hp2 + cdst) = w1;
                 if (mdst >= 0) {
                     wl_vf4 m0, m1;
                     m0.x = w0.y; m0.y = w0.x; m0.z = w0.w; m0.w = w0.z;
                     m1.x = w1.y; m1.y = w1.x; m1.z = w1.w; m1.w = w1.z;
                     *reinterpret_cast<wl_vf4*>(drow + mdst) = m0;
-                    *reinterpret_cast<wl_vf4*>(drow + mdst + 16) = m1;
+                    *reinterpret_cast<wl_vf4*>(drow + hp2 + mdst) = m1;
                 }
             }
         };
@@ -724,7 +725,8 @@ struct WlDtInv2Strip {
                 PH[e][t] = wl_uniform_v2(wl_v2{(float)f.g1b[e + 2 * t], (float)f.g1a[e + 2 * t]});
             }
         const int er = 1 - ph_c;                               // my row-interpolation tap phase
-        const int soff = (active ? q - s.q0 : 0) * 32;         // cell of quad column q - D2
+        const int soff = (active ? q - s.q0 : 0) * 16;         // cell of quad column q - D2
+        const int hp2 = a.st_pitch / 2;
         char* const yp = reinterpret_cast<char*>(f.y + (size_t)plane * (4 * (size_t)f.h * f.w));
         const unsigned rowb = (unsigned)(2 * f.w) * SZ, colb = (unsigned)(4 * q + 2 * ph_c) * SZ;
         wl_v2 wA[m2][2], wB[m2][2];                            // window: [quad row slot][row of the quad] = (col s0, col s1)
@@ -744,8 +746,8 @@ struct WlDtInv2Strip {
                     wl_v2 A = {0.f, 0.f}, B = {0.f, 0.f};
 #pragma unroll
                     for (int t = 0; t < m2; ++t) {
-                        const wl_vf4 c0 = *reinterpret_cast<const wl_vf4*>(slot + i * a.st_pitch + 32 * t);
-                        const wl_vf4 c1 = *reinterpret_cast<const wl_vf4*>(slot + i * a.st_pitch + 32 * t + 16);
+                        const wl_vf4 c0 = *reinterpret_cast<const wl_vf4*>(slot + i * a.st_pitch + 16 * t);
+                        const wl_vf4 c1 = *reinterpret_cast<const wl_vf4*>(slot + i * a.st_pitch + hp2 + 16 * t);
                         if (er) {
                             fma_ee(A, PL[1][t], wl_v2{c0.x, c0.y}); fma_sw(A, PH[1][t], wl_v2{c0.z, c0.w});
                             fma_ee(B, PL[1][t], wl_v2{c1.x, c1.y}); fma_sw(B, PH[1][t], wl_v2{c1.z, c1.w});
