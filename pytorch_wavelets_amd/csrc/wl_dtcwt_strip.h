@@ -426,22 +426,38 @@ struct WlDtInv1Strip {
         wl_v2 r0[L0], r1[L1];      // row-filter taps, duplicated: (g0[t], g0[t]) meets (ll, lh), (g1[t], g1[t]) meets (hl, hh)
         wl_v2 cc[2 * M + 1];       // column-filter tap pairs (g0[t], g1[t]), both centred in 2M+1 slots
     };
-    // (A, B) of output column `COL` of the quad from the lane's pixels px[0..NPX): (x, y) = (ll, lh), (z, w) = (hl, hh)
-    template <int COL> static WL_DEV wl_v2 row_filter(const Wave& R, const wl_vf4 (&px)[NPX]) {
-        wl_v2 a0 = wl_pk_mul_vs(wl_v2{px[COL + M - M0].x, px[COL + M - M0].y}, R.r0[0]);
-        wl_v2 a1 = wl_pk_mul_vs(wl_v2{px[COL + M - M1].z, px[COL + M - M1].w}, R.r1[0]);
+    // (A, B) of both output columns of the quad from the lane's pixels px[0..NPX): (x, y) = (ll, lh), (z, w) = (hl, hh).
+    // Four accumulator chains, interleaved: on gfx950 a packed FMA that reads the result of one of the two instructions
+    // before it costs a wait state (the compiler pads with s_nop, which takes an issue slot like any instruction).
+    static WL_DEV void row_filter2(const Wave& R, const wl_vf4 (&px)[NPX], wl_v2& ra, wl_v2& rb) {
+        wl_v2 a0 = wl_pk_mul_vs(wl_v2{px[M - M0].x, px[M - M0].y}, R.r0[0]);
+        wl_v2 b0 = wl_pk_mul_vs(wl_v2{px[1 + M - M0].x, px[1 + M - M0].y}, R.r0[0]);
+        wl_v2 a1 = wl_pk_mul_vs(wl_v2{px[M - M1].z, px[M - M1].w}, R.r1[0]);
+        wl_v2 b1 = wl_pk_mul_vs(wl_v2{px[1 + M - M1].z, px[1 + M - M1].w}, R.r1[0]);
 #pragma unroll
-        for (int t = 1; t < L0; ++t) wl_pk_fma_vs(a0, wl_v2{px[COL + M - M0 + t].x, px[COL + M - M0 + t].y}, R.r0[t]);
-#pragma unroll
-        for (int t = 1; t < L1; ++t) wl_pk_fma_vs(a1, wl_v2{px[COL + M - M1 + t].z, px[COL + M - M1 + t].w}, R.r1[t]);
-        return a0 + a1;
+        for (int t = 1; t < (L0 > L1 ? L0 : L1); ++t) {
+            if (t < L0) {
+                wl_pk_fma_vs(a0, wl_v2{px[M - M0 + t].x, px[M - M0 + t].y}, R.r0[t]);
+                wl_pk_fma_vs(b0, wl_v2{px[1 + M - M0 + t].x, px[1 + M - M0 + t].y}, R.r0[t]);
+            }
+            if (t < L1) {
+                wl_pk_fma_vs(a1, wl_v2{px[M - M1 + t].z, px[M - M1 + t].w}, R.r1[t]);
+                wl_pk_fma_vs(b1, wl_v2{px[1 + M - M1 + t].z, px[1 + M - M1 + t].w}, R.r1[t]);
+            }
+        }
+        ra = a0 + a1; rb = b0 + b1;
     }
-    // output sample of the row centred on slot c
-    static WL_DEV float col_filter(const Wave& R, const wl_v2 (&w)[LW], int c) {
-        wl_v2 acc = wl_pk_mul_vs(w[(c + LW - M) % LW], R.cc[0]);
+    // output samples of the row centred on slot c, both columns (even / odd taps in chains of their own)
+    static WL_DEV void col_filter2(const Wave& R, const wl_v2 (&wa)[LW], const wl_v2 (&wb)[LW], int c, float& ya, float& yb) {
+        wl_v2 a0 = wl_pk_mul_vs(wa[(c + LW - M) % LW], R.cc[0]), b0 = wl_pk_mul_vs(wb[(c + LW - M) % LW], R.cc[0]);
+        wl_v2 a1 = wl_pk_mul_vs(wa[(c + LW - M + 1) % LW], R.cc[1]), b1 = wl_pk_mul_vs(wb[(c + LW - M + 1) % LW], R.cc[1]);
 #pragma unroll
-        for (int t = 1; t < 2 * M + 1; ++t) wl_pk_fma_vs(acc, w[(c + LW - M + t) % LW], R.cc[t]);
-        return acc.x + acc.y;
+        for (int t = 2; t < 2 * M + 1; ++t) {
+            if (t & 1) { wl_pk_fma_vs(a1, wa[(c + LW - M + t) % LW], R.cc[t]); wl_pk_fma_vs(b1, wb[(c + LW - M + t) % LW], R.cc[t]); }
+            else { wl_pk_fma_vs(a0, wa[(c + LW - M + t) % LW], R.cc[t]); wl_pk_fma_vs(b0, wb[(c + LW - M + t) % LW], R.cc[t]); }
+        }
+        a0 += a1; b0 += b1;
+        ya = a0.x + a0.y; yb = b0.x + b0.y;
     }
 
     static WL_DEV void compute(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int cw, int lane) {
@@ -481,10 +497,10 @@ struct WlDtInv1Strip {
 #pragma unroll
                     for (int u = 0; u < NPX; ++u) px[u] = *reinterpret_cast<const wl_vf4*>(slot + i * a.st_pitch + 16 * u);
                     const int w = (2 * ph + i) % LW;          // slot of the new row e = e_first + 2 hb + i
-                    wa[w] = row_filter<0>(R, px);
-                    wb[w] = row_filter<1>(R, px);
+                    row_filter2(R, px, wa[w], wb[w]);
                     const int o = s.e_first + 2 * hb + i - M;   // the row that is complete now
-                    const float ya = col_filter(R, wa, (w + LW - M) % LW), yb = col_filter(R, wb, (w + LW - M) % LW);
+                    float ya, yb;
+                    col_filter2(R, wa, wb, (w + LW - M) % LW, ya, yb);
                     if (o >= s.r_lo && o < s.r_hi) {
                         typedef T Vec2 __attribute__((ext_vector_type(2)));
                         Vec2 v = {(T)ya, (T)yb};
