@@ -315,11 +315,16 @@ def main():
     # the inverse twice.  duration(forward) = T(S + f) - T(S), duration(inverse) = T(S + i) - T(S): the kernels run in the
     # same back-to-back stream as in the timed region (the rocprofv3 trace of this command shows Start[k+1] == End[k]),
     # no event packet sits between two launches, and forward + inverse must add up to the step (reported as `closure`).
-    wl.run('f')
-    kernel = {'f': pw.last_kernel()}
-    if wl.ifm is not None:
-        wl.run('i')
-        kernel['i'] = pw.last_kernel()
+    # every kernel a part launches, by name (wl_kernel_history of the C ABI); the label of a multi-launch part is its FIRST
+    # launch = the finest level, which moves 3/4 and more of the part's bytes (DWT levels halve twice; the DTCWT's level 1,
+    # or levels 1 + 2 fused, carries 16 of its 20 bytes per pixel)
+    kernel, launches = {}, {}
+    for p in ('f', 'i') if wl.ifm is not None else ('f',):
+        c0 = pw.launch_count()
+        wl.run(p)
+        launches[p] = pw.kernels_since(c0)
+        order = launches[p] if p == 'f' else launches[p][::-1]      # (an inverse runs coarsest level first)
+        kernel[p] = order[0] if order else pw.last_kernel()
     parts = [p for p in 'fi' if p == 'f' or wl.ifm is not None]
 
     def time_seq(seq, n):
@@ -383,7 +388,7 @@ def main():
 
     # HBM traffic of the dominant kernels: only from a PMC summary measured on THIS build of the sources
     traffic = {}
-    tpath = os.path.join(ROOT, 'profiles', 'r03_hbm_traffic.json')
+    tpath = os.path.join(ROOT, 'profiles', 'r03_hbm_traffic.json' if wl.key == 'dwt' else 'r03_%s_hbm_traffic.json' % wl.key)
     if os.path.exists(tpath) and not emu:
         try:
             tj = json.load(open(tpath))
@@ -402,7 +407,7 @@ def main():
 
         def block(p):
             gbs = wl.bytes[p] / (part_ms[p] * 1e-3) / 1e9
-            b = {'kernel': kernel[p], 'achieved': round(gbs, 1), 'frac': round(gbs / HBM_PEAK_GBS, 4),
+            b = {'kernel': kernel[p], 'launches': launches[p], 'achieved': round(gbs, 1), 'frac': round(gbs / HBM_PEAK_GBS, 4),
                  'avg_launch_ms': round(part_ms[p], 4), 'algorithmic_bytes_per_launch': wl.bytes[p],
                  'traffic': traffic.get(p)}
             if copy_gbs:
@@ -419,7 +424,7 @@ def main():
                 'closure': round(closure, 4), 'step_ms_events': round(med['S'], 4)}
         roof.update(block('f'))
         if wl.key == 'dwt':
-            roof['launches_per_forward'] = 1 if 'WlAfbRows' in kernel['f'] else wl.J
+            roof['launches_per_forward'] = len(launches['f'])
         if 'i' in part_ms:
             roof['inverse'] = block('i')
         if copy_gbs:
@@ -482,6 +487,11 @@ def other_configs(pw, dev, sync):
 
     def frac(bytes_, ms):
         return round(bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+
+    def names(fn):
+        c0 = pw.launch_count()
+        fn()
+        return pw.kernels_since(c0)
     with torch.no_grad():
         xd = torch.randn(64, 3, 512, 512, device=dev)
         dx, di = pw.DTCWTForward(J=3).to(dev), pw.DTCWTInverse().to(dev)
@@ -490,14 +500,23 @@ def other_configs(pw, dev, sync):
         other['dtcwt_j3_near_sym_a_qshift_a_64x3x512x512_fp32'] = {
             'fwd_ms': round(tf, 4), 'inv_ms': round(ti, 4), 'fwd_inv_mpix_s': round(xd.numel() / (tf + ti) / 1e3, 1),
             'fwd_frac_of_hbm_peak_at_20B_per_px': frac(20 * xd.numel(), tf),
-            'inv_frac_of_hbm_peak_at_20B_per_px': frac(20 * xd.numel(), ti)}
+            'inv_frac_of_hbm_peak_at_20B_per_px': frac(20 * xd.numel(), ti),
+            'fwd_kernels': names(lambda: dx(xd)), 'inv_kernels': names(lambda: di((dyl, dyh)))}
+        d1x = pw.DTCWTForward(J=1).to(dev)
+        t1f = time_seq_fn(lambda: d1x(xd), 10, sync)
+        other['dtcwt_j1_near_sym_a_64x3x512x512_fp32'] = {'fwd_ms': round(t1f, 4), 'fwd_frac_of_hbm_peak_at_20B_per_px': frac(20 * xd.numel(), t1f),
+                                                         'fwd_kernels': names(lambda: d1x(xd))}
+        slw = pw.ScatLayer().to(dev)
+        tsw = time_seq_fn(lambda: slw(xd), 10, sync)
+        other['scatlayer_64x3x512x512_fp32'] = {'fwd_ms': round(tsw, 4), 'frac_of_hbm_peak_at_11B_per_px': frac(11 * xd.numel(), tsw),
+                                               'fwd_kernels': names(lambda: slw(xd))}
         del xd, dyl, dyh
         xs = torch.randn(256, 3, 256, 256, device=dev)
         sl = pw.ScatLayer().to(dev)
         ts = time_seq_fn(lambda: sl(xs), 10, sync)
         other['scatlayer_256x3x256x256_fp32_one_gpu'] = {
             'fwd_ms': round(ts, 4), 'mpix_s': round(xs.numel() / ts / 1e3, 1),
-            'frac_of_hbm_peak_at_11B_per_px': frac(11 * xs.numel(), ts)}
+            'frac_of_hbm_peak_at_11B_per_px': frac(11 * xs.numel(), ts), 'fwd_kernels': names(lambda: sl(xs))}
         # f2: ScatLayerj2 and the rotationally symmetric variant (no fused kernel: single-axis launches)
         xs2 = xs[:64]
         s2 = pw.ScatLayerj2().to(dev)
@@ -527,24 +546,22 @@ def other_configs(pw, dev, sync):
             fx, fi = pw.DWTForward(J=3, wave=wave, mode='symmetric').to(dev), pw.DWTInverse(wave=wave, mode='symmetric').to(dev)
             c = fx(xl)
             tf = time_seq_fn(lambda: fx(xl), 10, sync)
-            kf = pw.last_kernel()
             ti = time_seq_fn(lambda: fi(c), 10, sync)
             b = algorithmic_bytes_fwd(shape[0], shape[1], shape[2], shape[3], 3, L, 4)
             other[tag] = {'fwd_ms': round(tf, 4), 'inv_ms': round(ti, 4), 'fwd_frac': frac(b, tf), 'inv_frac': frac(b, ti),
-                          'last_fwd_kernel': kf, 'last_inv_kernel': pw.last_kernel()}
+                          'fwd_kernels': names(lambda: fx(xl)), 'inv_kernels': names(lambda: fi(c))}
             del xl, c
         xh = torch.randn(32, 16, 2048, 2048, device=dev, dtype=torch.float16)   # configs[4] at its full size (4.3 GB)
         hx = pw.DWTForward(J=4, wave='db8', mode='periodization').to(dev).half()
         hi = pw.DWTInverse(wave='db8', mode='periodization').to(dev).half()
         hyl, hyh = hx(xh)
         th = time_seq_fn(lambda: hx(xh), 3, sync)
-        hk = pw.last_kernel()
         tih = time_seq_fn(lambda: hi((hyl, hyh)), 3, sync)
         other['dwt_j4_db8_periodization_32x16x2048x2048_fp16'] = {
             'fwd_ms': round(th, 4), 'inv_ms': round(tih, 4), 'fwd_mpix_s': round(xh.numel() / th / 1e3, 1),
             'fwd_frac_of_hbm_peak_at_4B_per_px': frac(4 * xh.numel(), th),
             'inv_frac_of_hbm_peak_at_4B_per_px': frac(4 * xh.numel(), tih),
-            'last_fwd_kernel': hk, 'last_inv_kernel': pw.last_kernel()}
+            'fwd_kernels': names(lambda: hx(xh)), 'inv_kernels': names(lambda: hi((hyl, hyh)))}
         del xh, hyl, hyh
     return other
 

@@ -49,6 +49,11 @@ const char* wl_backend(void);
  * the process (static storage; autograd runs backward passes on its own threads), so that a benchmark can label its numbers with the dispatch actually taken. */
 int wl_set_option(const char* name, int value);
 const char* wl_last_kernel(void);
+/* wl_launch_count(): kernels launched by the process so far; wl_kernel_history(back): the functor launched `back` launches
+ * ago (0 = the last one, up to 7; "" beyond) - a multi-launch transform (DTCWT: one kernel per level or pair of levels)
+ * can then be labelled launch by launch. */
+long long wl_launch_count(void);
+const char* wl_kernel_history(int back);
 
 /* Coefficient count of one 1-D analysis level: (n+L-1)/2, or (n+1)/2 for periodization.
  * Replaces pywt.dwt_coeff_len at dwt/lowlevel.py:153. */

@@ -22,6 +22,25 @@ def last_kernel():
     return raw.split('K = ')[-1].rstrip(']') if 'K = ' in raw else raw
 
 
+def launch_count():
+    """Kernels the engine has launched in this process so far (wl_launch_count of the C ABI)."""
+    from . import ops
+    return int(ops._backend().wl_launch_count())
+
+
+def kernels_since(count):
+    """The kernel functors launched since ``count = launch_count()`` was read, oldest first (the engine remembers the last
+    eight): every launch of a multi-launch transform by name."""
+    from . import ops
+    be = ops._backend()
+    n = min(int(be.wl_launch_count()) - count, 8)
+    out = []
+    for back in range(n - 1, -1, -1):
+        raw = be.wl_kernel_history(back).decode()
+        out.append(raw.split('K = ')[-1].rstrip(']') if 'K = ' in raw else raw)
+    return out
+
+
 DTCWT = DTCWTForward
 IDTCWT = DTCWTInverse
 DWT = DWTForward

@@ -10,6 +10,8 @@ PROTOTYPES = {
     'wl_backend': (C.c_char_p, []),
     'wl_set_option': (I, [C.c_char_p, I]),
     'wl_last_kernel': (C.c_char_p, []),
+    'wl_launch_count': (C.c_longlong, []),
+    'wl_kernel_history': (C.c_char_p, [I]),
     'wl_dwt_coeff_len': (I, [I, I, I]),
     'wl_dwt2d_analysis': (I, [P, P, P, I, L, I, I, P, P, I, P, P, I, I, P]),
     'wl_dwt2d_analysis_strided': (I, [P, L, I, P, L, I, P, I, L, I, I, P, P, I, P, P, I, I, P]),

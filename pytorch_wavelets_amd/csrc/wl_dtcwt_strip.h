@@ -303,6 +303,10 @@ struct WlDtInv1Strip {
     static const int M0 = L0 / 2, M1 = L1 / 2, M = M0 > M1 ? M0 : M1, ME = (M + 1) & ~1;
     static const int LW = 2 * M + 2;                   // window slots (even): rotation by the 2 rows of a half-batch
     static const int PERIOD = LW / 2;
+#ifndef WL_DTI1_PF
+#define WL_DTI1_PF 2
+#endif
+    static const int PF = WL_DTI1_PF;                  // register sets of a stager
     static const int NPX = 2 + 2 * M;                  // pixels a lane reads per row
 
     struct Strip {
@@ -326,7 +330,7 @@ struct WlDtInv1Strip {
         s.r_lo = seg * a.seg_rows;
         s.r_hi = s.r_lo + a.seg_rows < a.f.H ? s.r_lo + a.seg_rows : a.f.H;
         s.e_first = s.r_lo - ME;
-        s.nhb = (s.r_hi - 1 + M - s.e_first) / 2 + 1;
+        s.nhb = ((s.r_hi - 1 + M - s.e_first) / 2 + 1 + PF - 1) / PF * PF;   // (a multiple of the stagers' register sets)
         return s;
     }
     // extended quad row (pair of extended pixel rows 2 eq, 2 eq + 1) -> source quad row; flip: its two rows swap
@@ -408,17 +412,20 @@ struct WlDtInv1Strip {
                 }
             }
         };
-        // software pipeline in registers: the loads of half-batch hb + 1 are in flight while hb is staged
-        Quad qa, qb;
-        load(0, qa);
-        for (int hb = 0; hb < s.nhb; hb += 2) {
-            if (hb + 1 < s.nhb) load(hb + 1, qb);
-            stage(hb, qa);
-            ctx.sync();
-            if (hb + 1 >= s.nhb) break;
-            if (hb + 2 < s.nhb) load(hb + 2, qa);
-            stage(hb + 1, qb);
-            ctx.sync();
+        // software pipeline in registers: PF sets, the loads of half-batches hb + 1 .. hb + PF - 1 are in flight while hb is
+        // staged (measured: PF = 2 is the fastest; 3 is 1 % and 4 is 5 % slower on the whole inverse).
+        // No branch in the loop (nhb is a multiple of PF; behind the last half-batch: that one again), so that the compiler
+        // counts the loads and waits for exactly the oldest set.
+        Quad qq[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) load(u < s.nhb ? u : s.nhb - 1, qq[u]);
+        for (int hb = 0; hb < s.nhb; hb += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                stage(hb + u, qq[u]);
+                ctx.sync();
+                load(hb + u + PF < s.nhb ? hb + u + PF : s.nhb - 1, qq[u]);
+            }
         }
     }
 

@@ -18,6 +18,13 @@
 static int wl_num_cus() { return 2; }
 static const char* wl_last_kernel_ptr = "";
 static const char* wl_last_kernel_name() { return wl_last_kernel_ptr; }
+static const char* wl_kernel_log_buf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static long long wl_kernel_log_n = 0;
+static long long wl_launch_count_value() { return wl_kernel_log_n; }
+static const char* wl_kernel_history_name(int back) {
+    if (back < 0 || back >= 8 || back >= wl_kernel_log_n) return "";
+    return wl_kernel_log_buf[(wl_kernel_log_n - 1 - back) & 7];
+}
 
 struct WlEmuBlock {
     ucontext_t main;
@@ -108,6 +115,7 @@ static int wl_launch(const typename K::Args& a, int64_t nblocks, size_t lds, voi
     if (nblocks <= 0) return 0;
     if (lds > 160 * 1024) return -2;
     wl_last_kernel_ptr = __PRETTY_FUNCTION__;
+    wl_kernel_log_buf[wl_kernel_log_n++ & 7] = __PRETTY_FUNCTION__;
     const int nt = K::kThreads;
     const size_t kStack = 256 * 1024;
 #pragma omp parallel

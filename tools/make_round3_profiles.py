@@ -112,7 +112,7 @@ for c in ('dtcwt', 'scat', 'cfg5'):
     durations(os.path.join(G, tag, 'prof_' + c, 'bench_kernel_trace.csv'), os.path.join(P, '%s_%s_kernel_durations.csv' % (tag, c)))
 traffic(os.path.join(G, 'pmc_%s_bench' % tag, 'pmc_summary.json'), os.path.join(P, 'r03_hbm_traffic.json'))
 for c in ('dtcwt', 'scat', 'cfg5'):
-    t = traffic(os.path.join(G, 'pmc_%s_%s' % (tag, c), 'pmc_summary.json'), os.path.join(P, '%s_%s_hbm_traffic.json' % (tag, c)))
+    t = traffic(os.path.join(G, 'pmc_%s_%s' % (tag, c), 'pmc_summary.json'), os.path.join(P, 'r03_%s_hbm_traffic.json' % c))
 # config 5: what the SQ counters say about the bound of the two strip kernels (level-1 dispatch = the largest)
 pmc = json.load(open(os.path.join(G, 'pmc_%s_cfg5' % tag, 'pmc_summary.json')))
 out = {'source_digest': bench.source_digest(), 'tag': tag,
