@@ -44,6 +44,9 @@ inline void wl_pk_fma_y_v(wl_v2& acc, wl_v2 tap, wl_v2 s) { wl_pk_fma_y(acc, tap
 #endif
 // (timing builds: workgroup 0 leaves (total, barrier) kilocycles of one wave per role in ll2[16..21])
 #define WL_DT12_SYNC() { const unsigned long long t_ = WL_DT12_TICK(); ctx.sync(); tbar += WL_DT12_TICK() - t_; }
+#ifndef WL_DT12_ROWLOADS
+#define WL_DT12_ROWLOADS 0       // 1: the level-1 lanes read a row's samples when they filter it (fewer registers) instead of the four rows up front
+#endif
 #ifndef WL_DT12_ABLATE
 #define WL_DT12_ABLATE 0        // A/B builds: 1 = level-2 waves idle, 2 = no level-1 band-pass stores, 4 = no level-2 stores, 8 = no level-1 arithmetic
 #endif
@@ -316,6 +319,7 @@ struct WlDtFwd12Strip {
                 if (!active || hb >= s.nhb1 || (WL_DT12_ABLATE & 8)) continue;
                 const char* slot = smem + a.st_off + (hb & 1) * 4 * a.st_pitch + soff;
                 char* l1slot = smem + a.l1_off + (hb & 1) * 4 * a.l1_pitch;
+#if !WL_DT12_ROWLOADS
                 wl_v2 sr[4][NC2];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -324,13 +328,25 @@ struct WlDtFwd12Strip {
                         const wl_f2 t = *reinterpret_cast<const wl_f2*>(slot + i * a.st_pitch + 8 * u);
                         sr[i][u] = wl_v2{t.x, t.y};
                     }
+#endif
                 const int o0 = s.o_base + 4 * hb;              // LL1 rows o0 .. o0 + 3 are completed in this half-batch
                 wl_v2 pL[2], pH[2];                            // the quad's upper row: (ll, hl), (lh, hh) of its two columns
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int w = (4 * ph + i) % LW;           // slot of the new input row e = o + M
+#if WL_DT12_ROWLOADS
+                    wl_v2 sri[NC2];
+#pragma unroll
+                    for (int u = 0; u < NC2; ++u) {
+                        const wl_f2 t = *reinterpret_cast<const wl_f2*>(slot + i * a.st_pitch + 8 * u);
+                        sri[u] = wl_v2{t.x, t.y};
+                    }
+                    wa[w] = row_filter<0>(R, sri);
+                    wb[w] = row_filter<1>(R, sri);
+#else
                     wa[w] = row_filter<0>(R, sr[i]);
                     wb[w] = row_filter<1>(R, sr[i]);
+#endif
                     wl_v2 aL, aH, bL, bH;
                     col_filter(R, wa, (w + LW - M) % LW, aL, aH);
                     col_filter(R, wb, (w + LW - M) % LW, bL, bH);
