@@ -13,6 +13,7 @@ banks from rank 0.  dwt / dtcwt / cfg5 scale weakly (the configured batch per GP
 256 images split over the ranks (strong).  Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -285,12 +286,22 @@ def main():
         """W warmup steps, then EXACTLY K steps between barrier + synchronize on both sides; MAX over ranks."""
         for _ in range(args.warmup):
             wl.step()
+        # the cyclic garbage collector stays out of the K timed steps (like timeit): a full collection of a process that
+        # has imported torch takes 35-65 ms, the whole timed region of --config dtcwt 6 ms (seen: one step of ten at 65 ms)
+        gc.collect()
+        gc.disable()
         barrier()
         t0 = time.perf_counter()
+        stamps = []
         for _ in range(K):
             out = wl.step()
+            stamps.append(time.perf_counter())
         barrier()
         dt = time.perf_counter() - t0
+        gc.enable()
+        if os.environ.get('WL_BENCH_STAMPS'):
+            print('[stamps] host ms per step: %s; drain %.2f ms' % (' '.join('%.2f' % ((b - a) * 1e3) for a, b in zip([t0] + stamps, stamps)),
+                                                                   (t0 + dt - stamps[-1]) * 1e3), file=sys.stderr, flush=True)
         if world > 1:
             tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
