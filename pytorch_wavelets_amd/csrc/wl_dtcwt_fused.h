@@ -68,8 +68,9 @@ struct WlDtFusedArgs {
 
 // MODE 2: levels 1 + 2 (above).  The same stagers and level-1 lanes without the level-2 waves are the lean level-1 kernels:
 // MODE 0: fwd_j1 alone (lowpass and band-pass coefficients to memory), MODE 1: ScatLayerj1_f.forward (scatternet/lowlevel.py:
-// 76-111: the 2x2-averaged lowpass and the six smoothed magnitudes sqrt(re^2 + im^2 + b^2) - b, optionally (re, im) / r for
-// the backward pass and the full-resolution lowpass for ScatLayerj2).
+// 76-111: the 2x2-averaged lowpass and the six smoothed magnitudes sqrt(re^2 + im^2 + b^2) - b, optionally the
+// full-resolution lowpass for ScatLayerj2), MODE 3: MODE 1 + (re, im) / r saved for the backward pass (a compile-time
+// variant: the inference kernel does not carry the pointers of the saved tensors through its scalar registers).
 template <typename T, int L0, int L1, int LQ, int MODE = 2, int CW_ = 4>
 struct WlDtFwd12Strip {
     typedef WlDtFusedArgs<T> Args;
@@ -86,7 +87,8 @@ struct WlDtFwd12Strip {
 #define WL_DT12_MINW1 6
 #endif
     // two workgroups of 10 (12) waves per CU, or three of 8: at most 96 (80) registers
-    static const int kMinWaves = MODE == 1 ? WL_DT12_MINW1 : (SW == 2 && MODE == 2 ? 5 : 6);
+    static const bool kScat = MODE == 1 || MODE == 3;
+    static const int kMinWaves = kScat ? WL_DT12_MINW1 : (SW == 2 && MODE == 2 ? 5 : 6);
     static const int SZ = (int)sizeof(T);
     static const int M0 = L0 / 2, M1 = L1 / 2, M = M0 > M1 ? M0 : M1;
     static const int LW = (2 * M + 1 + 3) / 4 * 4;
@@ -299,8 +301,8 @@ struct WlDtFwd12Strip {
         char* const lbase = reinterpret_cast<char*>(f.ll + (size_t)plane * f.H * f.W);
         // ScatLayer output (N, 7, C, H/2, Q): my plane (n, c) of entry 0; entries 1 .. 6 follow C planes apart.  The saved
         // (re, im) / r are (N, 6, C, H/2, Q)
-        const int64_t n_img = MODE == 1 ? plane / f.C : 0;
-        const int c_img = MODE == 1 ? (int)(plane - n_img * f.C) : 0;
+        const int64_t n_img = kScat ? plane / f.C : 0;
+        const int c_img = kScat ? (int)(plane - n_img * f.C) : 0;
         const size_t zplane = (size_t)f.C * (f.H / 2) * Q * SZ;
         char* const zbase = reinterpret_cast<char*>(f.z) + ((size_t)n_img * 7 * f.C + c_img) * ((size_t)(f.H / 2) * Q) * SZ;
         const size_t dbase = ((size_t)n_img * 6 * f.C + c_img) * ((size_t)(f.H / 2) * Q) * SZ;
@@ -373,7 +375,7 @@ struct WlDtFwd12Strip {
                     const float hh0 = pH[0].y, hh1 = pH[1].y, hh2 = aH.y, hh3 = bH.y;
                     const float hl0 = pL[0].y, hl1 = pL[1].y, hl2 = aL.y, hl3 = bL.y;
                     const unsigned qrow = (unsigned)((o - 1) / 2) * (unsigned)Q;
-                    if (MODE != 1) {
+                    if (!kScat) {
                         if (!f.highs) continue;
                         char* const rowp = hbase + (size_t)(qrow * 2u * SZ);       // (uniform)
                         Pair z;
@@ -398,7 +400,7 @@ struct WlDtFwd12Strip {
                                 const float e = w2i ? v1[u] - v2[u] : v1[u] + v2[u];
                                 const float r = wl_sqrt(0.5f * (d * d + e * e) + b2);
                                 *reinterpret_cast<T*>(zp + (size_t)(o6 + 1) * zplane) = (T)(r - b);
-                                if (f.drdx) {
+                                if (MODE == 3) {
                                     const float ir = k / r;
                                     char* const dp = reinterpret_cast<char*>(f.drdx) + dbase + (size_t)o6 * zplane + (size_t)(qrow * SZ) + voff1;
                                     char* const dq = reinterpret_cast<char*>(f.drdy) + dbase + (size_t)o6 * zplane + (size_t)(qrow * SZ) + voff1;
