@@ -226,8 +226,10 @@ WORKLOADS = {w.key: w for w in (DwtWorkload, DtcwtWorkload, ScatWorkload, Cfg5Wo
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100,
+                    help='timed steps (default 100: the ~0.3 ms the barrier / synchronize at either end of the timed region cost '
+                         'are then under 1 %% of it; with 20 steps they were 4 %%)')
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', choices=sorted(WORKLOADS), default='dwt',
                     help='dwt = BASELINE configs[1] (the metric); dtcwt / scat / cfg5 = configs[2] / [3] / [4]')
     ap.add_argument('--batch', type=int, default=0, help='images per GPU (scat: in total); 0 = the BASELINE value')

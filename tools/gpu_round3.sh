@@ -5,7 +5,7 @@ TAG=$1
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 REPO=$(pwd)
 timeout 1200 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/pytest_gpu.log
-timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err; echo "bench rc=$?"
+timeout 600 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err; echo "bench rc=$?"
 for c in dtcwt scat cfg5; do
   timeout 300 python bench.py --config $c --steps 10 --warmup 3 2>> $OUT/bench.err | tail -1 > $OUT/bench_$c.json; echo "bench $c rc=$?"
 done
