@@ -44,14 +44,39 @@ struct WlCorr1d {
         const int64_t per = (int64_t)a.K * a.inner;
         const int64_t idx = ctx.bid * kThreads + ctx.tid;
         if (idx >= a.outer * per) return;
-        const int64_t o = idx / per;
-        const int64_t rem = idx - o * per;
-        const int k = (int)(rem / a.inner);
-        const int64_t i = rem - (int64_t)k * a.inner;
+        int64_t o, i;
+        int k;
+        if (a.outer * per < (1LL << 31)) {       // (uniform) 32-bit index arithmetic: a 64-bit division costs ~40 instructions
+            const unsigned u = (unsigned)idx, up = (unsigned)per, ui = (unsigned)a.inner;
+            const unsigned uo = u / up, ur = u - uo * up;
+            const unsigned uk = ui == 1 ? ur : ur / ui;
+            o = uo; k = (int)uk; i = ur - uk * ui;
+        } else {
+            o = idx / per;
+            const int64_t rem = idx - o * per;
+            k = (int)(rem / a.inner);
+            i = rem - (int64_t)k * a.inner;
+        }
         const T* xp = a.x + o * a.n * a.inner + i;
         A acc0 = 0, acc1 = 0;
         const int p0 = a.start + a.step * k;
-        if (a.ext == WL_EXT_PER_FOLD1) {
+        if (a.ext != WL_EXT_PER_FOLD1 && a.dstep > 0 && p0 >= 0 && p0 + a.dstep * (a.nt - 1) < a.n) {
+            // interior: every tap meets a sample of the signal (all but the first / last few outputs of a row): no extension
+            // arithmetic per tap
+            const T* xq = xp + (int64_t)p0 * a.inner;
+            const int64_t st = (int64_t)a.dstep * a.inner;
+            const A* h0 = a.h0 + a.t0;
+            const A* h1 = a.h1 + a.t0;
+            if (a.y1) {
+                for (int t = 0; t < a.nt; ++t) {
+                    const A v = (A)xq[t * st];
+                    acc0 += h0[a.ts * t] * v;
+                    acc1 += h1[a.ts * t] * v;
+                }
+            } else {
+                for (int t = 0; t < a.nt; ++t) acc0 += h0[a.ts * t] * (A)xq[t * st];
+            }
+        } else if (a.ext == WL_EXT_PER_FOLD1) {
             const int ne = a.n + (a.n & 1), L2 = a.nt / 2;
             const int nfold = k < (L2 < ne / 2 ? L2 : ne / 2) ? 2 : 1;
             for (int f = 0; f < nfold; ++f)
@@ -109,10 +134,19 @@ struct WlSynth1d {
         const int64_t per = (int64_t)a.ny * a.inner;
         const int64_t idx = ctx.bid * kThreads + ctx.tid;
         if (idx >= a.outer * per) return;
-        const int64_t o = idx / per;
-        const int64_t rem = idx - o * per;
-        const int p = (int)(rem / a.inner);
-        const int64_t i = rem - (int64_t)p * a.inner;
+        int64_t o, i;
+        int p;
+        if (a.outer * per < (1LL << 31)) {       // (uniform) 32-bit index arithmetic
+            const unsigned u = (unsigned)idx, up = (unsigned)per, ui = (unsigned)a.inner;
+            const unsigned uo = u / up, ur = u - uo * up;
+            const unsigned uq = ui == 1 ? ur : ur / ui;
+            o = uo; p = (int)uq; i = ur - uq * ui;
+        } else {
+            o = idx / per;
+            const int64_t rem = idx - o * per;
+            p = (int)(rem / a.inner);
+            i = rem - (int64_t)p * a.inner;
+        }
         const T* lp = a.lo + o * a.K * a.inner + i;
         const T* hp = a.hi ? a.hi + o * a.K * a.inner + i : nullptr;
         A v;
