@@ -344,6 +344,11 @@ struct WlDtInv1Strip {
         return m < 0 ? 0 : (m >= H2 ? H2 - 1 : m);     // (one fold: the launcher requires H2 > M)
     }
 
+    // byte offset of staged cell c (pixel column px0 + c) inside a staged row: even and odd cells live in the two halves of
+    // the row, so that the lanes of a wave (one quad = two pixels each) read and write consecutive 16-byte words (with the
+    // cells simply side by side every access was a 2-way bank conflict: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50)
+    static WL_HD int cell_off(const Args& a, int c) { return (c & 1) * (a.st_pitch / 2) + (c >> 1) * 16; }
+
     typedef T Pair2 __attribute__((ext_vector_type(2), may_alias));
     struct Quad { Pair2 l0, l1, b[6]; };               // the eight sources of one quad, as loaded
 
@@ -362,13 +367,13 @@ struct WlDtInv1Strip {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int p = 2 * Q + c;
-            cdst[c] = (p - s.px0) * 16;
+            cdst[c] = cell_off(a, p - s.px0);
             int e = -1000000;
             if (f.ext != WL_EXT_ZERO && qon) {
                 if (p < M && -1 - p >= s.e_lo) e = -1 - p;
                 if (p >= f.W - M && 2 * f.W - 1 - p <= e_hi) e = 2 * f.W - 1 - p;
             }
-            mdst[c] = e == -1000000 ? -1 : (e - s.px0) * 16;
+            mdst[c] = e == -1000000 ? -1 : cell_off(a, e - s.px0);
         }
         auto load = [&](int h, Quad& qd) {
             bool flip;
@@ -483,7 +488,8 @@ struct WlDtInv1Strip {
             const float v1 = t1 >= 0 && t1 < L1 ? (float)f.g1[t1 >= 0 && t1 < L1 ? t1 : 0] : 0.f;
             R.cc[t] = wl_uniform_v2(wl_v2{v0, v1});
         }
-        const int soff = (s.e_lo - s.px0 + 2 * (active ? q - s.q0 : 0)) * 16;
+        const int soff = (active ? q - s.q0 : 0) * 16;         // cell (e_lo - px0) + 2 (q - q0) + u: see cell_off (e_lo - px0 = M & 1)
+        const int hp2 = a.st_pitch / 2;
         char* const yp = reinterpret_cast<char*>(f.y + (size_t)plane * f.H * f.W);
         const unsigned rowb = (unsigned)f.W * SZ, colb = (unsigned)(2 * q) * SZ;
         wl_v2 wa[LW], wb[LW];
@@ -502,7 +508,8 @@ struct WlDtInv1Strip {
                 for (int i = 0; i < 2; ++i) {
                     wl_vf4 px[NPX];
 #pragma unroll
-                    for (int u = 0; u < NPX; ++u) px[u] = *reinterpret_cast<const wl_vf4*>(slot + i * a.st_pitch + 16 * u);
+                    for (int u = 0; u < NPX; ++u)
+                        px[u] = *reinterpret_cast<const wl_vf4*>(slot + i * a.st_pitch + (((M & 1) + u) & 1) * hp2 + (((M & 1) + u) >> 1) * 16);
                     const int w = (2 * ph + i) % LW;          // slot of the new row e = e_first + 2 hb + i
                     row_filter2(R, px, wa[w], wb[w]);
                     const int o = s.e_first + 2 * hb + i - M;   // the row that is complete now
