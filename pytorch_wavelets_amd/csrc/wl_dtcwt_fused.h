@@ -71,6 +71,8 @@ struct WlDtFusedArgs {
 // 76-111: the 2x2-averaged lowpass and the six smoothed magnitudes sqrt(re^2 + im^2 + b^2) - b, optionally the
 // full-resolution lowpass for ScatLayerj2), MODE 3: MODE 1 + (re, im) / r saved for the backward pass (a compile-time
 // variant: the inference kernel does not carry the pointers of the saved tensors through its scalar registers).
+// MODE 4: fwd_j2plus alone - the stagers put the rows of the level's input (and their mirrored cells: exact, no symmetry
+// assumed) straight into the ring the level-2 lanes read; no level-1 waves.
 template <typename T, int L0, int L1, int LQ, int MODE = 2, int CW_ = 4>
 struct WlDtFwd12Strip {
     typedef WlDtFusedArgs<T> Args;
@@ -79,7 +81,7 @@ struct WlDtFwd12Strip {
 #endif
     // level-1, level-2 and stager waves (CW_ = 2: planes of up to 256 columns, two stagers of two rows each: one wave of the
     // workgroup per SIMD)
-    static const int CW = CW_, QW = MODE == 2 ? CW_ : 0, SW = CW_ == 2 ? 2 : WL_DT12_SW;
+    static const int CW = MODE == 4 ? 0 : CW_, QW = MODE == 2 || MODE == 4 ? CW_ : 0, SW = CW_ == 2 ? 2 : WL_DT12_SW;
     static const int LROWS = 4 / SW;                   // rows of a half-batch per stager wave
     static const int kWaves = CW + QW + SW;
     static const int kThreads = 64 * kWaves;
@@ -90,16 +92,16 @@ struct WlDtFwd12Strip {
     static const bool kScat = MODE == 1 || MODE == 3;
     static const int kMinWaves = kScat ? WL_DT12_MINW1 : (SW == 2 && MODE == 2 ? 5 : 6);
     static const int SZ = (int)sizeof(T);
-    static const int M0 = L0 / 2, M1 = L1 / 2, M = M0 > M1 ? M0 : M1;
+    static const int M0 = L0 / 2, M1 = L1 / 2, M = MODE == 4 ? 0 : (M0 > M1 ? M0 : M1);   // (MODE 4: no level-1 filters)
     static const int LW = (2 * M + 1 + 3) / 4 * 4;
     static const int PERIOD = LW / 4;
     static const int NS = 2 + 2 * M;
     static const int NC2 = NS / 2;
-    static const int HQ = MODE == 2 ? LQ - 2 : 0;      // LL1 columns / rows level 2 reads beyond its own, either side
+    static const int HQ = MODE == 2 || MODE == 4 ? LQ - 2 : 0;   // LL1 columns / rows level 2 reads beyond its own, either side
     static const int HG = HQ / 4;                      // the same in 4-row groups
     static const int NW2 = 2 * LQ;                     // rows of the level-2 window
     static const int NG2 = NW2 / 4;
-    static const int WARM1 = (2 * M + 3) / 4;          // half-batches before the first LL1 row of a segment is complete
+    static const int WARM1 = MODE == 4 ? 0 : (2 * M + 3) / 4;   // half-batches before the first LL1 row of a segment is complete
     static const int MAXG = 3;                         // 4-cell groups per stager lane and row
 #ifndef WL_DT12_PF
 #define WL_DT12_PF 2
@@ -124,8 +126,10 @@ struct WlDtFwd12Strip {
         s.q1 = s.q0 + a.strip_quads < Q ? s.q0 + a.strip_quads : Q;
         s.qa = s.q0 > 0 ? s.q0 - HQ / 2 : 0;
         s.qb = s.q1 < Q ? s.q1 + HQ / 2 : Q;
-        s.e_lo = 2 * s.qa - M;
-        const int e_hi = 2 * s.qb - 1 + M;
+        // columns the stagers provide: MODE 4 stages the ring level 2 reads (own columns + HQ either side), the others the
+        // samples of the level-1 lanes
+        s.e_lo = MODE == 4 ? 2 * s.q0 - HQ : 2 * s.qa - M;
+        const int e_hi = MODE == 4 ? 2 * s.q1 - 1 + HQ : 2 * s.qb - 1 + M;
         s.nl = s.e_lo < 0 ? -s.e_lo : 0;
         s.nr = e_hi > a.f.W - 1 ? e_hi - (a.f.W - 1) : 0;
         s.gc0 = (s.e_lo < 0 ? 0 : s.e_lo) / 4;
@@ -151,6 +155,7 @@ struct WlDtFwd12Strip {
     // ---- stager wave: row `sidx` of every half-batch --------------------------------------------------------------------
     typedef T Quad4 __attribute__((ext_vector_type(4), aligned(sizeof(T)), may_alias));
     struct RowRegs { Quad4 g[LROWS][MAXG]; T h[LROWS]; };
+    static const int SLACK = MODE == 4 ? 0 : 4;        // staged cell of column e_lo (MODE 4: e_lo is a multiple of 4, groups start on it)
     template <int NGL>
     static WL_DEV void stager(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int lane, int sidx) {
         const WlDtFwd1Args<T>& f = a.f;
@@ -162,12 +167,12 @@ struct WlDtFwd12Strip {
             const int g = lane + 64 * i;
             const int col = 4 * (s.gc0 + g);
             goff[i] = g < s.ng ? col * SZ : 0;
-            gdst[i] = g < s.ng ? (col - s.e_lo + 4) * 4 : -1;
+            gdst[i] = g < s.ng ? (col - s.e_lo + SLACK) * 4 : -1;
         }
         int hdst = -1, hoff = 0;                               // one mirrored cell per lane
         if (lane < s.nl + s.nr) {
             const int e = lane < s.nl ? s.e_lo + lane : f.W + (lane - s.nl);
-            hdst = (e - s.e_lo + 4) * 4;
+            hdst = (e - s.e_lo + SLACK) * 4;
             hoff = wl_ext(e, f.W, WL_EXT_SYM) * SZ;
         }
         auto load = [&](int h, RowRegs& rr) {
@@ -183,7 +188,8 @@ struct WlDtFwd12Strip {
         auto stage = [&](int hb, const RowRegs& rr) {
 #pragma unroll
             for (int r4 = 0; r4 < LROWS; ++r4) {
-                char* srow = ctx.smem + a.st_off + ((hb & 1) * 4 + LROWS * sidx + r4) * a.st_pitch;
+                char* srow = MODE == 4 ? ctx.smem + a.l1_off + ((hb & 1) * 4 + LROWS * sidx + r4) * a.l1_pitch
+                                       : ctx.smem + a.st_off + ((hb & 1) * 4 + LROWS * sidx + r4) * a.st_pitch;
 #pragma unroll
                 for (int i = 0; i < NGL; ++i) {
                     if (gdst[i] < 0) continue;
@@ -453,7 +459,10 @@ struct WlDtFwd12Strip {
         const long hstep = half ? -(long)qplane2 : (long)qplane2;               // my three orientations: 0, 1, 2 or 5, 4, 3
         typedef WlPair<T> Pair;
         const int l1lane = half * a.l1_pitch + 16 * j;
-        const int G0 = s.o_base / 4 - 1;                                       // LL1 group in the ring at half-batch hb: G0 + hb
+        // MODE 2: the level-1 lanes fill ring slot hb & 1 AFTER barrier hb, level 2 reads it one half-batch later; MODE 4:
+        // the stagers fill it BEFORE barrier hb, level 2 reads it right after
+        static const int LAG = MODE == 2 ? 1 : 0;
+        const int G0 = s.o_base / 4 - LAG;                                     // LL1 group in the ring at half-batch hb: G0 + hb
         unsigned long long tbar = 0;
         const unsigned long long tstart = WL_DT12_TICK();
         static const int P2 = LQ / 2;
@@ -463,10 +472,10 @@ struct WlDtFwd12Strip {
                 const int hb = hb0 + ph;
                 if (hb >= s.nhb) break;
                 WL_DT12_SYNC();
-                if (hb < 1 || hb > s.nhb1 || (WL_DT12_ABLATE & 1)) continue;
+                if (hb < LAG || hb - LAG >= s.nhb1 || (WL_DT12_ABLATE & 1)) continue;
                 const int G = G0 + hb;
                 if (G < s.g_lo - HG) continue;                                 // rows of the level-1 warm-up
-                const char* l1slot = smem + a.l1_off + ((hb - 1) & 1) * 4 * a.l1_pitch + l1lane;
+                const char* l1slot = smem + a.l1_off + ((hb - LAG) & 1) * 4 * a.l1_pitch + l1lane;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     // dual-tree row filters of the 2 LQ samples X[4k + 2 - LQ ..]: k = my column group
@@ -548,10 +557,10 @@ struct WlDtFwd12Strip {
             if (ngl <= 1) stager<1>(a, s, ctx, plane, lane, wave - CW - QW);
             else if (ngl == 2) stager<2>(a, s, ctx, plane, lane, wave - CW - QW);
             else stager<3>(a, s, ctx, plane, lane, wave - CW - QW);
-        } else if (MODE == 2 && wave >= CW) {
+        } else if ((MODE == 2 || MODE == 4) && wave >= CW) {
             level2(a, s, ctx, plane, wave - CW, lane);
         } else {
-            level1(a, s, ctx, plane, wave, lane);
+            if constexpr (MODE != 4) level1(a, s, ctx, plane, wave, lane);
         }
     }
 };

@@ -310,3 +310,26 @@ def test_streaming_level2_inverse(shape, qshift, dtype):
         ref = wo.dtcwt_inverse(yl[n:n + 1, c:c + 1].double().cpu().numpy(), [v[n:n + 1, c:c + 1].double().cpu().numpy() for v in yh], *hb)
         got = out[0][0][n:n + 1, c:c + 1].double().cpu().numpy()
         assert np.abs(got - ref).max() <= (5e-3 if dtype == torch.float16 else 1e-5) * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('shape,dtype', [((64, 3, 256, 256), torch.float32), ((64, 3, 512, 512), torch.float32), ((20, 3, 260, 1024), torch.float32),
+                                         ((160, 1, 128, 512), torch.float16)])
+def test_streaming_level2_forward(shape, dtype):
+    """fwd_j2plus alone on the stagers and level-2 lanes of the fused kernel (MODE 4) against the tile kernel on every plane."""
+    from pytorch_wavelets_amd import _lib, ops
+    torch.manual_seed(3)
+    x = torch.randn(*shape, device=DEV).to(dtype)
+    xfm = pw.DTCWTForward(J=2).to(DEV).to(dtype)
+    lib = _lib.get()
+    out = {}
+    try:
+        for ns in (0, 1):
+            lib.wl_set_option(b'no_stream', ns)
+            out[ns] = ops.dtcwt_fwd2(x, xfm.h0a, xfm.h0b, xfm.h1a, xfm.h1b)
+            if ns == 0:
+                assert 'WlDtFwd12Strip' in pw.last_kernel() and ', 10, 4' in pw.last_kernel(), pw.last_kernel()
+    finally:
+        lib.wl_set_option(b'no_stream', 0)
+    tol = 5e-3 if dtype == torch.float16 else 3e-6
+    for u, v in zip(out[0], out[1]):
+        assert float((u.float() - v.float()).abs().max()) <= tol * float(v.float().abs().max())
