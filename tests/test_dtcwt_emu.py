@@ -367,3 +367,19 @@ def test_streaming_level2_forward_equals_tile_kernel(shape, dtype):
     for u, v in zip(out[0], out[1]):
         assert u.shape == v.shape
         assert float((u.float() - v.float()).abs().max()) <= tol * float(v.float().abs().max())
+
+
+def test_kernel_history_names_every_launch_of_a_transform():
+    """wl_launch_count / wl_kernel_history (pw.kernels_since): a J=3 forward on wide planes is the fused level 1+2 launch and
+    one level-3 launch; the inverse three launches, coarsest level first."""
+    x = torch.randn(2, 1, 64, 1024, dtype=torch.float32)
+    with emu_backend.emulated():
+        xfm, ifm = pw.DTCWTForward(J=3), pw.DTCWTInverse()
+        c0 = pw.launch_count()
+        yl, yh = xfm(x)
+        fwd = pw.kernels_since(c0)
+        c1 = pw.launch_count()
+        ifm((yl, yh))
+        inv = pw.kernels_since(c1)
+    assert c1 - c0 == 2 and len(fwd) == 2 and 'WlDtFwd12Strip' in fwd[0] and 'WlDtFwd' in fwd[1], fwd
+    assert len(inv) == 3 and 'Inv2' in inv[0] and 'Inv2' in inv[1] and 'Inv1' in inv[2], inv
