@@ -43,7 +43,7 @@ const char* wl_backend(void);
 
 /* Diagnostics.  wl_set_option("generic_only", 1) routes every operator to the runtime-L generic kernels (the test-suite
  * compares the two kernel families); the initial value is read once from $WL_GENERIC_ONLY.  ("no_stream", 1) keeps the
- * level-1 DTCWT entry points off their strip kernels (tile kernels instead);
+ * DTCWT / ScatLayer entry points off their streaming kernels (tile kernels instead; wl_dtcwt_fwd_level12 then declines);
  * ("scat_stream", 1) lets wl_scat_fwd_level1 try the strip kernel (measured no faster: off by default).  Returns 0, or
  * WL_ERR_UNSUPPORTED for an unknown name.  wl_last_kernel(): name of the kernel functor launched last by any thread of
  * the process (static storage; autograd runs backward passes on its own threads), so that a benchmark can label its numbers with the dispatch actually taken. */
