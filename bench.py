@@ -407,8 +407,8 @@ def main():
             tj = json.load(open(tpath))
             if tj.get('source_digest') == source_digest():
                 for k, v in tj.get('kernels', {}).items():   # rocprof prints defaulted template arguments too
-                    for p in parts:
-                        if k.strip().startswith(kernel[p].rstrip('>')):
+                    for p in parts:                          # (several instantiations may share the prefix: the largest one is the part's kernel)
+                        if k.strip().startswith(kernel[p].rstrip('>')) and (v.get('hbm_bytes_corrected') or 0) > (traffic.get(p) or 0):
                             traffic[p] = v.get('hbm_bytes_corrected')
         except Exception:
             traffic = {}
