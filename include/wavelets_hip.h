@@ -48,6 +48,7 @@ const char* wl_backend(void);
  * WL_ERR_UNSUPPORTED for an unknown name.  wl_last_kernel(): name of the kernel functor launched last by any thread of
  * the process (static storage; autograd runs backward passes on its own threads), so that a benchmark can label its numbers with the dispatch actually taken. */
 int wl_set_option(const char* name, int value);
+int wl_get_option(const char* name);   /* current value, or WL_ERR_UNSUPPORTED for an unknown name */
 const char* wl_last_kernel(void);
 /* wl_launch_count(): kernels launched by the process so far; wl_kernel_history(back): the functor launched `back` launches
  * ago (0 = the last one, up to 7; "" beyond) - a multi-launch transform (DTCWT: one kernel per level or pair of levels)

@@ -9,6 +9,7 @@ PROTOTYPES = {
     'wl_version': (I, []),
     'wl_backend': (C.c_char_p, []),
     'wl_set_option': (I, [C.c_char_p, I]),
+    'wl_get_option': (I, [C.c_char_p]),
     'wl_last_kernel': (C.c_char_p, []),
     'wl_launch_count': (C.c_longlong, []),
     'wl_kernel_history': (C.c_char_p, [I]),

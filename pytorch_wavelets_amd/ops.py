@@ -569,7 +569,8 @@ def dtcwt_fwd12(x, h0o, h1o, h0a, h0b, h1a, h1b, mode, force=False):
                _DTYPES[x.dtype], N * C, H, W, t0.data_ptr(), t0.numel(), t1.data_ptr(), t1.numel(), ta.data_ptr(),
                tb.data_ptr(), tc.data_ptr(), td.data_ptr(), ta.numel(), mode, 1 if force else 0, _stream(x))
     if rc == -3:   # WL_ERR_UNSUPPORTED
-        if not force:
+        # (a decline is remembered - unless it is the streaming kernels being switched off for a test / an A/B run)
+        if not force and not _backend().wl_get_option(b'no_stream') and not _backend().wl_get_option(b'generic_only'):
             _FUSED_DECLINED.add(key)
         return None
     _lib.check(rc, 'wl_dtcwt_fwd_level12')
