@@ -207,7 +207,10 @@ int wl_dwt2d_analysis_stream(const void* x, int64_t x_plane_stride, int x_row_st
 /* ONE synthesis level by the streaming strip kernel (csrc/wl_idwt_strip.h): the same operator as wl_dwt2d_synthesis
  * (SFB2D.forward, dwt/lowlevel.py:671-680; the (OH, OW) crop is AFB2D.backward's, :356-364) for one square filter length L
  * (even, <= 20), float32 / float16, every mode, coefficient rows that are whole 16-byte pieces; highs must be present.
- * policy as for wl_dwt2d_analysis_stream.  Returns WL_ERR_UNSUPPORTED outside its envelope. */
+ * policy bit 0 as for wl_dwt2d_analysis_stream (1 = force); bit 1 (value 2) = the caller vouches that each highpass bank is
+ * the quadrature mirror of its lowpass bank, g_hi[t] = (-1)^t g_lo[L-1-t] (the reconstruction pair of every orthogonal
+ * wavelet): from 12 taps on the kernel then derives the highpass tap pairs from the lowpass ones by operand modifiers instead
+ * of holding both banks in scalar registers (same arithmetic, same results).  Returns WL_ERR_UNSUPPORTED outside its envelope. */
 int wl_dwt2d_synthesis_stream(const void* ll, int64_t ll_plane_stride, int ll_row_stride, const void* highs, void* y,
                               int dtype, int64_t planes, int Kh, int Kw, int OH, int OW, const void* g_w_lo,
                               const void* g_w_hi, const void* g_h_lo, const void* g_h_hi, int L, int mode, int policy,

@@ -48,7 +48,11 @@ struct WlIStripArgs {
     int quad_ok;                   // every lane's 4 output columns are one aligned store (OW % 4 == 0, aligned y)
 };
 
-template <typename T, int LT, int SODD>
+// QMF = 1: the caller vouches that each highpass bank is the quadrature mirror of its lowpass bank, g1[t] = (-1)^t g0[L-1-t]
+// (every orthogonal wavelet as pywt / the reference tabulates its RECONSTRUCTION pair): the highpass tap pairs are then the
+// lowpass pairs read backwards with the halves swapped and one half negated - operand modifiers of the packed FMA - and never
+// occupy scalar registers (68 of them at 16 taps: the scalar file overflowed, 32 v_readlane per half-batch).
+template <typename T, int LT, int SODD, int QMF = 0>
 struct WlSfbStrip {
     typedef WlIStripArgs<T> Args;
     static const int kWaves = WL_STRIP_CWAVES + 4;
@@ -247,9 +251,29 @@ struct WlSfbStrip {
 
     // ---- compute wave ---------------------------------------------------------------------------------------------
     struct Wave {
-        wl_v2 twl[NT], twh[NT];    // row-synthesis tap pairs of the W-low / W-high bank (shifted by one for SODD)
-        wl_v2 ghl[HL], ghh[HL];    // (g[2t], g[2t+1]) of the H-low / H-high bank
+        wl_v2 twl[NT], twh[QMF ? 1 : NT];    // row-synthesis tap pairs of the W-low / W-high bank (shifted by one for SODD)
+        wl_v2 ghl[HL], ghh[QMF ? 1 : HL];    // (g[2t], g[2t+1]) of the H-low / H-high bank
     };
+    // acc += q(pair) * s.x / s.y, q(pair) = (pair.y, pair.x) with one half negated: NEGLO -> (-pair.y, pair.x), else (pair.y, -pair.x)
+    template <int Y, int NEGLO> static WL_DEV void fma_q(wl_v2& acc, wl_v2 pair, wl_v2 sv) {
+#if defined(__HIPCC__)
+        if (Y) {
+            if (NEGLO) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "+v"(acc) : "s"(pair), "v"(sv));
+            else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "+v"(acc) : "s"(pair), "v"(sv));
+        } else {
+            if (NEGLO) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "+v"(acc) : "s"(pair), "v"(sv));
+            else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "+v"(acc) : "s"(pair), "v"(sv));
+        }
+#else
+        const float c = Y ? sv.y : sv.x;
+        const float q0 = NEGLO ? -pair.y : pair.y, q1 = NEGLO ? pair.x : -pair.x;
+        acc.x = __builtin_fmaf(q0, c, acc.x); acc.y = __builtin_fmaf(q1, c, acc.y);
+#endif
+    }
+    // row synthesis: twh[j] = (-twl[NT-1-j].y, twl[NT-1-j].x) for the shifted pairs (SODD), (twl[HL-1-j].y, -twl[HL-1-j].x) else
+    template <int r, int J> static WL_DEV void fma_cell_q(wl_v2& acc, const Wave& R, const wl_v2 (&v)[NC2]) {
+        fma_q<(r & 1), SODD>(acc, R.twl[NT - 1 - J], v[r / 2]);
+    }
     // the NT + 1 coefficients of one staged source row, as (even, odd) pairs
     static WL_DEV void load_row(const char* p, wl_v2 (&v)[NC2]) {
 #pragma unroll
@@ -270,7 +294,7 @@ struct WlSfbStrip {
     template <int P, int J> struct RowSyn {
         static WL_DEV void run(const Wave& R, const wl_v2 (&lo)[NC2], const wl_v2 (&hi)[NC2], wl_v2& acc) {
             fma_cell<NT - 1 - J + P>(acc, R.twl[J], lo);
-            fma_cell<NT - 1 - J + P>(acc, R.twh[J], hi);
+            if (QMF) fma_cell_q<NT - 1 - J + P, J>(acc, R, hi); else fma_cell<NT - 1 - J + P>(acc, R.twh[QMF ? 0 : J], hi);
             RowSyn<P, J + 1>::run(R, lo, hi, acc);
         }
     };
@@ -280,7 +304,7 @@ struct WlSfbStrip {
     template <int P>
     static WL_DEV wl_v2 row_syn(const Wave& R, const wl_v2 (&lo)[NC2], const wl_v2 (&hi)[NC2]) {
         wl_v2 acc = mul_cell<NT - 1 + P>(R.twl[0], lo);
-        fma_cell<NT - 1 + P>(acc, R.twh[0], hi);
+        if (QMF) fma_cell_q<NT - 1 + P, 0>(acc, R, hi); else fma_cell<NT - 1 + P>(acc, R.twh[0], hi);
         RowSyn<P, 1>::run(R, lo, hi, acc);
         return acc;
     }
@@ -288,14 +312,24 @@ struct WlSfbStrip {
     // y0 = (z-row 2m, 2m+1) of the pair's even column, y1 of its odd column
     static WL_DEV void col_syn(const Wave& R, const wl_v2 (&wa)[LW], const wl_v2 (&wb)[LW], int newest, wl_v2& y0, wl_v2& y1) {
         y0 = wl_pk_mul_x(R.ghl[0], wa[newest % LW]); y1 = wl_pk_mul_y(R.ghl[0], wa[newest % LW]);
-        wl_pk_fma_x(y0, R.ghh[0], wb[newest % LW]);
-        wl_pk_fma_y(y1, R.ghh[0], wb[newest % LW]);
+        if (QMF) {   // ghh[t] = (ghl[HL-1-t].y, -ghl[HL-1-t].x)
+            fma_q<0, 0>(y0, R.ghl[HL - 1], wb[newest % LW]);
+            fma_q<1, 0>(y1, R.ghl[HL - 1], wb[newest % LW]);
+        } else {
+            wl_pk_fma_x(y0, R.ghh[0], wb[newest % LW]);
+            wl_pk_fma_y(y1, R.ghh[0], wb[newest % LW]);
+        }
 #pragma unroll
         for (int t = 1; t < HL; ++t) {
             wl_pk_fma_x(y0, R.ghl[t], wa[(newest + LW - t) % LW]);
             wl_pk_fma_y(y1, R.ghl[t], wa[(newest + LW - t) % LW]);
-            wl_pk_fma_x(y0, R.ghh[t], wb[(newest + LW - t) % LW]);
-            wl_pk_fma_y(y1, R.ghh[t], wb[(newest + LW - t) % LW]);
+            if (QMF) {
+                fma_q<0, 0>(y0, R.ghl[HL - 1 - t], wb[(newest + LW - t) % LW]);
+                fma_q<1, 0>(y1, R.ghl[HL - 1 - t], wb[(newest + LW - t) % LW]);
+            } else {
+                wl_pk_fma_x(y0, R.ghh[QMF ? 0 : t], wb[(newest + LW - t) % LW]);
+                wl_pk_fma_y(y1, R.ghh[QMF ? 0 : t], wb[(newest + LW - t) % LW]);
+            }
         }
     }
 
@@ -312,12 +346,12 @@ struct WlSfbStrip {
             const float h0 = i0 >= 0 && i0 < LT ? a.g_w_hi[i0 >= 0 && i0 < LT ? i0 : 0] : 0.f;
             const float h1 = i1 >= 0 && i1 < LT ? a.g_w_hi[i1 >= 0 && i1 < LT ? i1 : 0] : 0.f;
             R.twl[j] = wl_uniform_v2(wl_v2{l0, l1});
-            R.twh[j] = wl_uniform_v2(wl_v2{h0, h1});
+            if (!QMF) R.twh[QMF ? 0 : j] = wl_uniform_v2(wl_v2{h0, h1});
         }
 #pragma unroll
         for (int t = 0; t < HL; ++t) {
             R.ghl[t] = wl_uniform_v2(wl_v2{a.g_h_lo[2 * t], a.g_h_lo[2 * t + 1]});
-            R.ghh[t] = wl_uniform_v2(wl_v2{a.g_h_hi[2 * t], a.g_h_hi[2 * t + 1]});
+            if (!QMF) R.ghh[QMF ? 0 : t] = wl_uniform_v2(wl_v2{a.g_h_hi[2 * t], a.g_h_hi[2 * t + 1]});
         }
         char* const yp = reinterpret_cast<char*>(a.y + (size_t)plane * a.OH * a.OW);
         const unsigned rowb = (unsigned)a.OW * SZ;

@@ -4,6 +4,7 @@ import torch
 import torch.nn as nn
 
 from .. import filters
+from .. import ops
 from . import lowlevel
 
 
@@ -59,13 +60,31 @@ class DWTInverse(nn.Module):
         self.register_buffer('g0_row', filts[2])
         self.register_buffer('g1_row', filts[3])
         self.mode = mode
+        self._refresh_qmf()
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._refresh_qmf())
+
+    def _refresh_qmf(self):
+        """Are the highpass banks the quadrature mirrors of the lowpass banks, g1[t] = (-1)**t g0[L-1-t] (every orthogonal
+        wavelet's reconstruction pair)?  The streaming synthesis kernels then derive the highpass tap pairs from the lowpass
+        ones instead of holding both in scalar registers (ops.qmf_hint).  Checked on the host when the module is built and
+        after load_state_dict - not on the hot path."""
+        ok = True
+        for lo, hi in ((self.g0_col, self.g1_col), (self.g0_row, self.g1_row)):
+            a, b = lo.detach().reshape(-1).double().cpu(), hi.detach().reshape(-1).double().cpu()
+            if a.numel() != b.numel() or a.numel() % 2:
+                ok = False
+                break
+            sign = torch.tensor([1.0, -1.0], dtype=torch.float64).repeat(a.numel() // 2)
+            ok = ok and bool(torch.equal(b, sign * a.flip(0)))
+        self._qmf = ok
 
     def forward(self, coeffs):
         yl, yh = coeffs
         mode = lowlevel.mode_to_int(self.mode)
         if len(yh) == 0:
             return yl
-        return lowlevel.SFB2DMulti.apply(yl, self.g0_col, self.g1_col, self.g0_row, self.g1_row, mode, *yh)
+        with ops.qmf_hint(self._qmf):
+            return lowlevel.SFB2DMulti.apply(yl, self.g0_col, self.g1_col, self.g0_row, self.g1_row, mode, *yh)
 
 
 class SWTForward(nn.Module):

@@ -1,5 +1,7 @@
 """Tensor-level wrappers over the C ABI: allocate outputs with torch, pass raw device pointers and
 the current HIP stream down, nothing else.  (PyTorch is plumbing here: memory + streams.)"""
+import contextlib
+import threading
 import torch
 
 from . import _lib
@@ -163,6 +165,22 @@ def sfb2d(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None):
 
 
 _CU_COUNT = {}
+_HINTS = threading.local()
+
+
+@contextlib.contextmanager
+def qmf_hint(flag):
+    """Inside this context the caller vouches that the HIGHPASS synthesis banks handed to sfb2d_stream are the quadrature
+    mirrors of the lowpass banks, g1[t] = (-1)**t * g0[L-1-t] (policy bit 1 of wl_dwt2d_synthesis_stream): DWTInverse sets it
+    from the filter table it was built with."""
+    prev = getattr(_HINTS, 'qmf', False)
+    _HINTS.qmf = bool(flag)
+    try:
+        yield
+    finally:
+        _HINTS.qmf = prev
+
+
 STREAM_FORCE = False   # tests: send every single-level analysis the strip kernel covers to it, whatever the shape
 FUSED_STRIPS = 0   # default `strips` of the two streaming entry points below: 0 = the engine's policy (the planes must fill
                    # the chip), 1 / 2 = force the streaming kernels whatever the batch (tests pin their backward passes so)
@@ -326,14 +344,15 @@ def sfb2d_stream(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None, f
     ll, ll_ps, ll_rs = _planes(ll)
     highs = highs.contiguous()
     _same_device(ll, highs)
-    key = ('sfbs', ll.device, ll.dtype, N * C, Kh, Kw, ll_ps, ll_rs, OH, OW, L, mode, bool(force))
+    qmf = bool(getattr(_HINTS, 'qmf', False))
+    key = ('sfbs', ll.device, ll.dtype, N * C, Kh, Kw, ll_ps, ll_rs, OH, OW, L, mode, bool(force), qmf)
     if key in _FUSED_DECLINED:
         return None
     gwl, gwh, ghl, ghh = (_taps(g, ll) for g in (g_w_lo, g_w_hi, g_h_lo, g_h_hi))
     y = torch.empty((N, C, OH, OW), dtype=ll.dtype, device=ll.device)
     rc = _call('wl_dwt2d_synthesis_stream', ll, ll.data_ptr(), ll_ps, ll_rs, highs.data_ptr(), y.data_ptr(), _DTYPES[ll.dtype],
                N * C, Kh, Kw, OH, OW, gwl.data_ptr(), gwh.data_ptr(), ghl.data_ptr(), ghh.data_ptr(), L, mode,
-               1 if force else 0, _stream(ll))
+               (1 if force else 0) | (2 if qmf else 0), _stream(ll))
     if rc == -3:
         _FUSED_DECLINED.add(key)
         return None

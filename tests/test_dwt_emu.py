@@ -539,3 +539,35 @@ def test_strip_synthesis_float16_modules_and_declines(monkeypatch):
         (rec2 * x).sum().backward()
     assert float((rec - rec2).abs().max()) < 1e-5 and float((rec - x).abs().max()) < 1e-4
     assert float((xa.grad - xb.grad).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize('wave,mode', [('db6', 'periodization'), ('db6', 'symmetric'), ('db7', 'zero'), ('db8', 'periodization'),
+                                       ('sym8', 'reflect'), ('coif3', 'periodization'), ('db10', 'periodization'), ('db10', 'symmetric')])
+def test_quadrature_mirror_variant_of_the_synthesis_strip_kernel(wave, mode, monkeypatch):
+    """From 12 taps on DWTInverse tells the streaming synthesis kernel that its highpass banks are the quadrature mirrors of
+    the lowpass banks (ops.qmf_hint): the kernel derives the highpass tap pairs by operand modifiers.  Same result as with
+    both banks in registers, both tap-pair shifts (periodization with L % 4 == 0 rolls by an odd amount), float32 / float16."""
+    from pytorch_wavelets_amd import ops
+    from pytorch_wavelets_amd.dwt import lowlevel as _ll
+    torch.manual_seed(0)
+    monkeypatch.setattr(ops, 'STREAM_FORCE', True)
+    monkeypatch.setattr(_ll, 'FUSED_LEVELS', False)      # (12 taps would otherwise take the fused multi-level kernel)
+    for dtype in (torch.float32, torch.float16):
+        x = torch.randn(2, 2, 64, 288, dtype=dtype)
+        with emu_backend.emulated():
+            xfm = pw.DWTForward(J=2, wave=wave, mode=mode).to(dtype)
+            ifm = pw.DWTInverse(wave=wave, mode=mode).to(dtype)
+            assert ifm._qmf
+            yl, yh = xfm(x)
+            r1 = ifm((yl, yh))
+            assert 'WlSfbStrip' in pw.last_kernel() and pw.last_kernel().rstrip('>').endswith(', 1'), pw.last_kernel()
+            ifm._qmf = False
+            r2 = ifm((yl, yh))
+            assert 'WlSfbStrip' in pw.last_kernel() and not pw.last_kernel().rstrip('>').endswith(', 1, 1'), pw.last_kernel()
+        tol = 2e-3 if dtype == torch.float16 else 1e-6
+        assert float((r1.float() - r2.float()).abs().max()) <= tol * float(r2.float().abs().max())
+        assert float((r1.float() - x.float()).abs().max()) <= (2e-2 if dtype == torch.float16 else 1e-4) * float(x.float().abs().max())
+
+
+def test_biorthogonal_banks_are_not_quadrature_mirrors():
+    assert not pw.DWTInverse(wave='bior2.2')._qmf and pw.DWTInverse(wave='db4')._qmf

@@ -639,3 +639,29 @@ def test_mixed_device_inputs_are_rejected():
     ifm = pw.DWTInverse(wave='db1').to('cuda:0')
     with pytest.raises(RuntimeError, match='different devices'):
         ifm((torch.randn(1, 1, 4, 4, device='cuda:0'), [torch.randn(1, 1, 3, 4, 4, device='cuda:1')]))
+
+
+@pytest.mark.parametrize('wave,mode,shape,dtype', [('db8', 'periodization', (8, 16, 1024, 1024), torch.float16),
+                                                    ('db8', 'symmetric', (64, 3, 512, 512), torch.float32),
+                                                    ('db6', 'periodization', (64, 3, 512, 512), torch.float32),
+                                                    ('coif3', 'zero', (64, 3, 512, 520), torch.float32)])
+def test_quadrature_mirror_variant_of_the_synthesis_strip_kernel_gpu(wave, mode, shape, dtype, monkeypatch):
+    """DWTInverse with orthogonal wavelets of 12 taps and more: the synthesis strip kernel derives its highpass tap pairs from
+    the lowpass ones (ops.qmf_hint).  Against the same kernel with both banks in registers, and the round trip."""
+    from pytorch_wavelets_amd.dwt import lowlevel as _ll
+    monkeypatch.setattr(_ll, 'FUSED_LEVELS', False)
+    torch.manual_seed(0)
+    x = torch.randn(*shape, device=DEV).to(dtype)
+    xfm = pw.DWTForward(J=2, wave=wave, mode=mode).to(DEV).to(dtype)
+    ifm = pw.DWTInverse(wave=wave, mode=mode).to(DEV).to(dtype)
+    assert ifm._qmf
+    yl, yh = xfm(x)
+    r1 = ifm((yl, yh))
+    k1 = pw.last_kernel()
+    ifm._qmf = False
+    r2 = ifm((yl, yh))
+    k2 = pw.last_kernel()
+    assert 'WlSfbStrip' in k1 and k1.rstrip('>').endswith(', 1') and 'WlSfbStrip' in k2 and k1 != k2, (k1, k2)
+    tol = 2e-3 if dtype == torch.float16 else 1e-6
+    assert float((r1.float() - r2.float()).abs().max()) <= tol * float(r2.float().abs().max())
+    assert float((r1.float() - x.float()).abs().max()) <= (2e-2 if dtype == torch.float16 else 1e-4) * float(x.float().abs().max())
