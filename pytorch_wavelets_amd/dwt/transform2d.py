@@ -47,6 +47,11 @@ class DWTForward(nn.Module):
         return outs[0], list(outs[1:])
 
 
+def _refresh_qmf_hook(module, incompatible_keys):
+    """load_state_dict post hook of DWTInverse (a module-level function so that the module stays picklable)."""
+    module._refresh_qmf()
+
+
 class DWTInverse(nn.Module):
     """2-D multi-level inverse DWT.  ``DWTInverse(wave='db1', mode='zero')((yl, yh)) -> x``;
     ``None`` entries of ``yh`` are zeros (reference transform2d.py:77-148)."""
@@ -61,7 +66,7 @@ class DWTInverse(nn.Module):
         self.register_buffer('g1_row', filts[3])
         self.mode = mode
         self._refresh_qmf()
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module._refresh_qmf())
+        self.register_load_state_dict_post_hook(_refresh_qmf_hook)
 
     def _refresh_qmf(self):
         """Are the highpass banks the quadrature mirrors of the lowpass banks, g1[t] = (-1)**t g0[L-1-t] (every orthogonal
