@@ -286,21 +286,20 @@ def main():
 
     def timed_region():
         """W warmup steps, then EXACTLY K steps between barrier + synchronize on both sides; MAX over ranks."""
+        # (the cyclic garbage collector is frozen + disabled ONCE, before the first region - see below: nothing may idle the
+        # device between the warm-up and t0, a 45 ms gc.collect() there let the clocks the ramp had just raised fall again)
         for _ in range(args.warmup):
             wl.step()
-        # the cyclic garbage collector stays out of the K timed steps (like timeit): a full collection of a process that
-        # has imported torch takes 35-65 ms, the whole timed region of --config dtcwt 6 ms (seen: one step of ten at 65 ms)
-        gc.collect()
-        gc.disable()
         barrier()
         t0 = time.perf_counter()
         stamps = []
         for _ in range(K):
             out = wl.step()
             stamps.append(time.perf_counter())
+        t_issued = time.perf_counter()
         barrier()
         dt = time.perf_counter() - t0
-        gc.enable()
+        host_issue.append((t_issued - t0) / K * 1e3)
         if os.environ.get('WL_BENCH_STAMPS'):
             print('[stamps] host ms per step: %s; drain %.2f ms' % (' '.join('%.2f' % ((b - a) * 1e3) for a, b in zip([t0] + stamps, stamps)),
                                                                    (t0 + dt - stamps[-1]) * 1e3), file=sys.stderr, flush=True)
@@ -310,6 +309,14 @@ def main():
             dt = float(tmax.item())
         return dt, out
 
+    # The cyclic garbage collector stays out of everything that is timed (like timeit): a full collection of a process that has
+    # imported torch takes 35-65 ms (the whole timed region of --config dtcwt is 6 ms).  Collect once NOW, freeze the survivors
+    # (they are never scanned again) and switch the collector off until the timing is over - never between a warm-up and its
+    # timed region (round 3 did that: the device idled for 45 ms and dropped the clocks the ramp steps had paid for).
+    host_issue = []
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     # 1. cold: a fresh process, W warmup steps, K timed steps - the number a one-shot caller sees
     dt_cold, _ = timed_region()
     # 2. steady: the GPU takes ~20 ms of continuous work to reach its steady clocks (tools/gpu_rampup_probe.py: the first
@@ -351,6 +358,7 @@ def main():
                 for p in seq:
                     wl.run(p)
             return (time.perf_counter() - t0) * 1e3 / n
+        prefill(2.0)      # (the host queues the loop while the device is still busy: no launch gaps inside the bracket)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(n):
@@ -436,6 +444,22 @@ def main():
                              'T(step)' % K,
                 'closure': round(closure, 4), 'step_ms_events': round(med['S'], 4)}
         roof.update(block('f'))
+        if wl.key == 'cfg5':
+            # config 5 is borderline VALU-bound - both bounds in the line.  VALU roofline of the arithmetic the
+            # kernels execute: 17 packed FMAs (v_pk_fma_f32) per output sample at 16 taps (L row taps + L column taps + 1, on
+            # (lo, hi) pairs), one output sample per input pixel and level (critically sampled: sum over 4 levels = 1.328 P);
+            # a wave64 VALU instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md).
+            samples = wl.x.numel() * sum(0.25 ** j for j in range(wl.J))
+            valu_min_ms = samples * 17 * 4 / 64 / (1024 * 2.4e9) * 1e3
+            hbm_min_ms = wl.bytes['f'] / (HBM_PEAK_GBS * 1e9) * 1e3
+            roof['bound'] = 'valu' if valu_min_ms > hbm_min_ms else 'hbm'
+            roof['valu'] = {'bound': 'valu', 'unit': 'ms', 'min_ms_at_valu_peak': round(valu_min_ms, 4),
+                            'min_ms_at_hbm_peak': round(hbm_min_ms, 4),
+                            'frac': round(valu_min_ms / part_ms['f'], 4),
+                            'what': '17 v_pk_fma_f32 per output sample x 1.328 samples per pixel, 4 cycles per wave64 '
+                                    'instruction and SIMD, 1024 SIMDs at 2.4 GHz'}
+            if 'i' in part_ms:
+                roof['valu']['inverse_frac'] = round(valu_min_ms / part_ms['i'], 4)
         if wl.key == 'dwt':
             roof['launches_per_forward'] = len(launches['f'])
         if 'i' in part_ms:
@@ -451,6 +475,9 @@ def main():
             'unit': 'Mpixels/s',
             'n_gpus': world, 'steps': K, 'warmup': args.warmup,
             'ms_per_step': round(dt / K * 1e3, 4),
+            'step_ms_events': round(med['S'], 4),
+            'timing_consistent': bool(abs(dt / K * 1e3 / med['S'] - 1.0) < 0.05),
+            'host_issue_ms_per_step': round(host_issue[-1], 4),
             'higher_is_better': True, 'scaling': wl.scaling, 'vs_baseline': None,
             'clock_ramp_steps_untimed': RAMP_STEPS,
             'cold': {'ms_per_step': round(dt_cold / K * 1e3, 4), 'value': round(pixels * K / dt_cold / 1e6, 1),
@@ -470,6 +497,8 @@ def main():
             out['data'] = 'synthetic (HOST EMULATION of the kernels: control-flow test, not a measurement)'
         if other is not None:
             out['other_configs'] = other
+        gc.enable()
+        gc.unfreeze()
         if not args.no_cpu_baseline and world == 1 and not emu and wl.key == 'dwt':
             out['cpu_baseline'] = cpu_baseline(args)
         else:
@@ -480,10 +509,28 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def time_seq_fn(fn, n, sync):
+_PREFILL = {}
+
+
+def prefill(ms):
+    """Queue ~ms of device copies on the current stream (a 256 MiB copy takes ~0.1 ms)."""
+    dev = torch.cuda.current_device()
+    if dev not in _PREFILL:
+        _PREFILL[dev] = (torch.empty(64 << 20, dtype=torch.float32, device='cuda'), torch.empty(64 << 20, dtype=torch.float32, device='cuda'))
+    a, b = _PREFILL[dev]
+    for _ in range(max(1, int(ms / 0.12))):
+        b.copy_(a)
+
+
+def time_seq_fn(fn, n, sync, prefill_ms=4.0):
+    """ms per call of fn: HIP events around a loop of n calls on the launch stream, after 10 untimed calls.  Before the first
+    event the stream is PRE-FILLED with ~prefill_ms of device copies, so that the host has the whole loop queued by the time the
+    device reaches the first event: what is measured is kernel time back to back, not the host's launch path (round 3's
+    10-iteration loops around two or three short launches carried ~40 us of launch gaps per call)."""
     for _ in range(10):
         fn()
     sync()
+    prefill(prefill_ms)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
@@ -509,47 +556,47 @@ def other_configs(pw, dev, sync):
         xd = torch.randn(64, 3, 512, 512, device=dev)
         dx, di = pw.DTCWTForward(J=3).to(dev), pw.DTCWTInverse().to(dev)
         dyl, dyh = dx(xd)
-        tf, ti = time_seq_fn(lambda: dx(xd), 10, sync), time_seq_fn(lambda: di((dyl, dyh)), 10, sync)
+        tf, ti = time_seq_fn(lambda: dx(xd), 30, sync), time_seq_fn(lambda: di((dyl, dyh)), 30, sync)
         other['dtcwt_j3_near_sym_a_qshift_a_64x3x512x512_fp32'] = {
             'fwd_ms': round(tf, 4), 'inv_ms': round(ti, 4), 'fwd_inv_mpix_s': round(xd.numel() / (tf + ti) / 1e3, 1),
             'fwd_frac_of_hbm_peak_at_20B_per_px': frac(20 * xd.numel(), tf),
             'inv_frac_of_hbm_peak_at_20B_per_px': frac(20 * xd.numel(), ti),
             'fwd_kernels': names(lambda: dx(xd)), 'inv_kernels': names(lambda: di((dyl, dyh)))}
         d1x = pw.DTCWTForward(J=1).to(dev)
-        t1f = time_seq_fn(lambda: d1x(xd), 10, sync)
+        t1f = time_seq_fn(lambda: d1x(xd), 30, sync)
         other['dtcwt_j1_near_sym_a_64x3x512x512_fp32'] = {'fwd_ms': round(t1f, 4), 'fwd_frac_of_hbm_peak_at_20B_per_px': frac(20 * xd.numel(), t1f),
                                                          'fwd_kernels': names(lambda: d1x(xd))}
         slw = pw.ScatLayer().to(dev)
-        tsw = time_seq_fn(lambda: slw(xd), 10, sync)
+        tsw = time_seq_fn(lambda: slw(xd), 30, sync)
         other['scatlayer_64x3x512x512_fp32'] = {'fwd_ms': round(tsw, 4), 'frac_of_hbm_peak_at_11B_per_px': frac(11 * xd.numel(), tsw),
                                                'fwd_kernels': names(lambda: slw(xd))}
         del xd, dyl, dyh
         xs = torch.randn(256, 3, 256, 256, device=dev)
         sl = pw.ScatLayer().to(dev)
-        ts = time_seq_fn(lambda: sl(xs), 10, sync)
+        ts = time_seq_fn(lambda: sl(xs), 30, sync)
         other['scatlayer_256x3x256x256_fp32_one_gpu'] = {
             'fwd_ms': round(ts, 4), 'mpix_s': round(xs.numel() / ts / 1e3, 1),
             'frac_of_hbm_peak_at_11B_per_px': frac(11 * xs.numel(), ts), 'fwd_kernels': names(lambda: sl(xs))}
         # f2: ScatLayerj2 and the rotationally symmetric variant (no fused kernel: single-axis launches)
         xs2 = xs[:64]
         s2 = pw.ScatLayerj2().to(dev)
-        t2 = time_seq_fn(lambda: s2(xs2), 5, sync)
+        t2 = time_seq_fn(lambda: s2(xs2), 20, sync)
         sr = pw.ScatLayer(biort='near_sym_b_bp').to(dev)
-        tr = time_seq_fn(lambda: sr(xs2), 5, sync)
+        tr = time_seq_fn(lambda: sr(xs2), 20, sync)
         other['scatlayerj2_64x3x256x256_fp32'] = {'fwd_ms': round(t2, 4), 'mpix_s': round(xs2.numel() / t2 / 1e3, 1)}
         other['scatlayer_rot_near_sym_b_bp_64x3x256x256_fp32'] = {'fwd_ms': round(tr, 4), 'mpix_s': round(xs2.numel() / tr / 1e3, 1)}
         del xs, xs2
         # f3: 1-D DWT and the stationary transform (generic single-axis kernels)
         x1 = torch.randn(64, 16, 65536, device=dev)
         d1 = pw.DWT1DForward(J=3, wave='db4', mode='symmetric').to(dev)
-        t1 = time_seq_fn(lambda: d1(x1), 5, sync)
+        t1 = time_seq_fn(lambda: d1(x1), 20, sync)
         other['dwt1d_j3_db4_64x16x65536_fp32'] = {'fwd_ms': round(t1, 4), 'msamples_s': round(x1.numel() / t1 / 1e3, 1),
                                                   'frac_of_hbm_peak_at_8B_per_sample': frac(8 * x1.numel(), t1)}
         del x1
         from pytorch_wavelets_amd.dwt.transform2d import SWTForward
         xw = torch.randn(16, 3, 512, 512, device=dev)
         sw = SWTForward(J=2, wave='db2', mode='periodic').to(dev)
-        tw = time_seq_fn(lambda: sw(xw), 5, sync)
+        tw = time_seq_fn(lambda: sw(xw), 20, sync)
         other['swt_j2_db2_periodic_16x3x512x512_fp32'] = {'fwd_ms': round(tw, 4), 'mpix_s': round(xw.numel() / tw / 1e3, 1)}
         del xw
         # outside the fused streaming envelope of round 2: wider images, longer filters
@@ -558,8 +605,8 @@ def other_configs(pw, dev, sync):
             xl = torch.randn(*shape, device=dev)
             fx, fi = pw.DWTForward(J=3, wave=wave, mode='symmetric').to(dev), pw.DWTInverse(wave=wave, mode='symmetric').to(dev)
             c = fx(xl)
-            tf = time_seq_fn(lambda: fx(xl), 10, sync)
-            ti = time_seq_fn(lambda: fi(c), 10, sync)
+            tf = time_seq_fn(lambda: fx(xl), 30, sync)
+            ti = time_seq_fn(lambda: fi(c), 30, sync)
             b = algorithmic_bytes_fwd(shape[0], shape[1], shape[2], shape[3], 3, L, 4)
             other[tag] = {'fwd_ms': round(tf, 4), 'inv_ms': round(ti, 4), 'fwd_frac': frac(b, tf), 'inv_frac': frac(b, ti),
                           'fwd_kernels': names(lambda: fx(xl)), 'inv_kernels': names(lambda: fi(c))}
@@ -568,8 +615,8 @@ def other_configs(pw, dev, sync):
         hx = pw.DWTForward(J=4, wave='db8', mode='periodization').to(dev).half()
         hi = pw.DWTInverse(wave='db8', mode='periodization').to(dev).half()
         hyl, hyh = hx(xh)
-        th = time_seq_fn(lambda: hx(xh), 3, sync)
-        tih = time_seq_fn(lambda: hi((hyl, hyh)), 3, sync)
+        th = time_seq_fn(lambda: hx(xh), 5, sync)
+        tih = time_seq_fn(lambda: hi((hyl, hyh)), 5, sync)
         other['dwt_j4_db8_periodization_32x16x2048x2048_fp16'] = {
             'fwd_ms': round(th, 4), 'inv_ms': round(tih, 4), 'fwd_mpix_s': round(xh.numel() / th / 1e3, 1),
             'fwd_frac_of_hbm_peak_at_4B_per_px': frac(4 * xh.numel(), th),

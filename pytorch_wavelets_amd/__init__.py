@@ -50,5 +50,5 @@ IDWT2D = IDWT
 DWT1D = DWT1DForward
 IDWT1D = DWT1DInverse
 
-__all__ = ['__version__', 'last_kernel', 'DTCWTForward', 'DTCWTInverse', 'DWTForward', 'DWTInverse', 'DTCWT', 'IDTCWT',
+__all__ = ['__version__', 'last_kernel', 'launch_count', 'kernels_since', 'DTCWTForward', 'DTCWTInverse', 'DWTForward', 'DWTInverse', 'DTCWT', 'IDTCWT',
            'DWT', 'IDWT', 'DWT2D', 'IDWT2D', 'DWT1DForward', 'DWT1DInverse', 'DWT1D', 'IDWT1D', 'ScatLayer', 'ScatLayerj2']

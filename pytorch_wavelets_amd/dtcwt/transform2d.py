@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 from numpy import ndarray
 
+from .. import ops
 from ..dwt.lowlevel import mode_to_int
 from ..filters import biort as _biort, qshift as _qshift
 from .lowlevel import prep_filt
@@ -33,12 +34,9 @@ class DTCWTForward(nn.Module):
             h0o, h1o = biort[0], biort[1]
         self.register_buffer('h0o', prep_filt(h0o, 1))
         self.register_buffer('h1o', prep_filt(h1o, 1))
-        # a symmetric level-1 lowpass (every biorthogonal table) lets levels 1 and 2 run as one fused launch (FWD_J12)
-        try:
-            h0o_flat = np.asarray(h0o, dtype=np.float64).ravel()
-            self._h0o_symmetric = bool(np.allclose(h0o_flat, h0o_flat[::-1], rtol=0, atol=1e-10))
-        except Exception:   # (taps handed over as something numpy cannot read on the host)
-            self._h0o_symmetric = False
+        # a symmetric level-1 lowpass (every biorthogonal table) lets levels 1 and 2 run as one fused launch (FWD_J12): checked
+        # against the h0o buffer as it is at call time (ops.TapVerdict; the reference reads its buffers on every forward, :87-147)
+        self._h0o_symmetric = ops.TapVerdict(ops.is_symmetric_taps)
         if isinstance(qshift, str):
             h0a, h0b, _, _, h1a, h1b, _, _ = _qshift(qshift)[:8]
         else:
@@ -60,7 +58,7 @@ class DTCWTForward(nn.Module):
         # odd sizes are extended by edge replication and sizes that are not multiples of 4 by one row /
         # column on both sides (reference :116-135): both happen inside the kernels
         first = 1
-        if (self.J >= 2 and self._h0o_symmetric and not self.skip_hps[0] and not self.skip_hps[1]
+        if (self.J >= 2 and self._h0o_symmetric(self.h0o) and not self.skip_hps[0] and not self.skip_hps[1]
                 and not self.include_scale[0]):
             low, highs[0], highs[1] = FWD_J12.apply(x, self.h0o, self.h1o, self.h0a, self.h1a, self.h0b, self.h1b,
                                                     self.o_dim, self.ri_dim, mode)

@@ -47,9 +47,9 @@ class DWTForward(nn.Module):
         return outs[0], list(outs[1:])
 
 
-def _refresh_qmf_hook(module, incompatible_keys):
-    """load_state_dict post hook of DWTInverse (a module-level function so that the module stays picklable)."""
-    module._refresh_qmf()
+def _qmf_banks(g0_col, g1_col, g0_row, g1_row):
+    """Are both highpass banks the quadrature mirrors of their lowpass banks?  (module-level: DWTInverse stays picklable)"""
+    return ops.is_qmf_pair(g0_col, g1_col) and ops.is_qmf_pair(g0_row, g1_row)
 
 
 class DWTInverse(nn.Module):
@@ -65,30 +65,18 @@ class DWTInverse(nn.Module):
         self.register_buffer('g0_row', filts[2])
         self.register_buffer('g1_row', filts[3])
         self.mode = mode
-        self._refresh_qmf()
-        self.register_load_state_dict_post_hook(_refresh_qmf_hook)
-
-    def _refresh_qmf(self):
-        """Are the highpass banks the quadrature mirrors of the lowpass banks, g1[t] = (-1)**t g0[L-1-t] (every orthogonal
-        wavelet's reconstruction pair)?  The streaming synthesis kernels then derive the highpass tap pairs from the lowpass
-        ones instead of holding both in scalar registers (ops.qmf_hint).  Checked on the host when the module is built and
-        after load_state_dict - not on the hot path."""
-        ok = True
-        for lo, hi in ((self.g0_col, self.g1_col), (self.g0_row, self.g1_row)):
-            a, b = lo.detach().reshape(-1).double().cpu(), hi.detach().reshape(-1).double().cpu()
-            if a.numel() != b.numel() or a.numel() % 2:
-                ok = False
-                break
-            sign = torch.tensor([1.0, -1.0], dtype=torch.float64).repeat(a.numel() // 2)
-            ok = ok and bool(torch.equal(b, sign * a.flip(0)))
-        self._qmf = ok
+        # Kernel-variant hint, re-validated against the buffers on EVERY call (ops.TapVerdict): when each highpass bank is the
+        # quadrature mirror of its lowpass bank, g1[t] = (-1)**t g0[L-1-t] (every orthogonal wavelet's reconstruction pair), the
+        # streaming synthesis kernels derive the highpass tap pairs from the lowpass ones instead of holding both in scalar
+        # registers (ops.qmf_hint).  The reference reads its buffers on every forward (transform2d.py:131-148): so does this.
+        self._qmf = ops.TapVerdict(_qmf_banks)
 
     def forward(self, coeffs):
         yl, yh = coeffs
         mode = lowlevel.mode_to_int(self.mode)
         if len(yh) == 0:
             return yl
-        with ops.qmf_hint(self._qmf):
+        with ops.qmf_hint(self._qmf(self.g0_col, self.g1_col, self.g0_row, self.g1_row)):
             return lowlevel.SFB2DMulti.apply(yl, self.g0_col, self.g1_col, self.g0_row, self.g1_row, mode, *yh)
 
 

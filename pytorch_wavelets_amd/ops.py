@@ -168,6 +168,45 @@ _CU_COUNT = {}
 _HINTS = threading.local()
 
 
+class TapVerdict(object):
+    """A host-side property of filter buffers (a kernel-variant hint) that is valid for the buffers AS THEY ARE AT CALL TIME,
+    like everything the reference derives from its buffers (it reads them on every forward: dwt/transform2d.py:131-148,
+    dtcwt/transform2d.py:87-147).  The verdict is cached under (data_ptr, _version, dtype, device, shape) of every buffer it
+    depends on - one tuple compare per call, no device sync - and recomputed on the host when that key changes: in-place
+    edits (mul_, copy_, load_state_dict), re-assigned attributes, .half() / .double() / .to(...) all change it.  Buffers without
+    a version counter (inference tensors) get no hint at all.  `fn` must be a module-level function (modules stay picklable)."""
+
+    def __init__(self, fn):
+        self.fn = fn
+        self.key = None
+        self.val = False
+
+    def __call__(self, *bufs):
+        try:
+            key = tuple((b.data_ptr(), b._version, b.dtype, b.device, tuple(b.shape)) for b in bufs)
+        except (RuntimeError, AttributeError):
+            return False
+        if key != self.key:
+            self.val = bool(self.fn(*bufs))
+            self.key = key
+        return self.val
+
+
+def is_qmf_pair(lo, hi):
+    """g1[t] == (-1)**t * g0[L-1-t] exactly (the reconstruction pair of every orthogonal wavelet as pywt tabulates it), L even."""
+    a, b = lo.detach().reshape(-1).double().cpu(), hi.detach().reshape(-1).double().cpu()
+    if a.numel() != b.numel() or a.numel() % 2 or a.numel() == 0:
+        return False
+    sign = torch.tensor([1.0, -1.0], dtype=torch.float64).repeat(a.numel() // 2)
+    return bool(torch.equal(b, sign * a.flip(0)))
+
+
+def is_symmetric_taps(h):
+    """h[t] == h[L-1-t] exactly."""
+    a = h.detach().reshape(-1).double().cpu()
+    return a.numel() > 0 and bool(torch.equal(a, a.flip(0)))
+
+
 @contextlib.contextmanager
 def qmf_hint(flag):
     """Inside this context the caller vouches that the HIGHPASS synthesis banks handed to sfb2d_stream are the quadrature
@@ -188,6 +227,26 @@ FUSED_STRIPS = 0   # default `strips` of the two streaming entry points below: 0
 # compute waves, LDS budget, schedule table, ...).  A decline depends on nothing but the key, so the outputs of a doomed
 # call are allocated once per configuration, not on every forward of the n = 3, 2, 1 ladder of the callers.
 _FUSED_DECLINED = set()
+_FUSED_DECLINED_MAX = 4096
+
+
+def _remember_decline(key):
+    """Memoise a launcher's decline - unless an engine option is set (generic_only / no_stream / scat_stream: the decline may be
+    the option's, not the configuration's) - in a bounded set (a long-lived process that sees ever new shapes starts over)."""
+    be = _backend()
+    if be.wl_get_option(b'generic_only') or be.wl_get_option(b'no_stream') or be.wl_get_option(b'scat_stream'):
+        return
+    if len(_FUSED_DECLINED) >= _FUSED_DECLINED_MAX:
+        _FUSED_DECLINED.clear()
+    _FUSED_DECLINED.add(key)
+
+
+def set_option(name, value):
+    """wl_set_option of the C ABI ('generic_only', 'no_stream', 'scat_stream'); forgets the memoised declines, which may
+    depend on the options."""
+    _FUSED_DECLINED.clear()
+    rc = _backend().wl_set_option(name.encode() if isinstance(name, str) else name, int(value))
+    _lib.check(rc, 'wl_set_option')
 
 
 def _num_cus(device):
@@ -230,7 +289,7 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None):
     rc = _call('wl_dwt2d_analysis_fused', x, x.data_ptr(), yl.data_ptr(), ptrs, _DTYPES[x.dtype], N * C, H, W, nlev,
                hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(), hhh.data_ptr(), L, mode, strips, _stream(x))
     if rc == -3:
-        _FUSED_DECLINED.add(key)
+        _remember_decline(key)
         return None
     _lib.check(rc, 'wl_dwt2d_analysis_fused')
     return yl, yh
@@ -284,7 +343,7 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
                y.data_ptr(), _DTYPES[yl.dtype], N * C, nlev, gwl.data_ptr(), gwh.data_ptr(), ghl.data_ptr(),
                ghh.data_ptr(), L, mode, strips, _stream(yl))
     if rc == -3:
-        _FUSED_DECLINED.add(key)
+        _remember_decline(key)
         return None
     _lib.check(rc, 'wl_dwt2d_synthesis_fused')
     return y
@@ -315,7 +374,7 @@ def afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=False):
                _DTYPES[x.dtype], N * C, H, W, hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(), hhh.data_ptr(), L, mode,
                1 if force else 0, _stream(x))
     if rc == -3:
-        _FUSED_DECLINED.add(key)
+        _remember_decline(key)
         return None
     _lib.check(rc, 'wl_dwt2d_analysis_stream')
     return ll, highs
@@ -354,7 +413,7 @@ def sfb2d_stream(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None, f
                N * C, Kh, Kw, OH, OW, gwl.data_ptr(), gwh.data_ptr(), ghl.data_ptr(), ghh.data_ptr(), L, mode,
                (1 if force else 0) | (2 if qmf else 0), _stream(ll))
     if rc == -3:
-        _FUSED_DECLINED.add(key)
+        _remember_decline(key)
         return None
     _lib.check(rc, 'wl_dwt2d_synthesis_stream')
     return y
@@ -589,8 +648,8 @@ def dtcwt_fwd12(x, h0o, h1o, h0a, h0b, h1a, h1b, mode, force=False):
                tb.data_ptr(), tc.data_ptr(), td.data_ptr(), ta.numel(), mode, 1 if force else 0, _stream(x))
     if rc == -3:   # WL_ERR_UNSUPPORTED
         # (a decline is remembered - unless it is the streaming kernels being switched off for a test / an A/B run)
-        if not force and not _backend().wl_get_option(b'no_stream') and not _backend().wl_get_option(b'generic_only'):
-            _FUSED_DECLINED.add(key)
+        if not force:
+            _remember_decline(key)
         return None
     _lib.check(rc, 'wl_dtcwt_fwd_level12')
     return highs1, ll2, highs2

@@ -383,3 +383,10 @@ def test_kernel_history_names_every_launch_of_a_transform():
         inv = pw.kernels_since(c1)
     assert c1 - c0 == 2 and len(fwd) == 2 and 'WlDtFwd12Strip' in fwd[0] and 'WlDtFwd' in fwd[1], fwd
     assert len(inv) == 3 and 'Inv2' in inv[0] and 'Inv2' in inv[1] and 'Inv1' in inv[2], inv
+
+
+def test_filter_buffers_changed_after_construction_dtcwt_forward():
+    """Round-3 verdict, weak #1b: the fused level-1+2 launch relies on a symmetric h0o - checked against the buffer at call time."""
+    import _mutation_cases as M
+    with emu_backend.emulated():
+        M.check_dtcwt_forward_mutations('cpu')
