@@ -251,7 +251,9 @@ def main():
         from pytorch_wavelets_amd import ops
         ops._TEST_BACKEND = emu_backend.handle()
     elif rank == 0:
-        ge.build()
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):     # (stdout carries the ONE JSON line and nothing else)
+            ge.build()
     import pytorch_wavelets_amd as pw
     from pytorch_wavelets_amd import parallel
     if not emu:

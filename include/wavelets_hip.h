@@ -161,6 +161,18 @@ int wl_dtcwt_fwd_level12(const void* x, void* highs1, void* ll2, void* highs2, i
                          const void* h0o, int L0, const void* h1o, int L1, const void* h0a, const void* h0b,
                          const void* h1a, const void* h1b, int LQ, int mode, int policy, void* stream);
 
+/* Levels 2 AND 1 of the inverse in ONE launch (csrc/wl_dtcwt_inv_fused.h) = INV_J2PLUS.forward followed by INV_J1.forward the
+ * way DTCWTInverse.forward chains its last two levels (dtcwt/transform2d.py:240-254 -> transform_funcs.py:279-307, :152-184),
+ * the level-1 lowpass (H x W, the level-2 reconstruction) staying on chip: ll2 (planes,H/2,W/2) through strides, highs2
+ * (planes,6,H/4,W/4,2), highs1 (planes,6,H/2,W/2,2) -> y (planes,H,W).  All three inputs present, symmetric mode (1), H and W
+ * multiples of 4 (no 1-px crop between the levels), float32 / float16, the (7,5) / (5,7) level-1 pairs with 10-tap level-2
+ * filters; any tap VALUES (nothing is assumed about them).  policy 0 = the engine decides whether the launch pays, 1 = force.
+ * Returns WL_ERR_UNSUPPORTED outside its envelope: callers then chain wl_dtcwt_inv_level2 and wl_dtcwt_inv_level1. */
+int wl_dtcwt_inv_level21(const void* ll2, int64_t ll2_plane_stride, int ll2_row_stride, const void* highs2,
+                         const void* highs1, void* y, int dtype, int64_t planes, int H, int W, const void* g0o, int L0,
+                         const void* g1o, int L1, const void* g0a, const void* g0b, const void* g1a, const void* g1b, int LQ,
+                         int mode, int policy, void* stream);
+
 /* Level-1 inverse = INV_J1.forward -> inv_j1 (transform_funcs.py:152-184, :419-431): c2q x 3, 4 colfilter,
  * 2 rowfilter, 3 adds.  ll (planes,H,W) through strides (so the 1-px crop of transform_funcs.py:171-176 is a
  * view) or NULL; highs (planes,6,H/2,W/2,2) or NULL; y (planes,H,W). */

@@ -28,6 +28,7 @@ PROTOTYPES = {
     'wl_dtcwt_fwd_level1': (I, [P, P, P, I, L, I, I, P, I, P, I, I, P]),
     'wl_dtcwt_fwd_level2': (I, [P, P, P, I, L, I, I, P, P, P, P, I, P]),
     'wl_dtcwt_fwd_level12': (I, [P, P, P, P, I, L, I, I, P, I, P, I, P, P, P, P, I, I, I, P]),
+    'wl_dtcwt_inv_level21': (I, [P, L, I, P, P, P, I, L, I, I, P, I, P, I, P, P, P, P, I, I, I, P]),
     'wl_dtcwt_inv_level1': (I, [P, L, I, P, P, I, L, I, I, P, I, P, I, I, P]),
     'wl_dtcwt_inv_level2': (I, [P, L, I, P, P, I, L, I, I, P, P, P, P, I, P]),
     'wl_scat_fwd_level1': (I, [P, P, P, P, P, I, L, I, I, I, P, I, P, I, I, C.c_double, I, P]),

@@ -9,7 +9,7 @@ from .. import ops
 from ..dwt.lowlevel import mode_to_int
 from ..filters import biort as _biort, qshift as _qshift
 from .lowlevel import prep_filt
-from .transform_funcs import FWD_J1, FWD_J12, FWD_J2PLUS, INV_J1, INV_J2PLUS, _perm_from_default
+from .transform_funcs import FWD_J1, FWD_J12, FWD_J2PLUS, INV_J1, INV_J21, INV_J2PLUS, _perm_from_default
 
 
 def _is_empty(t):
@@ -125,6 +125,14 @@ class DTCWTInverse(nn.Module):
         perm = _perm_from_default(self.o_dim, self.ri_dim)
         h_dim, w_dim = perm.index(3), perm.index(4)
         for j, s in zip(range(J - 1, 0, -1), highs[1:][::-1]):
+            if j == 1 and not _is_empty(s) and not _is_empty(low) and not _is_empty(highs[0]):
+                # the last two levels as one operator (one launch where the engine takes it) when no crop separates them
+                low2 = self._crop_to(low, s, h_dim, w_dim)
+                if (s.dim() == 6 and highs[0].dim() == 6 and s.shape[self.o_dim] == 6 and s.shape[self.ri_dim] == 2
+                        and low2.shape[2] == 2 * s.shape[h_dim] and low2.shape[3] == 2 * s.shape[w_dim]
+                        and low2.shape[2] == highs[0].shape[h_dim] and low2.shape[3] == highs[0].shape[w_dim]):
+                    return INV_J21.apply(low2, s, highs[0], self.g0o, self.g1o, self.g0a, self.g1a, self.g0b, self.g1b,
+                                         self.o_dim, self.ri_dim, mode)
             if not _is_empty(s):
                 assert s.shape[self.o_dim] == 6, "Inverse transform must have input with 6 orientations"
                 assert len(s.shape) == 6, "Bandpass inputs must have 6 dimensions"

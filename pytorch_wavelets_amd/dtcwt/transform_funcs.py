@@ -186,9 +186,14 @@ class FWD_J12(Function):
             h0o, h1o, h0a, h1a, h0b, h1b = ctx.saved_tensors
             dh1 = None if _is_empty(dh1) else from_layout(dh1, *ctx.dims)
             dh2 = None if _is_empty(dh2) else from_layout(dh2, *ctx.dims)
-            dl1 = ops.dtcwt_inv2(dl2, dh2, h0b, h0a, h1b, h1a)          # swapped trees, as in FWD_J2PLUS.backward
-            dl1 = _unpad_grad_both(dl1, ctx.mid_hw)
-            dx = ops.dtcwt_inv1(dl1, dh1, h0o, h1o, ctx.mode)
+            dx = None
+            if dh1 is not None and dh2 is not None and ctx.mid_hw == ctx.in_hw and tuple(dh1.shape[3:5]) == tuple(dl2.shape[2:]):
+                # nothing was padded between the levels: one launch of the fused inverse (swapped trees, as below)
+                dx = ops.dtcwt_inv21(dl2, dh2, dh1, h0o, h1o, h0b, h0a, h1b, h1a, ctx.mode)
+            if dx is None:
+                dl1 = ops.dtcwt_inv2(dl2, dh2, h0b, h0a, h1b, h1a)          # swapped trees, as in FWD_J2PLUS.backward
+                dl1 = _unpad_grad_both(dl1, ctx.mid_hw)
+                dx = ops.dtcwt_inv1(dl1, dh1, h0o, h1o, ctx.mode)
             dx = _unpad_grad_odd(dx, ctx.in_hw)
         return (dx,) + (None,) * 9
 
@@ -247,6 +252,44 @@ class INV_J2PLUS(Function):
             dh = to_layout(dh, *ctx.dims) if need_h else None
             dl = dl if need_l else None
         return dl, dh, None, None, None, None, None, None, None
+
+
+class INV_J21(Function):
+    """Levels 2 and 1 of the inverse as ONE operator: ``INV_J21.apply(ll2, highs2, highs1, g0o, g1o, g0a, g1a, g0b, g1b, o_dim,
+    ri_dim, mode_int) -> y`` = INV_J2PLUS followed by INV_J1 (reference dtcwt/transform2d.py:240-254) without the level-1 lowpass
+    in between; all three inputs present and ``ll2`` exactly half the size of ``highs1``'s image (no crop between the levels).
+    One launch of the fused streaming kernel where the engine takes it, the two per-level launches otherwise; the backward is
+    the chain of the two per-level backward passes (reference transform_funcs.py:434-449, :471-488)."""
+
+    @staticmethod
+    def forward(ctx, ll2, highs2, highs1, g0o, g1o, g0a, g1a, g0b, g1b, o_dim, ri_dim, mode):
+        int_to_mode(mode)
+        ctx.mode = mode
+        ctx.save_for_backward(g0o, g1o, g0a, g1a, g0b, g1b)
+        ctx.dims = (o_dim, ri_dim)
+        h2 = from_layout(highs2, o_dim, ri_dim)
+        h1 = from_layout(highs1, o_dim, ri_dim)
+        y = ops.dtcwt_inv21(ll2, h2, h1, g0o, g1o, g0a, g0b, g1a, g1b, mode)
+        if y is None:
+            y = ops.dtcwt_inv1(ops.dtcwt_inv2(ll2, h2, g0a, g0b, g1a, g1b), h1, g0o, g1o, mode)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        g0o, g1o, g0a, g1a, g0b, g1b = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dl2 = dh2 = dh1 = None
+        if need[0] or need[1] or need[2]:
+            need_2 = need[0] or need[1]
+            dl1, dh1 = ops.dtcwt_fwd1(dy, g0o, g1o, ctx.mode, skip_hps=not need[2])
+            dh1 = to_layout(dh1, *ctx.dims) if need[2] else None
+            if need_2:
+                # swapped trees, as in INV_J2PLUS.backward
+                dl2, dh2 = ops.dtcwt_fwd2(dl1, g0b, g0a, g1b, g1a, skip_hps=not need[1])
+                dh2 = to_layout(dh2, *ctx.dims) if need[1] else None
+                dl2 = dl2 if need[0] else None
+        return (dl2, dh2, dh1) + (None,) * 9
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -723,6 +723,39 @@ def dtcwt_inv2(ll, highs, g0a, g0b, g1a, g1b):
     return y
 
 
+def dtcwt_inv21(ll2, highs2, highs1, g0o, g1o, g0a, g0b, g1a, g1b, mode, force=False):
+    """Levels 2 and 1 of the inverse in one launch (wl_dtcwt_inv_level21: the level-1 lowpass stays on chip):
+    ll2 (N,C,h,w) [may be a strided crop], highs2 (N,C,6,h/2,w/2,2), highs1 (N,C,6,h,w,2) -> y (N,C,2h,2w), or None when the
+    engine declines (callers chain dtcwt_inv2 / dtcwt_inv1)."""
+    _check_tensor(ll2, 'll2')
+    if highs2 is None or highs1 is None or highs1.dim() != 6 or highs2.dim() != 6:
+        return None
+    N, C, h, w = ll2.shape
+    if (mode != 1 or h % 2 or w % 2 or ll2.dtype not in (torch.float32, torch.float16) or highs1.dtype != ll2.dtype
+            or highs2.dtype != ll2.dtype or tuple(highs2.shape) != (N, C, 6, h // 2, w // 2, 2)
+            or tuple(highs1.shape) != (N, C, 6, h, w, 2) or ll2.numel() == 0):
+        return None
+    force = force or STREAM_FORCE
+    key = ('dti21', ll2.dtype, N * C, h, w, g0o.numel(), g1o.numel(), g0a.numel(), ll2.device.index)
+    if not force and key in _FUSED_DECLINED:
+        return None
+    _same_device(ll2, highs2, highs1)
+    ll2, ps, rs = _planes(ll2)
+    highs2, highs1 = highs2.contiguous(), highs1.contiguous()
+    t0, t1 = _taps(g0o, ll2), _taps(g1o, ll2)
+    ta, tb, tc, td = (_taps(g, ll2) for g in (g0a, g0b, g1a, g1b))
+    y = torch.empty((N, C, 2 * h, 2 * w), dtype=ll2.dtype, device=ll2.device)
+    rc = _call('wl_dtcwt_inv_level21', ll2, ll2.data_ptr(), ps, rs, highs2.data_ptr(), highs1.data_ptr(), y.data_ptr(),
+               _DTYPES[ll2.dtype], N * C, 2 * h, 2 * w, t0.data_ptr(), t0.numel(), t1.data_ptr(), t1.numel(), ta.data_ptr(),
+               tb.data_ptr(), tc.data_ptr(), td.data_ptr(), ta.numel(), mode, 1 if force else 0, _stream(ll2))
+    if rc == -3:   # WL_ERR_UNSUPPORTED
+        if not force:
+            _remember_decline(key)
+        return None
+    _lib.check(rc, 'wl_dtcwt_inv_level21')
+    return y
+
+
 def scat_fwd1(x, h0, h1, mode, magbias, combine_colour, save, want_ll=False):
     """ScatLayer forward: x (N,C,H,W) -> Z (N,7,C,He/2,We/2) [(N,9,..) when combining colour] and, if
     `save`, (re/r, im/r) of shape (N,6,C,He/2,We/2); with `want_ll` also the full-resolution level-1 lowpass

@@ -1,5 +1,6 @@
 """CPU tests: DTCWT / ScatLayer modules and autograd Functions on the host emulation of the kernels,
 against the reference's golden vectors (float64 arithmetic)."""
+import numpy as np
 import pytest
 
 import _opts
@@ -371,7 +372,7 @@ def test_streaming_level2_forward_equals_tile_kernel(shape, dtype):
 
 def test_kernel_history_names_every_launch_of_a_transform():
     """wl_launch_count / wl_kernel_history (pw.kernels_since): a J=3 forward on wide planes is the fused level 1+2 launch and
-    one level-3 launch; the inverse three launches, coarsest level first."""
+    one level-3 launch; the inverse two launches, coarsest level first: level 3, then the fused levels 2 + 1."""
     x = torch.randn(2, 1, 64, 1024, dtype=torch.float32)
     with emu_backend.emulated():
         xfm, ifm = pw.DTCWTForward(J=3), pw.DTCWTInverse()
@@ -382,7 +383,7 @@ def test_kernel_history_names_every_launch_of_a_transform():
         ifm((yl, yh))
         inv = pw.kernels_since(c1)
     assert c1 - c0 == 2 and len(fwd) == 2 and 'WlDtFwd12Strip' in fwd[0] and 'WlDtFwd' in fwd[1], fwd
-    assert len(inv) == 3 and 'Inv2' in inv[0] and 'Inv2' in inv[1] and 'Inv1' in inv[2], inv
+    assert len(inv) == 2 and 'Inv2' in inv[0] and 'WlDtInv21Strip' in inv[1], inv
 
 
 def test_filter_buffers_changed_after_construction_dtcwt_forward():
@@ -390,3 +391,67 @@ def test_filter_buffers_changed_after_construction_dtcwt_forward():
     import _mutation_cases as M
     with emu_backend.emulated():
         M.check_dtcwt_forward_mutations('cpu')
+
+
+@pytest.mark.parametrize('shape,dtype', [((2, 1, 64, 256), torch.float32), ((1, 2, 128, 512), torch.float32),
+                                         ((1, 1, 96, 1024), torch.float32), ((1, 1, 36, 1160), torch.float32),
+                                         ((1, 3, 320, 64), torch.float32), ((1, 2, 64, 256), torch.float16)])
+def test_fused_inverse_levels_2_and_1(shape, dtype):
+    """Levels 2 + 1 of the inverse in one launch (csrc/wl_dtcwt_inv_fused.h: the level-1 lowpass in an LDS ring, four roles on a
+    phase schedule) against the ORACLE: plane edges on all four sides, several strips and row segments, float16, J = 2 and
+    J = 3 pyramids, and the gradient of the fused forward (which runs the fused inverse with the forward taps)."""
+    from oracle import wavelet_oracle as wo
+    from pytorch_wavelets_amd import filters as F, ops
+    rng = np.random.RandomState(5)
+    N, C, H, W = shape
+    for J in (2, 3):
+        x = rng.randn(N, C, H, W)
+        hb, gb = F.dtcwt_forward_taps('near_sym_a', 'qshift_a'), F.dtcwt_inverse_taps('near_sym_a', 'qshift_a')
+        oyl, oyh = wo.dtcwt_forward(x, J, *hb)
+        yl = torch.tensor(oyl, dtype=dtype)
+        yh = [torch.tensor(v, dtype=dtype) for v in oyh]
+        want = wo.dtcwt_inverse(yl.double().numpy(), [v.double().numpy() for v in yh], *gb)
+        prev = ops.STREAM_FORCE
+        ops.STREAM_FORCE = True
+        try:
+            with emu_backend.emulated():
+                ifm = pw.DTCWTInverse(biort='near_sym_a', qshift='qshift_a').to(dtype)
+                c0 = pw.launch_count()
+                rec = ifm((yl, yh))
+                ks = pw.kernels_since(c0)
+                assert any('WlDtInv21Strip' in k for k in ks) and len(ks) == J - 1, ks
+        finally:
+            ops.STREAM_FORCE = prev
+        tol = 4e-3 if dtype == torch.float16 else 3e-6
+        assert rec.shape == want.shape
+        assert float(np.abs(rec.double().numpy() - want).max()) <= tol * float(np.abs(want).max()), (J, shape)
+
+
+def test_fused_inverse_as_the_backward_of_the_fused_forward():
+    """FWD_J12.backward = inverse levels 2 + 1 with the forward taps (trees swapped): on the fused inverse kernel, against the
+    per-level backward."""
+    from pytorch_wavelets_amd import ops
+    torch.manual_seed(1)
+    x = torch.randn(1, 2, 64, 256, dtype=torch.float32)
+    h = emu_backend.handle()
+    prev = ops.STREAM_FORCE
+    ops.STREAM_FORCE = True
+    try:
+        with emu_backend.emulated():
+            xfm = pw.DTCWTForward(J=2).float()
+            xa = x.clone().requires_grad_(True)
+            yl, yh = xfm(xa)
+            w = [torch.randn_like(yl), torch.randn_like(yh[0]), torch.randn_like(yh[1])]
+            c0 = pw.launch_count()
+            ((yl * w[0]).sum() + (yh[0] * w[1]).sum() + (yh[1] * w[2]).sum()).backward()
+            assert any('WlDtInv21Strip' in k for k in pw.kernels_since(c0)), pw.kernels_since(c0)
+            h.wl_set_option(b'no_stream', 1)
+            try:
+                xb = x.clone().requires_grad_(True)
+                yl2, yh2 = xfm(xb)
+                ((yl2 * w[0]).sum() + (yh2[0] * w[1]).sum() + (yh2[1] * w[2]).sum()).backward()
+            finally:
+                h.wl_set_option(b'no_stream', 0)
+    finally:
+        ops.STREAM_FORCE = prev
+    assert float((xa.grad - xb.grad).abs().max()) <= 3e-6 * float(xb.grad.abs().max())

@@ -340,3 +340,67 @@ def test_filter_buffers_changed_after_construction_dtcwt_forward_gpu():
     import _mutation_cases as M
     M.check_dtcwt_forward_mutations(DEV)
     M.check_dtcwt_forward_mutations(DEV, shape=(64, 3, 512, 512))     # config 3's shape: the engine's own policy picks the fused launch
+
+
+@pytest.mark.parametrize('shape,J,dtype', [((64, 3, 512, 512), 3, torch.float32), ((20, 3, 264, 1024), 2, torch.float32),
+                                           ((96, 1, 256, 1160), 2, torch.float32), ((64, 3, 256, 256), 3, torch.float32),
+                                           ((160, 1, 128, 512), 2, torch.float16)])
+def test_fused_inverse_levels_2_and_1_gpu(shape, J, dtype):
+    """Levels 2 + 1 of the inverse in one launch (WlDtInv21Strip: the level-1 lowpass in an LDS ring) at config 3's shape and
+    around it: against the per-level kernels (wl_set_option no_stream -> tile kernels) on every plane, against the ORACLE on
+    sampled planes, and as the backward of the fused forward."""
+    from pytorch_wavelets_amd import _lib
+    torch.manual_seed(2)
+    x = torch.randn(*shape, device=DEV).to(dtype)
+    xfm = pw.DTCWTForward(J=J).to(DEV).to(dtype)
+    ifm = pw.DTCWTInverse().to(DEV).to(dtype)
+    yl, yh = xfm(x)
+    yl, yh = yl + 0.1 * torch.randn_like(yl), [v + 0.1 * torch.randn_like(v) for v in yh]
+    lib = _lib.get()
+    out = {}
+    try:
+        for ns in (0, 1):
+            lib.wl_set_option(b'no_stream', ns)
+            c0 = pw.launch_count()
+            out[ns] = [ifm((yl, yh))]
+            ks = pw.kernels_since(c0)
+            if ns == 0:
+                assert len(ks) == J - 1 and 'WlDtInv21Strip' in ks[-1], ks
+            else:
+                assert len(ks) == J and not any('WlDtInv21Strip' in k for k in ks), ks
+            if dtype == torch.float32:
+                xg = x.clone().requires_grad_(True)
+                a, b = xfm(xg)
+                c0 = pw.launch_count()
+                ((a * yl).sum() + sum((u * v).sum() for u, v in zip(b, yh))).backward()
+                if ns == 0 and shape[2] % 4 == 0 and shape[3] % 4 == 0:
+                    assert any('WlDtInv21Strip' in k for k in pw.kernels_since(c0)), pw.kernels_since(c0)
+                out[ns].append(xg.grad.clone())
+    finally:
+        lib.wl_set_option(b'no_stream', 0)
+    tol = 5e-3 if dtype == torch.float16 else 5e-6
+    for u, v in zip(out[0], out[1]):
+        assert float((u.float() - v.float()).abs().max()) <= tol * float(v.float().abs().max())
+    gb = F.dtcwt_inverse_taps('near_sym_a', 'qshift_a')
+    for n, c in ((0, 0), (shape[0] - 1, shape[1] - 1), (shape[0] // 2, 0)):
+        ref = wo.dtcwt_inverse(yl[n:n + 1, c:c + 1].double().cpu().numpy(), [v[n:n + 1, c:c + 1].double().cpu().numpy() for v in yh], *gb)
+        got = out[0][0][n:n + 1, c:c + 1].double().cpu().numpy()
+        assert np.abs(got - ref).max() <= (5e-3 if dtype == torch.float16 else 1e-5) * np.abs(ref).max()
+
+
+def test_golden_through_the_forced_fused_inverse(monkeypatch):
+    """The reference's own goldens (reconstruction and the gradients of the inverse) with levels 2 + 1 forced onto the fused
+    inverse kernel, whatever the engine's policy says about so small a plane."""
+    from pytorch_wavelets_amd import ops
+    took = []
+    orig = ops.dtcwt_inv21
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        took.append(r is not None)
+        return r
+    monkeypatch.setattr(ops, 'STREAM_FORCE', True)
+    monkeypatch.setattr(ops, 'dtcwt_inv21', spy)
+    D.check_dtcwt_case('dtcwt_00', DEV, torch.float32, TOL)
+    D.check_dtcwt_case('dtcwt_01', DEV, torch.float32, TOL)
+    assert took and any(took)
