@@ -5,19 +5,20 @@
 // PMC traffic 1.57x the algorithmic bytes of a J = 3 inverse in round 3); here it lives in an LDS ring of 16 rows.
 //
 // A workgroup (15 waves, one per CU) owns one (plane, strip of level-1 quad columns, segment of output rows) and marches
-// down it once in PHASES (one workgroup barrier each; a phase = one level-1 quad row = two output rows):
+// down it once in PHASES (one workgroup barrier each; a phase = one GROUP of four output rows = one level-2 quad row = two
+// level-1 quad rows: the first version had one level-1 quad row per phase and spent twice the barriers and LDS round trips):
 //   * 3 level-2 STAGER waves (WlDtInv2Strip's): every lane owns one input quad of the level-2 quad row (ll2 2 x 2, six
-//     (re, im) pairs: 8-byte loads one half-batch ahead in registers), c2q, band-pair cells (+ mirrored / flipped copies at
-//     the plane's edges) - one level-2 quad row every TWO phases (it yields four rows of the level-1 lowpass);
+//     (re, im) pairs: 8-byte loads PF2 phases ahead in registers), c2q, band-pair cells (+ mirrored / flipped copies at
+//     the plane's edges);
 //   * 4 level-2 COMPUTE waves (WlDtInv2Strip's lanes: two of the four output columns of an input quad column, row
-//     interpolation into register windows in the phase after the staging, column interpolation in the phase after that):
-//     the four rows x two columns of the level-1 lowpass go into the LL1 RING (4 groups of 4 rows) instead of memory;
-//   * 4 level-1 STAGER waves (WlDtInv1Strip's): every lane owns one level-1 quad: its six (re, im) pairs from memory one
-//     phase ahead in registers, its 2 x 2 lowpass pixels from the LL1 ring (rows above / below the plane are the ring's
-//     rows flipped, columns left / right of it mirrored cells: symmetric extension of the reconstruction, exact for any
-//     taps), c2q, (ll, lh, hl, hh) 16-byte cells;
+//     interpolation into register windows, column interpolation D2 quad rows later) in the phase after the staging: the four
+//     rows x two columns of the level-1 lowpass go into the LL1 RING (NG groups of 4 rows) instead of memory;
+//   * 4 level-1 STAGER waves (WlDtInv1Strip's): every lane owns one level-1 quad COLUMN: the six (re, im) pairs of its two
+//     quads of the phase from memory PF1 phases ahead in registers, their 4 x 2 lowpass pixels from the LL1 ring (rows above /
+//     below the plane are the ring's rows flipped, columns left / right of it mirrored cells: symmetric extension of the
+//     reconstruction, exact for any taps), c2q, (ll, lh, hl, hh) 16-byte cells;
 //   * 4 level-1 COMPUTE waves (WlDtInv1Strip's lanes): the two columns of a quad column, row filter into register
-//     windows, column filter M rows later, 8-byte stores of y.
+//     windows, column filter M rows later, 8-byte stores of y - four rows per phase.
 // The level-1 stagers run P1 phases behind the level-2 stagers (the launcher simulates every segment: a ring group must have
 // been written a phase before it is read and must not be overwritten before its last read); waves of one role sit on
 // the four SIMDs of the CU (wave index mod 4), so every SIMD carries one wave of each role.
@@ -42,8 +43,8 @@ struct WlDtInv21Args {
     int H, W;
     int nstrips, strip_quads;      // level-1 quad columns per strip (even); the last strip may be narrower
     int nseg, seg_rows;            // output rows per segment (a multiple of 4)
-    int P1;                        // phase of the level-1 stagers' first quad row
-    int st1_off, st1_pitch;        // level-1 staged ring: 2 slots x 2 rows
+    int P1;                        // phase of the level-1 stagers' first group
+    int st1_off, st1_pitch;        // level-1 staged ring: 2 slots x 4 rows
     int st2_off, st2_pitch;        // level-2 staged ring: 2 slots x 2 rows
     int l1_off, l1_pitch;          // LL1 ring: 4 * NG rows of float32
     int lds_bytes;
@@ -59,9 +60,26 @@ struct WlDtInv21Strip {
     static const int kThreads = 64 * kWaves;
     static const int kMinWaves = 4;                    // one workgroup per CU: up to 128 registers
     static const int SZ = (int)sizeof(T);
-    static const int M = K1::M, ME = K1::ME, LW = K1::LW, PERIOD = K1::PERIOD, NPX = K1::NPX;
+    static const int M = K1::M, ME = K1::ME, LW = K1::LW, NPX = K1::NPX;
+    static_assert(ME == 4 && LW % 4 == 0, "level-1 pairs with M = 3 (7 / 5 taps): a segment starts one whole group above its rows");
+    static const int PERIOD = LW / 4;                  // phases per rotation of the level-1 windows (4 rows per phase)
     static const int m2 = K2::m2, D2 = K2::D2;
-    static const int NG = 4;                           // groups (of 4 rows) of the LL1 ring
+#ifndef WL_DTI21_KO
+#define WL_DTI21_KO 0      // knock-out experiments (tools/build_ab_dtinv.sh): bits switch parts of the work off - wrong results
+#endif
+    static const int KO = WL_DTI21_KO;
+#ifndef WL_DTI21_NG
+#define WL_DTI21_NG 4
+#endif
+#ifndef WL_DTI21_PF1
+#define WL_DTI21_PF1 2
+#endif
+#ifndef WL_DTI21_PF2
+#define WL_DTI21_PF2 3
+#endif
+    static const int NG = WL_DTI21_NG;                 // groups (of 4 rows) of the LL1 ring
+    // register sets of the stagers = how many phases ahead their loads run
+    static const int PF1 = WL_DTI21_PF1, PF2 = WL_DTI21_PF2;
 
     struct Geo {
         // level 1 (WlDtInv1Strip::Strip)
@@ -69,13 +87,13 @@ struct WlDtInv21Strip {
         int e_lo, px0;         // first extended pixel column a lane reads; pixel column of staged cell 0 (even)
         int Qa, nq;            // level-1 quads [Qa, Qa + nq) are staged, one per stager lane
         int r_lo, r_hi;        // output rows
-        int eq1_first, n1;     // first extended quad row, quad rows (= phases of level-1 work; even)
+        int ge_first, n1;      // first extended group (of four rows; -1 above the plane), groups = phases of level-1 work
         // level 2
         int ka, kb;            // level-2 quad columns [ka, kb] whose four output columns the strip reads (inside the plane)
         int c0;                // quad column of level-2 staged cell 0 = ka - D2
         int Qa2, nq2;          // level-2 input quads [Qa2, Qa2 + nq2) are loaded, one per stager lane
-        int G_lo, G_hi;        // LL1 groups (of four rows) the segment reads
-        int n2;                // level-2 half-batches
+        int G_lo, G_hi;        // LL1 groups the segment reads
+        int n2;                // level-2 half-batches (one per phase)
         int NP;                // phases (= barriers) of the workgroup
     };
     static WL_HD int src_quad_row(int eq, int nq, bool& flip) {
@@ -85,9 +103,13 @@ struct WlDtInv21Strip {
         const int m = eq < 0 ? -1 - eq : 2 * nq - 1 - eq;
         return m < 0 ? 0 : (m >= nq ? nq - 1 : m);
     }
+    // LL1 group an extended group of four rows reads (both of its quad rows mirror into the same group)
+    static WL_HD int group_of(int ge, int HG) { bool f; return src_quad_row(ge, HG, f); }
+    // level-1 phases that produce rows of the segment: extended rows [r_lo - ME, r_hi + M) in groups of four
+    static WL_HD int real_n1(int r_lo, int r_hi) { return (r_hi + M - (r_lo - ME) + 3) / 4; }
     static WL_HD Geo geometry(const Args& a, int strip, int seg) {
         Geo s;
-        const int W1q = a.W / 2, H1q = a.H / 2, W2q = a.W / 4;
+        const int W1q = a.W / 2, HG = a.H / 4, W2q = a.W / 4;
         s.q0 = strip * a.strip_quads;
         s.q1 = s.q0 + a.strip_quads < W1q ? s.q0 + a.strip_quads : W1q;
         s.e_lo = 2 * s.q0 - M;
@@ -99,8 +121,8 @@ struct WlDtInv21Strip {
         s.Qa = qa; s.nq = qb - qa + 1;
         s.r_lo = seg * a.seg_rows;
         s.r_hi = s.r_lo + a.seg_rows < a.H ? s.r_lo + a.seg_rows : a.H;
-        s.eq1_first = (s.r_lo - ME) / 2;               // (r_lo is a multiple of 4, ME even: exact, may be negative)
-        s.n1 = (((s.r_hi - 1 + M) - (s.r_lo - ME)) / 2 + 1 + 1) / 2 * 2;
+        s.ge_first = s.r_lo / 4 - 1;                   // (r_lo is a multiple of 4, ME = 4)
+        s.n1 = (real_n1(s.r_lo, s.r_hi) + PF1 - 1) / PF1 * PF1;   // (a multiple of the stagers' register sets)
         // level 2: the in-plane LL1 columns [2 Qa, 2 (Qa + nq)) in groups of four
         s.ka = (2 * s.Qa) / 4;
         s.kb = (2 * (s.Qa + s.nq) - 1) / 4;
@@ -108,21 +130,19 @@ struct WlDtInv21Strip {
         int qa2 = s.c0 < 0 ? 0 : s.c0, qb2 = s.kb + D2;
         if (qb2 > W2q - 1) qb2 = W2q - 1;
         s.Qa2 = qa2; s.nq2 = qb2 - qa2 + 1;
-        // LL1 groups: the source quad rows of extended quad rows [eq1_first, eq1_first + n1) (mirrored at the plane's edges)
-        const int eq_last = s.eq1_first + s.n1 - 1;
-        const int lo = s.eq1_first < 0 ? 0 : s.eq1_first, hi = eq_last > H1q - 1 ? H1q - 1 : eq_last;
-        s.G_lo = lo / 2; s.G_hi = hi / 2;
+        // LL1 groups: the sources of extended groups [ge_first, ge_first + n1) (mirrored at the plane's edges)
+        const int ge_last = s.ge_first + s.n1 - 1;
+        s.G_lo = s.ge_first < 0 ? 0 : s.ge_first;
+        s.G_hi = ge_last > HG - 1 ? HG - 1 : ge_last;
         s.n2 = s.G_hi - s.G_lo + 1 + 2 * D2;
-        const int np1 = a.P1 + s.n1 + 1, np2 = 2 * s.n2 + 1;
+        const int np1 = a.P1 + s.n1 + 1, np2 = s.n2 + 1;
         s.NP = np1 > np2 ? np1 : np2;
         return s;
     }
-    // LL1 group an extended level-1 quad row reads
-    static WL_HD int group_of(int eq1, int H1q) { bool f; return src_quad_row(eq1, H1q, f) / 2; }
 
     typedef T Pair2 __attribute__((ext_vector_type(2), may_alias));
 
-    // ---- level-2 stager wave (WlDtInv2Strip::stager on the phase schedule) ------------------------------------------
+    // ---- level-2 stager wave (WlDtInv2Strip::stager on the phase schedule): phase j stages half-batch j ---------------------
     struct Quad2 { Pair2 l0, l1, b[6]; };
     static WL_DEV void stager2(const Args& a, const Geo& s, const WlCtx& ctx, int64_t plane, int lane, int sidx) {
         const int H2q = a.H / 4, W2q = a.W / 4;
@@ -155,6 +175,9 @@ struct WlDtInv21Strip {
             src_quad_row(eq0 + hb, H2q, flip);
             char* sslot = ctx.smem + a.st2_off + (hb & 1) * 2 * a.st2_pitch;
             if (!qon) return;
+#if defined(__HIPCC__)
+            if (KO & 8) { asm volatile("" :: "v"(qd.l0), "v"(qd.l1), "v"(qd.b[0]), "v"(qd.b[1]), "v"(qd.b[2]), "v"(qd.b[3]), "v"(qd.b[4]), "v"(qd.b[5])); return; }
+#endif
             float re[6], im[6];
 #pragma unroll
             for (int o = 0; o < 6; ++o) { re[o] = (float)qd.b[o].x; im[o] = (float)qd.b[o].y; }
@@ -184,25 +207,25 @@ struct WlDtInv21Strip {
                 }
             }
         };
-        // phase 2 j: stage half-batch j; phase 2 j + 1: nothing (its loads are in flight: two register sets)
-        const int n2e = (s.n2 + 1) / 2 * 2;
-        Quad2 qa, qb;
-        load(0, qa);
+        // PF2 register sets: the loads of half-batch j + PF2 go out right behind the staging of j (no load sits inside a
+        // branch: the compiler counts them and waits for the oldest set)
+        const int n2e = (s.n2 + PF2 - 1) / PF2 * PF2;
+        Quad2 qq[PF2];
+#pragma unroll
+        for (int u = 0; u < PF2; ++u) load(u < s.n2 ? u : s.n2 - 1, qq[u]);
         int done = 0;
-        for (int hb = 0; hb < n2e; hb += 2) {
-            load(hb + 1 < s.n2 ? hb + 1 : s.n2 - 1, qb);
-            if (hb < s.n2) stage(hb, qa);
-            if (done < s.NP) { ctx.sync(); ++done; }
-            if (done < s.NP) { ctx.sync(); ++done; }
-            load(hb + 2 < s.n2 ? hb + 2 : s.n2 - 1, qa);
-            if (hb + 1 < s.n2) stage(hb + 1, qb);
-            if (done < s.NP) { ctx.sync(); ++done; }
-            if (done < s.NP) { ctx.sync(); ++done; }
+        for (int hb = 0; hb < n2e; hb += PF2) {
+#pragma unroll
+            for (int u = 0; u < PF2; ++u) {
+                if (hb + u < s.n2) stage(hb + u, qq[u]);
+                load(hb + u + PF2 < s.n2 ? hb + u + PF2 : s.n2 - 1, qq[u]);
+                if (done < s.NP) { ctx.sync(); ++done; }
+            }
         }
         for (; done < s.NP; ++done) ctx.sync();
     }
 
-    // ---- level-2 compute wave: WlDtInv2Strip::compute, the output rows into the LL1 ring ---------------------------------
+    // ---- level-2 compute wave: WlDtInv2Strip::compute, the output rows into the LL1 ring; phase j + 1 works on half-batch j --
     static WL_DEV void compute2(const Args& a, const Geo& s, const WlCtx& ctx, int cw, int lane) {
         const int ph_c = cw >> 1;                              // column phase: 0 -> columns 4q, 4q+1 (e = 1); 1 -> 4q+2, 4q+3 (e = 0)
         const int q = s.ka + 64 * (cw & 1) + lane;
@@ -230,8 +253,8 @@ struct WlDtInv21Strip {
             for (int ph = 0; ph < m2; ++ph) {
                 const int hb = hb0 + ph;
                 if (hb >= s.n2) break;
-                // phase 2 hb + 1: row interpolation of both rows of the quad row
-                if (active) {
+                if (active && !(KO & 4)) {
+                    // row interpolation of both rows of the quad row
                     const char* slot = smem + a.st2_off + (hb & 1) * 2 * a.st2_pitch + soff;
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
@@ -250,25 +273,24 @@ struct WlDtInv21Strip {
                         }
                         wA[ph][i] = A; wB[ph][i] = B;
                     }
-                }
-                ctx.sync(); ++done;
-                // phase 2 hb + 2: column interpolation of the group kr = G_lo - 2 D2 + hb -> LL1 ring
-                const int kr = s.G_lo - 2 * D2 + hb;
-                if (active && kr >= s.G_lo && kr <= s.G_hi) {
-                    wl_v2 y0 = {0.f, 0.f}, y1 = {0.f, 0.f}, y2 = {0.f, 0.f}, y3 = {0.f, 0.f};
+                    // column interpolation of the group kr = G_lo - 2 D2 + hb -> LL1 ring
+                    const int kr = s.G_lo - 2 * D2 + hb;
+                    if (kr >= s.G_lo && kr <= s.G_hi) {
+                        wl_v2 y0 = {0.f, 0.f}, y1 = {0.f, 0.f}, y2 = {0.f, 0.f}, y3 = {0.f, 0.f};
 #pragma unroll
-                    for (int t = 0; t < m2; ++t) {
-                        const int sl = (ph + 1 + t) % m2;
-                        K2::template fma_cc<0>(y0, wA[sl][0], PL[1][t]); K2::template fma_cc<0>(y0, wB[sl][1], PH[1][t]);
-                        K2::template fma_cc<1>(y1, wA[sl][1], PL[1][t]); K2::template fma_cc<1>(y1, wB[sl][0], PH[1][t]);
-                        K2::template fma_cc<0>(y2, wA[sl][0], PL[0][t]); K2::template fma_cc<0>(y2, wB[sl][1], PH[0][t]);
-                        K2::template fma_cc<1>(y3, wA[sl][1], PL[0][t]); K2::template fma_cc<1>(y3, wB[sl][0], PH[0][t]);
+                        for (int t = 0; t < m2; ++t) {
+                            const int sl = (ph + 1 + t) % m2;
+                            K2::template fma_cc<0>(y0, wA[sl][0], PL[1][t]); K2::template fma_cc<0>(y0, wB[sl][1], PH[1][t]);
+                            K2::template fma_cc<1>(y1, wA[sl][1], PL[1][t]); K2::template fma_cc<1>(y1, wB[sl][0], PH[1][t]);
+                            K2::template fma_cc<0>(y2, wA[sl][0], PL[0][t]); K2::template fma_cc<0>(y2, wB[sl][1], PH[0][t]);
+                            K2::template fma_cc<1>(y3, wA[sl][1], PL[0][t]); K2::template fma_cc<1>(y3, wB[sl][0], PH[0][t]);
+                        }
+                        char* const rp = smem + a.l1_off + (4 * (kr % NG)) * a.l1_pitch + loff;
+                        *reinterpret_cast<wl_f2*>(rp) = wl_f2{y0.x, y0.y};
+                        *reinterpret_cast<wl_f2*>(rp + a.l1_pitch) = wl_f2{y1.x, y1.y};
+                        *reinterpret_cast<wl_f2*>(rp + 2 * a.l1_pitch) = wl_f2{y2.x, y2.y};
+                        *reinterpret_cast<wl_f2*>(rp + 3 * a.l1_pitch) = wl_f2{y3.x, y3.y};
                     }
-                    char* const rp = smem + a.l1_off + (4 * (kr & (NG - 1))) * a.l1_pitch + loff;
-                    *reinterpret_cast<wl_f2*>(rp) = wl_f2{y0.x, y0.y};
-                    *reinterpret_cast<wl_f2*>(rp + a.l1_pitch) = wl_f2{y1.x, y1.y};
-                    *reinterpret_cast<wl_f2*>(rp + 2 * a.l1_pitch) = wl_f2{y2.x, y2.y};
-                    *reinterpret_cast<wl_f2*>(rp + 3 * a.l1_pitch) = wl_f2{y3.x, y3.y};
                 }
                 ctx.sync(); ++done;
             }
@@ -276,8 +298,8 @@ struct WlDtInv21Strip {
         for (; done < s.NP; ++done) ctx.sync();
     }
 
-    // ---- level-1 stager wave: WlDtInv1Strip::stager, the lowpass pixels from the LL1 ring --------------------------------
-    struct Quad1 { Pair2 b[6]; };
+    // ---- level-1 stager wave: WlDtInv1Strip::stager, two quad rows per phase, the lowpass pixels from the LL1 ring ----------
+    struct Quad1 { Pair2 b[2][6]; };
     static WL_DEV void stager1(const Args& a, const Geo& s, const WlCtx& ctx, int64_t plane, int lane, int sidx) {
         const int H1q = a.H / 2, W1q = a.W / 2;
         const size_t qplane = (size_t)H1q * W1q;
@@ -302,64 +324,79 @@ struct WlDtInv21Strip {
             mdst[c] = e == -1000000 ? -1 : (mc & 1) * hp1 + (mc >> 1) * 16;
         }
         const int lcol = (2 * Q - 4 * s.ka) * 4;                 // my two lowpass columns in an LL1 ring row
+        const int eq_first = 2 * s.ge_first;
         auto load = [&](int h, Quad1& qd) {
-            bool flip;
-            const int sq = src_quad_row(s.eq1_first + h, H1q, flip);
             if (!qon) return;
 #pragma unroll
-            for (int o = 0; o < 6; ++o) qd.b[o] = *reinterpret_cast<const Pair2*>(hp + ((size_t)o * qplane + (size_t)sq * W1q) * 2);
-        };
-        const float k = (float)WL_SQRT1_2;
-        auto stage = [&](int hb, const Quad1& qd) {
-            bool flip;
-            const int sq = src_quad_row(s.eq1_first + hb, H1q, flip);
-            char* sslot = ctx.smem + a.st1_off + (hb & 1) * 2 * a.st1_pitch;
-            if (!qon) return;
-            const char* lrow = ctx.smem + a.l1_off + ((2 * sq) & (4 * NG - 1)) * a.l1_pitch + lcol;
-            const wl_f2 l0 = *reinterpret_cast<const wl_f2*>(lrow);
-            const wl_f2 l1 = *reinterpret_cast<const wl_f2*>(lrow + a.l1_pitch);
-            float re[6], im[6];
+            for (int r = 0; r < 2; ++r) {
+                bool flip;
+                const int sq = src_quad_row(eq_first + 2 * h + r, H1q, flip);
+                if (KO & 32) {
 #pragma unroll
-            for (int o = 0; o < 6; ++o) { re[o] = (float)qd.b[o].x; im[o] = (float)qd.b[o].y; }
-            // c2q: orientation pairs (0,5) -> lh, (2,3) -> hl, (1,4) -> hh;  v[row][col][ll, lh, hl, hh]
-            float v[2][2][4];
+                    for (int o = 0; o < 6; ++o) qd.b[r][o] = Pair2{(T)0.f, (T)0.f};
+                } else {
 #pragma unroll
-            for (int ch = 1; ch < 4; ++ch) {
-                const int o1 = ch == 1 ? 0 : (ch == 2 ? 2 : 1), o2 = ch == 1 ? 5 : (ch == 2 ? 3 : 4);
-                v[0][0][ch] = (re[o1] + re[o2]) * k; v[0][1][ch] = (im[o1] + im[o2]) * k;
-                v[1][0][ch] = (im[o1] - im[o2]) * k; v[1][1][ch] = (re[o2] - re[o1]) * k;
-            }
-            v[0][0][0] = l0.x; v[0][1][0] = l0.y; v[1][0][0] = l1.x; v[1][1][0] = l1.y;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                char* drow = sslot + (flip ? 1 - i : i) * a.st1_pitch;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    wl_vf4 w;
-                    w.x = v[i][c][0]; w.y = v[i][c][1]; w.z = v[i][c][2]; w.w = v[i][c][3];
-                    *reinterpret_cast<wl_vf4*>(drow + cdst[c]) = w;
-                    if (mdst[c] >= 0) *reinterpret_cast<wl_vf4*>(drow + mdst[c]) = w;
+                    for (int o = 0; o < 6; ++o) qd.b[r][o] = *reinterpret_cast<const Pair2*>(hp + ((size_t)o * qplane + (size_t)sq * W1q) * 2);
                 }
             }
         };
-        // phase P1 + h: stage quad row h (band-pass pairs loaded two phases earlier: two register sets)
-        Quad1 qq[2];
-        load(0, qq[0]);
-        load(1, qq[1]);
+        const float k = (float)WL_SQRT1_2;
+        auto stage = [&](int hb, const Quad1& qd) {
+            char* sslot = ctx.smem + a.st1_off + (hb & 1) * 4 * a.st1_pitch;
+            if (!qon) return;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+#if defined(__HIPCC__)
+                if (KO & 2) { asm volatile("" :: "v"(qd.b[r][0]), "v"(qd.b[r][1]), "v"(qd.b[r][2]), "v"(qd.b[r][3]), "v"(qd.b[r][4]), "v"(qd.b[r][5])); continue; }
+#endif
+                bool flip;
+                const int sq = src_quad_row(eq_first + 2 * hb + r, H1q, flip);
+                const char* lrow = ctx.smem + a.l1_off + ((2 * sq) % (4 * NG)) * a.l1_pitch + lcol;
+                const wl_f2 l0 = *reinterpret_cast<const wl_f2*>(lrow);
+                const wl_f2 l1 = *reinterpret_cast<const wl_f2*>(lrow + a.l1_pitch);
+                float re[6], im[6];
+#pragma unroll
+                for (int o = 0; o < 6; ++o) { re[o] = (float)qd.b[r][o].x; im[o] = (float)qd.b[r][o].y; }
+                // c2q: orientation pairs (0,5) -> lh, (2,3) -> hl, (1,4) -> hh;  v[row][col][ll, lh, hl, hh]
+                float v[2][2][4];
+#pragma unroll
+                for (int ch = 1; ch < 4; ++ch) {
+                    const int o1 = ch == 1 ? 0 : (ch == 2 ? 2 : 1), o2 = ch == 1 ? 5 : (ch == 2 ? 3 : 4);
+                    v[0][0][ch] = (re[o1] + re[o2]) * k; v[0][1][ch] = (im[o1] + im[o2]) * k;
+                    v[1][0][ch] = (im[o1] - im[o2]) * k; v[1][1][ch] = (re[o2] - re[o1]) * k;
+                }
+                v[0][0][0] = l0.x; v[0][1][0] = l0.y; v[1][0][0] = l1.x; v[1][1][0] = l1.y;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    char* drow = sslot + (2 * r + (flip ? 1 - i : i)) * a.st1_pitch;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        wl_vf4 w;
+                        w.x = v[i][c][0]; w.y = v[i][c][1]; w.z = v[i][c][2]; w.w = v[i][c][3];
+                        *reinterpret_cast<wl_vf4*>(drow + cdst[c]) = w;
+                        if (mdst[c] >= 0) *reinterpret_cast<wl_vf4*>(drow + mdst[c]) = w;
+                    }
+                }
+            }
+        };
+        // phase P1 + h: stage group h (band-pass pairs loaded PF1 phases earlier: PF1 register sets)
+        Quad1 qq[PF1];
+#pragma unroll
+        for (int u = 0; u < PF1; ++u) load(u < s.n1 ? u : s.n1 - 1, qq[u]);
         int done = 0;
         for (; done < a.P1; ++done) ctx.sync();
-        for (int hb = 0; hb < s.n1; hb += 2) {                 // (n1 is even)
+        for (int hb = 0; hb < s.n1; hb += PF1) {               // (n1 is a multiple of PF1)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < PF1; ++u) {
                 stage(hb + u, qq[u]);
+                load(hb + u + PF1 < s.n1 ? hb + u + PF1 : s.n1 - 1, qq[u]);
                 ctx.sync(); ++done;
-                load(hb + u + 2 < s.n1 ? hb + u + 2 : s.n1 - 1, qq[u]);
             }
         }
         for (; done < s.NP; ++done) ctx.sync();
     }
 
-    // ---- level-1 compute wave: WlDtInv1Strip::compute on the phase schedule -------------------------------------------
+    // ---- level-1 compute wave: WlDtInv1Strip::compute, four rows per phase -----------------------------------------------
     static WL_DEV void compute1(const Args& a, const Geo& s, const WlCtx& ctx, int64_t plane, int cw, int lane) {
         const int q = s.q0 + 64 * cw + lane;
         const bool active = q < s.q1;
@@ -384,28 +421,28 @@ struct WlDtInv21Strip {
 #pragma unroll
         for (int t = 0; t < LW; ++t) wa[t] = wb[t] = wl_v2{0.f, 0.f};
         char* const smem = ctx.smem;
-        const int e_first = 2 * s.eq1_first;
+        const int e_first = 4 * s.ge_first;
         int done = 0;
-        for (; done <= a.P1; ++done) ctx.sync();               // phases 0 .. P1: the first quad row is staged in phase P1
+        for (; done <= a.P1; ++done) ctx.sync();               // phases 0 .. P1: the first group is staged in phase P1
         for (int hb0 = 0; hb0 < s.n1; hb0 += PERIOD) {
 #pragma unroll
             for (int ph = 0; ph < PERIOD; ++ph) {
                 const int hb = hb0 + ph;
                 if (hb >= s.n1) break;
-                if (active) {
-                    const char* slot = smem + a.st1_off + (hb & 1) * 2 * a.st1_pitch + soff;
+                if (active && !(KO & 1)) {
+                    const char* slot = smem + a.st1_off + (hb & 1) * 4 * a.st1_pitch + soff;
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
+                    for (int i = 0; i < 4; ++i) {
                         wl_vf4 px[NPX];
 #pragma unroll
                         for (int u = 0; u < NPX; ++u)
                             px[u] = *reinterpret_cast<const wl_vf4*>(slot + i * a.st1_pitch + (((M & 1) + u) & 1) * hp1 + (((M & 1) + u) >> 1) * 16);
-                        const int w = (2 * ph + i) % LW;
+                        const int w = (4 * ph + i) % LW;
                         K1::row_filter2(R, px, wa[w], wb[w]);
-                        const int o = e_first + 2 * hb + i - M;
+                        const int o = e_first + 4 * hb + i - M;
                         float ya, yb;
                         K1::col_filter2(R, wa, wb, (w + LW - M) % LW, ya, yb);
-                        if (o >= s.r_lo && o < s.r_hi) {
+                        if (o >= s.r_lo && o < s.r_hi && (!(KO & 16) || ya == 12345.678f)) {
                             typedef T Vec2 __attribute__((ext_vector_type(2)));
                             Vec2 v = {(T)ya, (T)yb};
                             *reinterpret_cast<Vec2*>(yp + (unsigned)o * rowb + colb) = v;
