@@ -209,7 +209,7 @@ int wl_scat_bwd_level1(const void* dz, const void* drdx, const void* drdy, void*
 /* ONE analysis level by the streaming strip kernel (csrc/wl_dwt_strip.h): the same operator as wl_dwt2d_analysis_strided
  * (AFB2D.forward, dwt/lowlevel.py:336-347) for one square filter length L (even, <= 20), float32 / float16, every mode, rows
  * of any width that are a whole number of 16-byte pieces: every input sample is read once per column strip and row
- * segment, by LDS-DMA.  policy 0 = the engine decides whether the launch pays (enough workgroups for the chip), 1 = force.
+ * segment, by LDS-DMA.  policy bit 0: 0 = the engine decides whether the launch pays (enough workgroups for the chip), 1 = force; bit 1 (value 2) = the caller vouches that each highpass bank is the quadrature mirror of its lowpass bank, h_hi[t] == (-1)^t h_lo[L-1-t] (the pair of every orthogonal wavelet as stored): from 12 taps on the kernel then holds the lowpass banks only.
  * Returns WL_ERR_UNSUPPORTED outside its envelope (callers then use wl_dwt2d_analysis_strided). */
 int wl_dwt2d_analysis_stream(const void* x, int64_t x_plane_stride, int x_row_stride, void* ll, int64_t ll_plane_stride,
                              int ll_row_stride, void* highs, int dtype, int64_t planes, int H, int W, const void* h_w_lo,
@@ -237,6 +237,15 @@ int wl_dwt2d_analysis_nonsep_bwd(const void* dy, void* dx, int dtype, int64_t pl
                                  int Ly, int Lx, int mode, void* stream);
 int wl_dwt2d_synthesis_nonsep_bwd(const void* dy, void* dc, int dtype, int64_t planes, int Kh, int Kw, const void* g,
                                   int Ly, int Lx, int mode, void* stream);
+
+/* J (1..4) levels of the 1-D analysis bank in ONE launch (csrc/wl_dwt1d_fused.h) = DWT1DForward.forward's level loop
+ * (dwt/transform1d.py:44-59 -> AFB1D.forward, dwt/lowlevel.py:368-424): x (rows,N) dense -> lo (rows,n_J) and highs[j]
+ * (rows,n_{j+1}), n_{j+1} = wl_dwt_coeff_len(n_j, L, mode); every input sample is read once, the intermediate lowpass signals
+ * stay in LDS.  Even L <= 20, float32 / float16, zero / symmetric / reflect for rows of any length (a workgroup owns a chunk of
+ * ~4096 samples), periodic / periodization while a row fits one chunk.  Returns WL_ERR_UNSUPPORTED outside its envelope:
+ * callers then chain wl_corr1d level by level. */
+int wl_dwt1d_analysis_fused(const void* x, void* lo, void* const* highs, int dtype, int64_t rows, int N, int J,
+                            const void* h0, const void* h1, int L, int mode, void* stream);
 
 /* ---- single-axis building blocks -------------------------------------------------------------------------------
  * One strided / dilated correlation with boundary extension along the middle axis of a dense (outer, n, inner) tensor:

@@ -116,9 +116,16 @@ struct WlStripArgs {
     int pair_ok;                   // every output-column pair of every band row is one aligned 2-element store (even Kw, ll_rs)
 };
 
-template <typename T, int LT>
+// QMF = 1: the caller vouches that each highpass bank is the quadrature mirror of its lowpass bank, hi[t] = (-1)^t lo[L-1-t]
+// (the decomposition pair of every orthogonal wavelet, in the order the reference stores it).  The (lo, hi) tap pair of tap t
+// is then (lo[t], +-lo[L-1-t]): with the lowpass bank held as the L/2 pairs P[u] = (lo[u], lo[L-1-u]) every tap pair is P[u]
+// or P[u] with its halves swapped, the high half negated for odd t - operand modifiers of the packed FMA (op_sel, neg_hi).
+// Half the scalar registers: at 16 taps the two banks of rows and columns were 64 of them and the scalar file overflowed
+// (25-34 spilled scalars, read back through v_readlane in the half-batch loop).
+template <typename T, int LT, int QMF = 0>
 struct WlAfbStrip {
     typedef WlStripArgs<T> Args;
+    static const int NB = QMF ? LT / 2 : LT;           // tap pairs held per bank
     static const int kWaves = WL_STRIP_CWAVES + WL_STRIP_SWAVES;
     static const int kThreads = 64 * kWaves;
     static const int kMinWaves = LT >= 18 ? 3 : 4;   // two 8-wave workgroups per CU need four waves per SIMD: at most 128 registers (18, 20 taps: 168)
@@ -416,36 +423,77 @@ struct WlAfbStrip {
     }
 
     // ---- compute wave ---------------------------------------------------------------------------------------------
+    // acc (+)= (lo[t], hi[t]) * s.x / s.y (XY = 0 / 1); t and XY are compile-time after unrolling: exactly one form survives
+    static WL_DEV void tap_fma(wl_v2& acc, const wl_v2 (&bank)[NB], int t, int xy, wl_v2 s) {
+        if (!QMF) { if (xy) wl_pk_fma_y(acc, bank[t], s); else wl_pk_fma_x(acc, bank[t], s); return; }
+        const int u = t < LT / 2 ? t : LT - 1 - t;
+        const bool sw = t >= LT / 2, neg = t & 1;
+#if defined(__HIPCC__)
+        if (!sw && !neg) { if (xy) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(bank[u]), "v"(s));
+                           else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(bank[u]), "v"(s)); }
+        else if (!sw && neg) { if (xy) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_hi:[1,0,0]" : "+v"(acc) : "s"(bank[u]), "v"(s));
+                               else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "+v"(acc) : "s"(bank[u]), "v"(s)); }
+        else if (sw && !neg) { if (xy) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(bank[u]), "v"(s));
+                               else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]" : "+v"(acc) : "s"(bank[u]), "v"(s)); }
+        else { if (xy) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "+v"(acc) : "s"(bank[u]), "v"(s));
+               else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "+v"(acc) : "s"(bank[u]), "v"(s)); }
+#else
+        const float c = xy ? s.y : s.x;
+        const float lo = sw ? bank[u].y : bank[u].x, hi = (sw ? bank[u].x : bank[u].y) * (neg ? -1.f : 1.f);
+        acc.x = __builtin_fmaf(lo, c, acc.x); acc.y = __builtin_fmaf(hi, c, acc.y);
+#endif
+    }
+    static WL_DEV wl_v2 tap_mul(const wl_v2 (&bank)[NB], int t, int xy, wl_v2 s) {
+        if (!QMF) return xy ? wl_pk_mul_y(bank[t], s) : wl_pk_mul_x(bank[t], s);
+        const int u = t < LT / 2 ? t : LT - 1 - t;
+        const bool sw = t >= LT / 2, neg = t & 1;
+        wl_v2 r;
+#if defined(__HIPCC__)
+        if (!sw && !neg) { if (xy) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "s"(bank[u]), "v"(s));
+                           else asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "s"(bank[u]), "v"(s)); }
+        else if (!sw && neg) { if (xy) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_hi:[1,0]" : "=v"(r) : "s"(bank[u]), "v"(s));
+                               else asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "s"(bank[u]), "v"(s)); }
+        else if (sw && !neg) { if (xy) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(r) : "s"(bank[u]), "v"(s));
+                               else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0]" : "=v"(r) : "s"(bank[u]), "v"(s)); }
+        else { if (xy) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(r) : "s"(bank[u]), "v"(s));
+               else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "s"(bank[u]), "v"(s)); }
+#else
+        const float c = xy ? s.y : s.x;
+        const float lo = sw ? bank[u].y : bank[u].x, hi = (sw ? bank[u].x : bank[u].y) * (neg ? -1.f : 1.f);
+        r.x = lo * c; r.y = hi * c;
+#endif
+        return r;
+    }
     struct Wave {
-        wl_v2 tw[LT], th[LT];      // (lo,hi) tap pairs along W / along H (wave-uniform: scalar registers)
+        wl_v2 tw[NB], th[NB];      // (lo,hi) tap pairs along W / along H (wave-uniform: scalar registers); QMF: P[u] = (lo[u], lo[L-1-u])
         char* llp; char* hp0; char* hp1; char* hp2;
         unsigned rowb, llrowb;
         bool two, pair_ok;
     };
     // row filter of one staged row for both columns of the lane: s = its L+2 samples as (even, odd) pairs
     static WL_DEV void row_pass(const Wave& R, const wl_v2 (&s)[2 * NV4], wl_v2& ra, wl_v2& rb) {
-        wl_v2 a0 = wl_pk_mul_x(R.tw[0], s[0]), b0 = wl_pk_mul_x(R.tw[0], s[1]);
-        wl_v2 a1 = wl_pk_mul_y(R.tw[1], s[0]), b1 = wl_pk_mul_y(R.tw[1], s[1]);
+        wl_v2 a0 = tap_mul(R.tw, 0, 0, s[0]), b0 = tap_mul(R.tw, 0, 0, s[1]);
+        wl_v2 a1 = tap_mul(R.tw, 1, 1, s[0]), b1 = tap_mul(R.tw, 1, 1, s[1]);
 #pragma unroll
         for (int u = 1; u < LT / 2; ++u) {
-            wl_pk_fma_x(a0, R.tw[2 * u], s[u]);
-            wl_pk_fma_x(b0, R.tw[2 * u], s[u + 1]);
-            wl_pk_fma_y(a1, R.tw[2 * u + 1], s[u]);
-            wl_pk_fma_y(b1, R.tw[2 * u + 1], s[u + 1]);
+            tap_fma(a0, R.tw, 2 * u, 0, s[u]);
+            tap_fma(b0, R.tw, 2 * u, 0, s[u + 1]);
+            tap_fma(a1, R.tw, 2 * u + 1, 1, s[u]);
+            tap_fma(b1, R.tw, 2 * u + 1, 1, s[u + 1]);
         }
         ra = a0 + a1;
         rb = b0 + b1;
     }
     // column filter over the circular window whose OLDEST row sits in slot `first` (compile-time after unrolling)
     static WL_DEV void col_pass(const Wave& R, const wl_v2 (&w)[LW], int first, wl_v2& cl, wl_v2& ch) {
-        wl_v2 l0 = wl_pk_mul_x(R.th[0], w[first % LW]), h0 = wl_pk_mul_y(R.th[0], w[first % LW]);
-        wl_v2 l1 = wl_pk_mul_x(R.th[1], w[(first + 1) % LW]), h1 = wl_pk_mul_y(R.th[1], w[(first + 1) % LW]);
+        wl_v2 l0 = tap_mul(R.th, 0, 0, w[first % LW]), h0 = tap_mul(R.th, 0, 1, w[first % LW]);
+        wl_v2 l1 = tap_mul(R.th, 1, 0, w[(first + 1) % LW]), h1 = tap_mul(R.th, 1, 1, w[(first + 1) % LW]);
 #pragma unroll
         for (int t = 2; t < LT; t += 2) {
-            wl_pk_fma_x(l0, R.th[t], w[(first + t) % LW]);
-            wl_pk_fma_y(h0, R.th[t], w[(first + t) % LW]);
-            wl_pk_fma_x(l1, R.th[t + 1], w[(first + t + 1) % LW]);
-            wl_pk_fma_y(h1, R.th[t + 1], w[(first + t + 1) % LW]);
+            tap_fma(l0, R.th, t, 0, w[(first + t) % LW]);
+            tap_fma(h0, R.th, t, 1, w[(first + t) % LW]);
+            tap_fma(l1, R.th, t + 1, 0, w[(first + t + 1) % LW]);
+            tap_fma(h1, R.th, t + 1, 1, w[(first + t + 1) % LW]);
         }
         cl = l0 + l1;
         ch = h0 + h1;
@@ -477,9 +525,9 @@ struct WlAfbStrip {
         const bool active = kA < s.k1;
         Wave R;
 #pragma unroll
-        for (int t = 0; t < LT; ++t) {
-            R.tw[t] = wl_uniform_v2(wl_v2{a.h_w_lo[t], a.h_w_hi[t]});
-            R.th[t] = wl_uniform_v2(wl_v2{a.h_h_lo[t], a.h_h_hi[t]});
+        for (int t = 0; t < NB; ++t) {
+            R.tw[t] = wl_uniform_v2(QMF ? wl_v2{a.h_w_lo[t], a.h_w_lo[LT - 1 - t]} : wl_v2{a.h_w_lo[t], a.h_w_hi[t]});
+            R.th[t] = wl_uniform_v2(QMF ? wl_v2{a.h_h_lo[t], a.h_h_lo[LT - 1 - t]} : wl_v2{a.h_h_lo[t], a.h_h_hi[t]});
         }
         const unsigned bplane = (unsigned)a.Kh * (unsigned)a.Kw;
         R.hp0 = reinterpret_cast<char*>(a.highs + (size_t)plane * 3 * bplane);

@@ -50,11 +50,14 @@ class DTCWTForward(nn.Module):
                               else [include_scale, ] * self.J)
 
     def forward(self, x):
-        scales = [x.new_zeros([]), ] * self.J
-        highs = [x.new_zeros([]), ] * self.J
         mode = mode_to_int(self.mode)
         if self.J == 0:
             return x, None
+        # (the reference fills both lists with 0-dim zeros up front, transform2d.py:107-108 - two fill launches per call; every
+        # highs entry is assigned below, and the scales placeholders are only made when a scale is asked for)
+        want_scales = True in self.include_scale
+        scales = [x.new_zeros([]), ] * self.J if want_scales else None
+        highs = [None, ] * self.J
         # odd sizes are extended by edge replication and sizes that are not multiples of 4 by one row /
         # column on both sides (reference :116-135): both happen inside the kernels
         first = 1
@@ -76,7 +79,7 @@ class DTCWTForward(nn.Module):
             highs[j] = h
             if self.include_scale[j]:
                 scales[j] = low
-        if True in self.include_scale:
+        if want_scales:
             return scales, highs
         return low, highs
 

@@ -251,6 +251,40 @@ class AFB1D(Function):
         return dx, None, None, None
 
 
+class AFB1DMulti(Function):
+    """All J levels of DWT1DForward as ONE autograd node: ``AFB1DMulti.apply(x, h0, h1, mode_int, J) -> (yl, yh_1 .. yh_J)`` =
+    J x AFB1D chained (reference dwt/transform1d.py:44-59).  One launch of the fused 1-D kernel where the engine takes it
+    (ops.afb1d_fused), the per-level launches otherwise; the backward is the chain of the per-level backward passes
+    (synthesis with the same stored taps, cropped: reference dwt/lowlevel.py:409-424)."""
+
+    @staticmethod
+    def forward(ctx, x, h0, h1, mode, J):
+        _check_bank_mode(mode)
+        ctx.save_for_backward(h0, h1)
+        ctx.mode = mode
+        res = ops.afb1d_fused(x, h0, h1, mode, J) if FUSED_LEVELS else None
+        if res is None:
+            lo, his = x, []
+            for _ in range(J):
+                lo, hi = ops.afb1d(lo, h0, h1, mode, 2)
+                his.append(hi)
+        else:
+            lo, his = res
+        ctx.lens = [x.shape[2]] + [h.shape[2] for h in his[:-1]]
+        return (lo,) + tuple(his)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dlo, *dhis):
+        dx = None
+        if ctx.needs_input_grad[0]:
+            h0, h1 = ctx.saved_tensors
+            dx = dlo
+            for dh, n in zip(dhis[::-1], ctx.lens[::-1]):
+                dx = ops.sfb1d(dx, dh, h0, h1, ctx.mode, 2, out_len=n)
+        return dx, None, None, None, None
+
+
 class SFB1D(Function):
     """One level of 1-D synthesis.  ``SFB1D.apply(low, high, g0, g1, mode_int) -> y`` (reference dwt/lowlevel.py:697-743).
     Backward = analysis with the stored synthesis taps."""

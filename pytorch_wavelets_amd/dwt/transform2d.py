@@ -22,6 +22,11 @@ def _resolve_bank(wave, lo_attr, hi_attr):
     raise ValueError("wave must be a name, a Wavelet, or a tuple of 2 or 4 filters")
 
 
+def _qmf_banks(g0_col, g1_col, g0_row, g1_row):
+    """Are both highpass banks the quadrature mirrors of their lowpass banks?  (module-level: DWTInverse stays picklable)"""
+    return ops.is_qmf_pair(g0_col, g1_col) and ops.is_qmf_pair(g0_row, g1_row)
+
+
 class DWTForward(nn.Module):
     """2-D multi-level DWT.  ``DWTForward(J=1, wave='db1', mode='zero')(x) -> (yl, yh)`` with
     ``yh[j]`` of shape (N, C, 3, H_j, W_j), finest scale first (reference transform2d.py:7-74)."""
@@ -36,6 +41,9 @@ class DWTForward(nn.Module):
         self.register_buffer('h1_row', filts[3])
         self.J = J
         self.mode = mode
+        # kernel-variant hint, re-validated against the buffers on every call (see DWTInverse): the stored decomposition pair of
+        # an orthogonal wavelet is a quadrature-mirror pair too, h1[t] = (-1)**t h0[L-1-t]
+        self._qmf = ops.TapVerdict(_qmf_banks)
 
     def forward(self, x):
         mode = lowlevel.mode_to_int(self.mode)
@@ -43,13 +51,9 @@ class DWTForward(nn.Module):
             return x, []
         # NB argument order: the module's *col* pair lands in the row slots (quirk Q1, reference
         # transform2d.py:70-71).  All J levels are one autograd node / (up to) one kernel launch.
-        outs = lowlevel.AFB2DMulti.apply(x, self.h0_col, self.h1_col, self.h0_row, self.h1_row, mode, self.J)
+        with ops.qmf_hint(self._qmf(self.h0_col, self.h1_col, self.h0_row, self.h1_row)):
+            outs = lowlevel.AFB2DMulti.apply(x, self.h0_col, self.h1_col, self.h0_row, self.h1_row, mode, self.J)
         return outs[0], list(outs[1:])
-
-
-def _qmf_banks(g0_col, g1_col, g0_row, g1_row):
-    """Are both highpass banks the quadrature mirrors of their lowpass banks?  (module-level: DWTInverse stays picklable)"""
-    return ops.is_qmf_pair(g0_col, g1_col) and ops.is_qmf_pair(g0_row, g1_row)
 
 
 class DWTInverse(nn.Module):

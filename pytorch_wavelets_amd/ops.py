@@ -209,9 +209,9 @@ def is_symmetric_taps(h):
 
 @contextlib.contextmanager
 def qmf_hint(flag):
-    """Inside this context the caller vouches that the HIGHPASS synthesis banks handed to sfb2d_stream are the quadrature
-    mirrors of the lowpass banks, g1[t] = (-1)**t * g0[L-1-t] (policy bit 1 of wl_dwt2d_synthesis_stream): DWTInverse sets it
-    from the filter table it was built with."""
+    """Inside this context the caller vouches that the HIGHPASS banks handed to sfb2d_stream / afb2d_stream are the quadrature
+    mirrors of the lowpass banks, hi[t] = (-1)**t * lo[L-1-t] (policy bit 1 of wl_dwt2d_synthesis_stream /
+    wl_dwt2d_analysis_stream): DWTInverse / DWTForward set it from their buffers as they are at call time (TapVerdict)."""
     prev = getattr(_HINTS, 'qmf', False)
     _HINTS.qmf = bool(flag)
     try:
@@ -363,7 +363,8 @@ def afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=False):
     if not force and W * es < 2048:
         return None                      # the engine's policy: narrower rows stay on the tile kernels
     x, x_ps, x_rs = _planes(x)
-    key = ('afbs', x.device, x.dtype, N * C, H, W, x_ps, x_rs, L, mode, bool(force))
+    qmf = bool(getattr(_HINTS, 'qmf', False))
+    key = ('afbs', x.device, x.dtype, N * C, H, W, x_ps, x_rs, L, mode, bool(force), qmf)
     if key in _FUSED_DECLINED:
         return None
     hwl, hwh, hhl, hhh = (_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi))
@@ -372,7 +373,7 @@ def afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=False):
     highs = torch.empty((N, C, 3, Kh, Kw), dtype=x.dtype, device=x.device)
     rc = _call('wl_dwt2d_analysis_stream', x, x.data_ptr(), x_ps, x_rs, ll.data_ptr(), Kh * Kw, Kw, highs.data_ptr(),
                _DTYPES[x.dtype], N * C, H, W, hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(), hhh.data_ptr(), L, mode,
-               1 if force else 0, _stream(x))
+               (1 if force else 0) | (2 if qmf else 0), _stream(x))
     if rc == -3:
         _remember_decline(key)
         return None
@@ -570,6 +571,39 @@ def afb1d(x, h0, h1, mode, dim):
     else:
         base = -((2 * (K - 1) - n + L) // 2)
     return corr1d(x, dim, h0, h1, K, base, 2, 1, _MODE_TO_EXT[mode])
+
+
+def afb1d_fused(x, h0, h1, mode, J):
+    """J (1..4) analysis levels along the LAST axis in ONE launch (wl_dwt1d_analysis_fused: every input sample read once, the
+    intermediate lowpass signals stay in LDS): x (..., n) -> (lo, [hi_1 .. hi_J]) finest first, or None when the kernel does
+    not cover the configuration (callers go level by level on afb1d)."""
+    import ctypes
+    _check_tensor(x, 'x')
+    L = h0.numel()
+    n = x.shape[-1]
+    if (x.dtype == torch.float64 or J < 1 or J > 4 or L % 2 or L > 20 or h1.numel() != L or x.numel() == 0 or n < L
+            or mode not in _MODE_TO_EXT):
+        return None
+    x = x.contiguous()
+    rows = x.numel() // n
+    key = ('afb1d', x.device, x.dtype, rows, n, L, mode, J)
+    if key in _FUSED_DECLINED:
+        return None
+    t0, t1 = _taps(h0, x), _taps(h1, x)
+    lens, m = [], n
+    for _ in range(J):
+        m = coeff_len(m, L, mode)
+        lens.append(m)
+    his = [torch.empty(x.shape[:-1] + (m,), dtype=x.dtype, device=x.device) for m in lens]
+    lo = torch.empty(x.shape[:-1] + (lens[-1],), dtype=x.dtype, device=x.device)
+    ptrs = (ctypes.c_void_p * J)(*[t.data_ptr() for t in his])
+    rc = _call('wl_dwt1d_analysis_fused', x, x.data_ptr(), lo.data_ptr(), ptrs, _DTYPES[x.dtype], rows, n, J, t0.data_ptr(),
+               t1.data_ptr(), L, mode, _stream(x))
+    if rc == -3:
+        _remember_decline(key)
+        return None
+    _lib.check(rc, 'wl_dwt1d_analysis_fused')
+    return lo, his
 
 
 def sfb1d(lo, hi, g0, g1, mode, dim, out_len=None):

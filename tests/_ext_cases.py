@@ -194,3 +194,48 @@ def check_nonsep(name, dev, dtype, tol):
     assert G.relerr(rec.detach().cpu().numpy(), g, 'rec') < tol
     dc, = torch.autograd.grad((rec * _t(g['gr'], dev, dtype)).sum(), c)
     assert G.relerr(dc.cpu().numpy(), g, 'dc') < tol
+
+
+def check_dwt1d_fused(dev, cases=None, tol=1e-5):
+    """DWT1DForward on the fused multi-level 1-D kernel (csrc/wl_dwt1d_fused.h) against the ORACLE: every mode, odd lengths,
+    rows of one chunk and of many chunks (chunk ends inside the signal, at its ends, shorter last chunks), 2-20 taps, J = 1..4,
+    float16; and its gradient against the per-level path."""
+    import numpy as np
+    from oracle import wavelet_oracle as wo
+    from pytorch_wavelets_amd import filters as F
+    from pytorch_wavelets_amd.dwt import lowlevel as _ll
+    rng = np.random.RandomState(23)
+    cases = cases or [('db4', 'symmetric', 3, (2, 3, 9000), torch.float32), ('db1', 'zero', 4, (1, 2, 12305), torch.float32),
+                      ('db3', 'reflect', 2, (3, 1, 4097), torch.float32), ('db8', 'symmetric', 3, (1, 2, 20000), torch.float32),
+                      ('sym10', 'zero', 2, (1, 1, 8191), torch.float32), ('db2', 'periodization', 3, (2, 2, 1000), torch.float32),
+                      ('db5', 'periodic', 2, (1, 3, 777), torch.float32), ('db6', 'periodization', 1, (2, 1, 333), torch.float32),
+                      ('db4', 'symmetric', 1, (4, 4, 64), torch.float32), ('coif2', 'reflect', 4, (1, 1, 16384), torch.float32),
+                      ('db4', 'symmetric', 3, (2, 2, 8192), torch.float16), ('db7', 'zero', 3, (1, 2, 5001), torch.float32)]
+    for wave, mode, J, shape, dtype in cases:
+        h0, h1 = F.dwt_analysis_taps(wave)
+        x = torch.tensor(rng.randn(*shape), dtype=dtype, device=dev)
+        oyl, oyh = wo.dwt1d_forward(x.detach().cpu().double().numpy(), J, h0, h1, mode)
+        xfm = pw.DWT1DForward(J=J, wave=wave, mode=mode).to(dev).to(dtype)
+        xa = x.clone().requires_grad_(dtype == torch.float32)
+        yl, yh = xfm(xa)
+        assert 'WlDwt1dFused' in pw.last_kernel(), (wave, mode, J, shape, pw.last_kernel())
+        t = 4e-3 if dtype == torch.float16 else tol
+        assert yl.shape == oyl.shape
+        assert np.abs(yl.detach().cpu().double().numpy() - oyl).max() <= t * np.abs(oyl).max(), (wave, mode, J, shape, 'yl')
+        for j in range(J):
+            assert yh[j].shape == oyh[j].shape and yh[j].is_contiguous()
+            assert np.abs(yh[j].detach().cpu().double().numpy() - oyh[j]).max() <= t * max(np.abs(oyh[j]).max(), 1e-30), (wave, mode, J, shape, j)
+        if dtype == torch.float32:
+            ws = [torch.randn_like(yl)] + [torch.randn_like(h) for h in yh]
+            ((yl * ws[0]).sum() + sum((h * w).sum() for h, w in zip(yh, ws[1:]))).backward()
+            prev = _ll.FUSED_LEVELS
+            _ll.FUSED_LEVELS = False
+            try:
+                xb = x.clone().requires_grad_(True)
+                yl2, yh2 = xfm(xb)
+                assert 'WlDwt1dFused' not in pw.last_kernel()
+                ((yl2 * ws[0]).sum() + sum((h * w).sum() for h, w in zip(yh2, ws[1:]))).backward()
+            finally:
+                _ll.FUSED_LEVELS = prev
+            assert float((xa.grad - xb.grad).abs().max()) <= 1e-5 * float(xb.grad.abs().max())
+            assert float((yl - yl2).detach().abs().max()) <= 1e-5 * float(yl2.detach().abs().max())

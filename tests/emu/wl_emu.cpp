@@ -4,3 +4,4 @@
 #include "../../pytorch_wavelets_amd/csrc/wl_rows_api.inc"
 #include "../../pytorch_wavelets_amd/csrc/wl_strip_api.inc"
 #include "../../pytorch_wavelets_amd/csrc/wl_dtinv_api.inc"
+#include "../../pytorch_wavelets_amd/csrc/wl_dwt1d_api.inc"

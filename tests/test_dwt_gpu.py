@@ -215,7 +215,8 @@ def test_fp16_config5_full_plane_size(W):
     pw.DWTForward(J=1, wave='db8', mode='periodization').to(DEV).half()(x)
     # W = 2048: the streaming strip kernel; W = 2046 (periodization needs whole wrapped groups): the tile kernel (pair
     # staging; V4 = 0 is the template default)
-    assert _last_kernel() == ('WlAfbStrip<_Float16, 16>' if W % 4 == 0 else 'WlAfbTile<_Float16, 16, 16, 64, 1>'), _last_kernel()
+    # (the module's banks are a quadrature-mirror pair: the strip kernel's QMF instantiation)
+    assert _last_kernel() == ('WlAfbStrip<_Float16, 16, 1>' if W % 4 == 0 else 'WlAfbTile<_Float16, 16, 16, 64, 1>'), _last_kernel()
     yl, yh = xfm(x)
     assert yl.shape == (2, 16, 128, (W + 15) // 16) and yh[0].shape == (2, 16, 3, 1024, W // 2)
     h0, h1 = F.dwt_analysis_taps('db8')
@@ -661,7 +662,7 @@ def test_quadrature_mirror_variant_of_the_synthesis_strip_kernel_gpu(wave, mode,
     ifm._qmf = lambda *bufs: False      # (no hint: both banks in registers)
     r2 = ifm((yl, yh))
     k2 = pw.last_kernel()
-    assert 'WlSfbStrip' in k1 and k1.rstrip('>').endswith(', 1') and 'WlSfbStrip' in k2 and k1 != k2, (k1, k2)
+    assert 'WlSfbStrip' in k1 and k1.rstrip('>').endswith(', 1') and 'WlSfbStrip' in k2 and k1 != k2, (k1, k2)   # (no 14-tap case here: it has no QMF instantiation)
     tol = 2e-3 if dtype == torch.float16 else 1e-6
     assert float((r1.float() - r2.float()).abs().max()) <= tol * float(r2.float().abs().max())
     assert float((r1.float() - x.float()).abs().max()) <= (2e-2 if dtype == torch.float16 else 1e-4) * float(x.float().abs().max())
@@ -701,3 +702,13 @@ def test_mutated_highpass_bank_on_the_production_policy_path():
         want = wo.dwt_inverse(npy(yl[n:n + 1, c:c + 1]), [npy(yh[0][n:n + 1, c:c + 1])], g[0], g[1], g[2], g[3], 'symmetric')
         assert rel(r1[n:n + 1, c:c + 1], want) < TOL
     assert float((r0 - r1).abs().max()) > 0.1
+
+
+@pytest.mark.parametrize('wave,mode,dtype,tol', [('db8', 'symmetric', torch.float32, 1e-5), ('db6', 'periodization', torch.float32, 1e-5),
+                                                 ('db7', 'zero', torch.float32, 1e-5), ('db10', 'reflect', torch.float32, 1e-5),
+                                                 ('db8', 'periodization', torch.float16, 4e-3)])
+def test_filter_buffers_changed_after_construction_dwt_forward_gpu(wave, mode, dtype, tol):
+    """The analysis strip kernel's quadrature-mirror variant (12-20 taps) against the ORACLE, and the hint following the
+    buffers as they are at call time."""
+    import _mutation_cases as M
+    M.check_dwt_forward_mutations(DEV, wave=wave, mode=mode, shape=(2, 2, 64, 288), dtype=dtype, tol=tol)

@@ -128,3 +128,13 @@ def test_rotationally_symmetric_variants(name):
     with emu_backend.emulated():
         E.check_rot(name, 'cpu', torch.float64, 5e-7)
         E.check_rot(name, 'cpu', torch.float32, 2e-5)
+
+
+def test_fused_multilevel_dwt1d_vs_oracle():
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float32)
+    try:
+        with emu_backend.emulated():
+            E.check_dwt1d_fused('cpu', tol=3e-6)
+    finally:
+        torch.set_default_dtype(prev)

@@ -88,3 +88,9 @@ def test_scatlayerj2_forward_and_backward(name):
 def test_rotationally_symmetric_variants(name):
     E.check_rot(name, DEV, torch.float32, 2e-5)
     E.check_rot(name, DEV, torch.float64, 5e-7)
+
+
+def test_fused_multilevel_dwt1d_vs_oracle_gpu():
+    E.check_dwt1d_fused(DEV)
+    E.check_dwt1d_fused(DEV, cases=[('db4', 'symmetric', 3, (8, 16, 65536), torch.float32), ('db8', 'zero', 4, (4, 3, 100003), torch.float32),
+                                    ('db4', 'symmetric', 3, (8, 16, 65536), torch.float16)])
