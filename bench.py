@@ -573,6 +573,44 @@ def other_configs(pw, dev, sync):
         other['scatlayer_64x3x512x512_fp32'] = {'fwd_ms': round(tsw, 4), 'frac_of_hbm_peak_at_11B_per_px': frac(11 * xd.numel(), tsw),
                                                'fwd_kernels': names(lambda: slw(xd))}
         del xd, dyl, dyh
+    # ---- training steps (forward + backward to the input): rows f1 of SURVEY 8(f).  Algorithmic bytes: the forward's, and for
+    # the backward the gradients of every output read once + the input gradient written once (= the forward's number again);
+    # ScatLayer also writes (forward) and reads (backward) the saved (re, im) / r: 6 planes of P/4 each, twice
+    def train_step(mod, x, outs_of):
+        xg = x.detach().requires_grad_(True)
+        outs = outs_of(mod(xg))
+        gos = [torch.randn_like(o) for o in outs]
+
+        def step():
+            xg2 = x.detach().requires_grad_(True)
+            o = outs_of(mod(xg2))
+            return torch.autograd.grad(o, xg2, gos)
+        return step
+    xt = torch.randn(128, 3, 512, 512, device=dev)
+    m = pw.DWTForward(J=3, wave='db4', mode='symmetric').to(dev)
+    st = train_step(m, xt, lambda r: [r[0]] + list(r[1]))
+    t = time_seq_fn(st, 30, sync)
+    b = 2 * algorithmic_bytes_fwd(128, 3, 512, 512, 3, 8, 4)
+    other['train_dwt_j3_db4_128x3x512x512_fp32'] = {'fwd_bwd_ms': round(t, 4), 'frac_of_hbm_peak': frac(b, t), 'algorithmic_bytes': b,
+                                                    'kernels': names(st)}
+    del xt
+    xt = torch.randn(64, 3, 512, 512, device=dev)
+    m = pw.DTCWTForward(J=3).to(dev)
+    st = train_step(m, xt, lambda r: [r[0]] + list(r[1]))
+    t = time_seq_fn(st, 30, sync)
+    b = 2 * 20 * xt.numel()
+    other['train_dtcwt_j3_64x3x512x512_fp32'] = {'fwd_bwd_ms': round(t, 4), 'frac_of_hbm_peak': frac(b, t), 'algorithmic_bytes': b,
+                                                 'kernels': names(st)}
+    del xt
+    xt = torch.randn(256, 3, 256, 256, device=dev)
+    m = pw.ScatLayer().to(dev)
+    st = train_step(m, xt, lambda r: [r])
+    t = time_seq_fn(st, 30, sync)
+    b = 46 * xt.numel()          # forward 4 (1 + 7/4 + 3) P, backward the same
+    other['train_scatlayer_256x3x256x256_fp32'] = {'fwd_bwd_ms': round(t, 4), 'frac_of_hbm_peak_at_46B_per_px': frac(b, t),
+                                                   'algorithmic_bytes': b, 'kernels': names(st)}
+    del xt
+    with torch.no_grad():
         xs = torch.randn(256, 3, 256, 256, device=dev)
         sl = pw.ScatLayer().to(dev)
         ts = time_seq_fn(lambda: sl(xs), 30, sync)

@@ -292,7 +292,11 @@ struct WlDtIStripArgs {
     int st_off, st_pitch, lds_bytes;
 };
 
-template <typename T, int L0, int L1>
+// SCAT = 1: ScatLayerj1_f.backward (reference scatternet/lowlevel.py:114-137) - the same inverse fed by the scattering
+// prologue: the lowpass quad is the 2 x 2 nearest-neighbour upsampling of dZ[:, 0] / 4, the band-pass pair of orientation o is
+// dZ[:, 1 + o] * (re / r, im / r) with the saved quotients; the stager lanes form them from 19 coalesced 4-byte loads per
+// quad (dZ (N, 7, C, h, w), drdx / drdy (N, 6, C, h, w)) instead of the eight 8-byte loads of the plain inverse.
+template <typename T, int L0, int L1, int SCAT = 0>
 struct WlDtInv1Strip {
     typedef WlDtIStripArgs<T> Args;
     static const int CW = 4;                           // compute waves: up to 256 quad columns per strip
@@ -350,7 +354,7 @@ struct WlDtInv1Strip {
     static WL_HD int cell_off(const Args& a, int c) { return (c & 1) * (a.st_pitch / 2) + (c >> 1) * 16; }
 
     typedef T Pair2 __attribute__((ext_vector_type(2), may_alias));
-    struct Quad { Pair2 l0, l1, b[6]; };               // the eight sources of one quad, as loaded
+    struct Quad { Pair2 l0, l1, b[6]; T z0, z[6], dx[6], dy[6]; };   // the sources of one quad, as loaded (SCAT: z0, z, dx, dy)
 
     static WL_DEV void stager(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int lane, int sidx) {
         const WlDtInv1Args<T>& f = a.f;
@@ -359,8 +363,15 @@ struct WlDtInv1Strip {
         const int j = 64 * sidx + lane;                       // this lane's quad of every quad row
         const int Q = s.Qa + j;
         const bool qon = j < s.nq;
-        const T* llp = f.ll + (size_t)plane * f.ll_plane_stride + 2 * Q;
-        const T* hp = f.highs + (size_t)plane * 6 * qplane * 2 + 2 * Q;
+        const T* llp = SCAT ? nullptr : f.ll + (size_t)plane * f.ll_plane_stride + 2 * Q;
+        const T* hp = SCAT ? nullptr : f.highs + (size_t)plane * 6 * qplane * 2 + 2 * Q;
+        // SCAT: my quad column of dZ[n, k, c], drdx[n, o, c], drdy[n, o, c]; entries k / o are C planes apart
+        const int64_t n_img = SCAT ? plane / f.C : 0;
+        const int c_img = SCAT ? (int)(plane - n_img * f.C) : 0;
+        const T* zp = SCAT ? f.sz + ((size_t)n_img * 7 * f.C + c_img) * qplane + Q : nullptr;
+        const T* dxp = SCAT ? f.sdx + ((size_t)n_img * 6 * f.C + c_img) * qplane + Q : nullptr;
+        const T* dyp = SCAT ? f.sdy + ((size_t)n_img * 6 * f.C + c_img) * qplane + Q : nullptr;
+        const size_t eplane = (size_t)f.C * qplane;
         // staged cells (16 bytes per pixel) of its two pixel columns, and of their mirror images inside the strip's range
         const int e_hi = 2 * s.q1 - 1 + M;
         int cdst[2], mdst[2];
@@ -380,6 +391,17 @@ struct WlDtInv1Strip {
             int sq = src_quad_row(s.e_first / 2 + h, H2, f.ext, flip);
             sq = sq < 0 ? 0 : sq;
             if (!qon) return;
+            if (SCAT) {
+                const size_t ro = (size_t)sq * W2;
+                qd.z0 = zp[ro];
+#pragma unroll
+                for (int o = 0; o < 6; ++o) {
+                    qd.z[o] = zp[(size_t)(o + 1) * eplane + ro];
+                    qd.dx[o] = dxp[(size_t)o * eplane + ro];
+                    qd.dy[o] = dyp[(size_t)o * eplane + ro];
+                }
+                return;
+            }
             qd.l0 = *reinterpret_cast<const Pair2*>(llp + (size_t)(2 * sq) * f.ll_row_stride);
             qd.l1 = *reinterpret_cast<const Pair2*>(llp + (size_t)(2 * sq + 1) * f.ll_row_stride);
 #pragma unroll
@@ -393,7 +415,10 @@ struct WlDtInv1Strip {
             if (!qon) return;
             float re[6], im[6];
 #pragma unroll
-            for (int o = 0; o < 6; ++o) { re[o] = (float)qd.b[o].x; im[o] = (float)qd.b[o].y; }
+            for (int o = 0; o < 6; ++o) {
+                if (SCAT) { re[o] = (float)qd.z[o] * (float)qd.dx[o]; im[o] = (float)qd.z[o] * (float)qd.dy[o]; }
+                else { re[o] = (float)qd.b[o].x; im[o] = (float)qd.b[o].y; }
+            }
             // c2q (dtcwt/lowlevel.py:263-295): orientation pairs (0,5) -> lh, (2,3) -> hl, (1,4) -> hh
             float v[2][2][4];                                 // [row][col][channel]
 #pragma unroll
@@ -402,7 +427,8 @@ struct WlDtInv1Strip {
                 v[0][0][ch] = (re[o1] + re[o2]) * k; v[0][1][ch] = (im[o1] + im[o2]) * k;
                 v[1][0][ch] = (im[o1] - im[o2]) * k; v[1][1][ch] = (re[o2] - re[o1]) * k;
             }
-            v[0][0][0] = (float)qd.l0.x; v[0][1][0] = (float)qd.l0.y; v[1][0][0] = (float)qd.l1.x; v[1][1][0] = (float)qd.l1.y;
+            if (SCAT) v[0][0][0] = v[0][1][0] = v[1][0][0] = v[1][1][0] = 0.25f * (float)qd.z0;
+            else { v[0][0][0] = (float)qd.l0.x; v[0][1][0] = (float)qd.l0.y; v[1][0][0] = (float)qd.l1.x; v[1][1][0] = (float)qd.l1.y; }
             const bool zero = sq < 0;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {

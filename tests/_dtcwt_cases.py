@@ -99,3 +99,31 @@ def check_layouts(dev, dtype, tol):
             assert torch.equal(back, b)
         rec = ifm((yl, yh))
         assert float((rec - x).abs().max() / x.abs().max()) < tol
+
+
+def check_scat_backward_streaming(dev, shapes, tol=1e-5):
+    """ScatLayer's backward on the streaming level-1 inverse with the scattering prologue in its stagers
+    (WlDtInv1Strip<..., SCAT = 1>) against the ORACLE's ScatLayerj1_f.backward (forward, saved quotients and gradient all from
+    the oracle in float64): whole planes, several strips / segments, float16."""
+    from oracle import wavelet_oracle as wo
+    from pytorch_wavelets_amd import filters as F
+    rng = np.random.RandomState(41)
+    h0o, h1o = F.dtcwt_forward_taps('near_sym_a', 'qshift_a')[:2]
+    for shape, dtype in shapes:
+        x = rng.randn(*shape)
+        if dtype == torch.float16:
+            x = np.float16(x).astype(np.float64)
+        Z, saved = wo.scat_layer_forward(x, h0o, h1o, return_saved=True)
+        dZ = rng.randn(*Z.shape)
+        want = wo.scat_layer_backward(dZ, saved, h0o, h1o)
+        sl = pw.ScatLayer().to(dev).to(dtype)
+        xg = torch.tensor(x, dtype=dtype, device=dev).requires_grad_(True)
+        z = sl(xg)
+        t = 6e-3 if dtype == torch.float16 else tol
+        assert float(np.abs(z.detach().cpu().double().numpy() - Z).max()) <= t * float(np.abs(Z).max())
+        c0 = pw.launch_count()
+        g, = torch.autograd.grad(z, xg, torch.tensor(dZ, dtype=dtype, device=dev))
+        ks = pw.kernels_since(c0)
+        assert any('WlDtInv1Strip' in k and k.rstrip('>').endswith(', 1') for k in ks), ks
+        assert g.shape == want.shape
+        assert float(np.abs(g.detach().cpu().double().numpy() - want).max()) <= t * float(np.abs(want).max()), (shape, dtype)

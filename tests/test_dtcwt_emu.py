@@ -455,3 +455,14 @@ def test_fused_inverse_as_the_backward_of_the_fused_forward():
     finally:
         ops.STREAM_FORCE = prev
     assert float((xa.grad - xb.grad).abs().max()) <= 3e-6 * float(xb.grad.abs().max())
+
+
+def test_scatlayer_backward_on_the_streaming_inverse():
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float32)
+    try:
+        with emu_backend.emulated():
+            D.check_scat_backward_streaming('cpu', [((1, 2, 64, 256), torch.float32), ((1, 3, 36, 1160), torch.float32),
+                                                    ((2, 1, 128, 512), torch.float32), ((1, 2, 64, 512), torch.float16)], tol=3e-6)
+    finally:
+        torch.set_default_dtype(prev)
