@@ -73,9 +73,14 @@ struct WlDtFusedArgs {
 // variant: the inference kernel does not carry the pointers of the saved tensors through its scalar registers).
 // MODE 4: fwd_j2plus alone - the stagers put the rows of the level's input (and their mirrored cells: exact, no symmetry
 // assumed) straight into the ring the level-2 lanes read; no level-1 waves.
-template <typename T, int L0, int L1, int LQ, int MODE = 2, int CW_ = 4>
+// PP = 2 (lean level-1 kernels, planes of up to 256 columns): a workgroup owns TWO consecutive planes - level-1 waves 0, 1 the
+// first, 2, 3 the second, every stager wave its row of both (the staged rows lie side by side) - so that all four level-1
+// waves of the wide-plane kernel work (with one 256-column plane per workgroup of two level-1 waves + two stagers ScatLayer
+// ran at 0.49-0.51 of its roofline against 0.55-0.57 on 512-column planes).
+template <typename T, int L0, int L1, int LQ, int MODE = 2, int CW_ = 4, int PP = 1>
 struct WlDtFwd12Strip {
     typedef WlDtFusedArgs<T> Args;
+    static_assert(PP == 1 || (PP == 2 && CW_ == 4 && MODE != 2 && MODE != 4), "two planes per workgroup: lean level-1 kernels only");
 #ifndef WL_DT12_SW
 #define WL_DT12_SW 4
 #endif
@@ -161,19 +166,30 @@ struct WlDtFwd12Strip {
         const WlDtFwd1Args<T>& f = a.f;
         const char* xp = reinterpret_cast<const char*>(f.x + (size_t)plane * f.H * f.W);
         const int row_stride = f.W * SZ;
+        // (PP = 2: groups [ng, 2 ng) are the second plane's - H W elements further on in memory, half a staged row further
+        // on in LDS; an odd number of planes leaves the last workgroup's second half empty)
+        const bool two = PP == 2 && plane + 1 < f.NC;
+        const int sub_src = f.H * f.W * SZ, sub_dst = a.st_pitch / 2;
         int goff[MAXG], gdst[MAXG];
 #pragma unroll
         for (int i = 0; i < MAXG; ++i) {
-            const int g = lane + 64 * i;
+            const int g0 = lane + 64 * i;
+            const int sub = PP == 2 && g0 >= s.ng ? 1 : 0;
+            const int g = g0 - sub * s.ng;
             const int col = 4 * (s.gc0 + g);
-            goff[i] = g < s.ng ? col * SZ : 0;
-            gdst[i] = g < s.ng ? (col - s.e_lo + SLACK) * 4 : -1;
+            const bool on = g < s.ng && (sub == 0 || two);
+            goff[i] = on ? col * SZ + sub * sub_src : 0;
+            gdst[i] = on ? (col - s.e_lo + SLACK) * 4 + sub * sub_dst : -1;
         }
-        int hdst = -1, hoff = 0;                               // one mirrored cell per lane
-        if (lane < s.nl + s.nr) {
-            const int e = lane < s.nl ? s.e_lo + lane : f.W + (lane - s.nl);
-            hdst = (e - s.e_lo + SLACK) * 4;
-            hoff = wl_ext(e, f.W, WL_EXT_SYM) * SZ;
+        int hdst = -1, hoff = 0;                               // one mirrored cell per lane (PP = 2: lanes 32 .. for the second plane)
+        {
+            const int sub = PP == 2 && lane >= 32 ? 1 : 0;
+            const int l = lane - 32 * sub;
+            if (l < s.nl + s.nr && (sub == 0 || two)) {
+                const int e = l < s.nl ? s.e_lo + l : f.W + (l - s.nl);
+                hdst = (e - s.e_lo + SLACK) * 4 + sub * sub_dst;
+                hoff = wl_ext(e, f.W, WL_EXT_SYM) * SZ + sub * sub_src;
+            }
         }
         auto load = [&](int h, RowRegs& rr) {
 #pragma unroll
@@ -274,10 +290,13 @@ struct WlDtFwd12Strip {
     // so the epilogue is written for few instructions: the addresses of the twelve band-pass stores of a quad row are one
     // scalar base per orientation plus ONE 32-bit lane offset, the column taps sit two to a scalar pair (the scalar file is
     // what overflows first: spilled taps come back through v_readlane + wait states).
-    static WL_DEV void level1(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int cw, int lane) {
+    static WL_DEV void level1(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane0, int cw0, int lane) {
         const WlDtFwd1Args<T>& f = a.f;
+        const int sub = PP == 2 ? cw0 / (CW / 2) : 0;          // PP = 2: waves 0, 1 the first plane, 2, 3 the second
+        const int cw = PP == 2 ? cw0 % (CW / 2) : cw0;
+        const int64_t plane = plane0 + sub;
         const int q = s.qa + 64 * cw + lane;
-        const bool active = q < s.qb;
+        const bool active = q < s.qb && plane < f.NC;
         const bool own_q = q >= s.q0 && q < s.q1;
         Taps1 R;
 #pragma unroll
@@ -291,7 +310,7 @@ struct WlDtFwd12Strip {
         for (int u = 0; u < (L0 + 1) / 2; ++u) R.c0[u] = wl_uniform_v2(wl_v2{(float)f.h0[2 * u], 2 * u + 1 < L0 ? (float)f.h0[2 * u + 1 < L0 ? 2 * u + 1 : 0] : 0.f});
 #pragma unroll
         for (int u = 0; u < (L1 + 1) / 2; ++u) R.c1[u] = wl_uniform_v2(wl_v2{(float)f.h1[2 * u], 2 * u + 1 < L1 ? (float)f.h1[2 * u + 1 < L1 ? 2 * u + 1 : 0] : 0.f});
-        const int soff = 16 + 8 * (active ? q - s.qa : 0);
+        const int soff = 16 + 8 * (active ? q - s.qa : 0) + (PP == 2 ? sub * (a.st_pitch / 2) : 0);
         // LL1 ring: cell 0 = pixel column 2 q0 - HQ.  At the plane's edges the mirrored copies go out with the pixel pair.
         const int Q = f.W / 2;
         const int l1c = 2 * q - (2 * s.q0 - HQ);
@@ -548,12 +567,13 @@ struct WlDtFwd12Strip {
         const int wave = wl_uniform(tid >> 6), lane = tid & 63;
         const int64_t lbid = wl_xcd_remap(ctx.bid, a.nblocks);
         const int per_plane = a.nstrips * a.nseg;
-        const int64_t plane = lbid / per_plane;
-        const int rem = (int)(lbid - plane * per_plane);
+        const int64_t pidx = lbid / per_plane;
+        const int64_t plane = pidx * PP;                       // (PP = 2: the first of the workgroup's two planes)
+        const int rem = (int)(lbid - pidx * per_plane);
         const int seg = rem / a.nstrips, strip = rem - seg * a.nstrips;
         const Strip s = geometry(a, strip, seg);
         if (wave >= CW + QW) {
-            const int ngl = (s.ng + 63) >> 6;
+            const int ngl = (PP * s.ng + 63) >> 6;
             if (ngl <= 1) stager<1>(a, s, ctx, plane, lane, wave - CW - QW);
             else if (ngl == 2) stager<2>(a, s, ctx, plane, lane, wave - CW - QW);
             else stager<3>(a, s, ctx, plane, lane, wave - CW - QW);

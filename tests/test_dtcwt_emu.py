@@ -258,7 +258,8 @@ def test_golden_through_the_forced_fused_kernel(monkeypatch):
     assert took and all(took)
 
 
-@pytest.mark.parametrize('shape,dtype,grad', [((2, 3, 32, 256), torch.float32, True), ((1, 2, 64, 512), torch.float32, False),
+@pytest.mark.parametrize('shape,dtype,grad', [((2, 3, 32, 256), torch.float32, True), ((1, 3, 36, 256), torch.float32, True),
+                                              ((3, 1, 32, 256), torch.float32, False), ((1, 2, 64, 512), torch.float32, False),
                                               ((1, 2, 36, 1024), torch.float32, True), ((2, 2, 32, 512), torch.float16, False)])
 def test_lean_scatlayer_kernel_equals_tile_kernel(shape, dtype, grad):
     """ScatLayer on the lean streaming kernel (wl_dtcwt_fused.h MODE 1: averaged lowpass, smoothed magnitudes, the saved

@@ -409,4 +409,4 @@ def test_golden_through_the_forced_fused_inverse(monkeypatch):
 def test_scatlayer_backward_on_the_streaming_inverse_gpu():
     """config 4's plane size (256 x 256, enough images for the engine's own policy to pick the streaming kernel) and wider planes."""
     D.check_scat_backward_streaming(DEV, [((64, 3, 256, 256), torch.float32), ((32, 3, 512, 512), torch.float32),
-                                          ((64, 2, 132, 1160), torch.float32), ((64, 3, 256, 256), torch.float16)])
+                                          ((64, 2, 132, 1160), torch.float32), ((64, 3, 256, 512), torch.float16)])
