@@ -95,7 +95,10 @@ struct WlDtFwd12Strip {
 #endif
     // two workgroups of 10 (12) waves per CU, or three of 8: at most 96 (80) registers
     static const bool kScat = MODE == 1 || MODE == 3;
-    static const int kMinWaves = kScat ? WL_DT12_MINW1 : (SW == 2 && MODE == 2 ? 5 : 6);
+    // (MODE 3, the training forward, keeps 19 output streams' addresses and values live: at the 80 registers of six waves per
+    // SIMD it spilled 88 bytes per lane and ran 0.354 ms at config 4's shape; at 128 registers (four waves, two workgroups per
+    // CU) nothing spills: 0.235 ms.  The inference kernel fits 78 registers and is faster at six.)
+    static const int kMinWaves = MODE == 3 ? 4 : (kScat ? WL_DT12_MINW1 : (SW == 2 && MODE == 2 ? 5 : 6));
     static const int SZ = (int)sizeof(T);
     static const int M0 = L0 / 2, M1 = L1 / 2, M = MODE == 4 ? 0 : (M0 > M1 ? M0 : M1);   // (MODE 4: no level-1 filters)
     static const int LW = (2 * M + 1 + 3) / 4 * 4;

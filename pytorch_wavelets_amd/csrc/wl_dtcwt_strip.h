@@ -296,7 +296,10 @@ struct WlDtIStripArgs {
 // prologue: the lowpass quad is the 2 x 2 nearest-neighbour upsampling of dZ[:, 0] / 4, the band-pass pair of orientation o is
 // dZ[:, 1 + o] * (re / r, im / r) with the saved quotients; the stager lanes form them from 19 coalesced 4-byte loads per
 // quad (dZ (N, 7, C, h, w), drdx / drdy (N, 6, C, h, w)) instead of the eight 8-byte loads of the plain inverse.
-template <typename T, int L0, int L1, int SCAT = 0>
+// PP = 2 (planes of up to 256 columns): a workgroup owns TWO consecutive planes - compute waves 0, 1 and stager waves 0, 1 the
+// first, 2, 3 the second, the staged rows side by side - so that all eight waves work (wl_dtcwt_fused.h does the same for the
+// lean forward kernels).
+template <typename T, int L0, int L1, int SCAT = 0, int PP = 1>
 struct WlDtInv1Strip {
     typedef WlDtIStripArgs<T> Args;
     static const int CW = 4;                           // compute waves: up to 256 quad columns per strip
@@ -351,18 +354,22 @@ struct WlDtInv1Strip {
     // byte offset of staged cell c (pixel column px0 + c) inside a staged row: even and odd cells live in the two halves of
     // the row, so that the lanes of a wave (one quad = two pixels each) read and write consecutive 16-byte words (with the
     // cells simply side by side every access was a 2-way bank conflict: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50)
-    static WL_HD int cell_off(const Args& a, int c) { return (c & 1) * (a.st_pitch / 2) + (c >> 1) * 16; }
+    static WL_HD int cell_off(const Args& a, int c) { return (c & 1) * (a.st_pitch / (2 * PP)) + (c >> 1) * 16; }
 
     typedef T Pair2 __attribute__((ext_vector_type(2), may_alias));
     struct Quad { Pair2 l0, l1, b[6]; T z0, z[6], dx[6], dy[6]; };   // the sources of one quad, as loaded (SCAT: z0, z, dx, dy)
 
-    static WL_DEV void stager(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int lane, int sidx) {
+    static WL_DEV void stager(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane0, int lane, int sidx0) {
         const WlDtInv1Args<T>& f = a.f;
         const int H2 = f.H / 2, W2 = f.W / 2;
         const size_t qplane = (size_t)H2 * W2;
+        const int sub = PP == 2 ? sidx0 / 2 : 0;              // PP = 2: stager waves 0, 1 the first plane, 2, 3 the second
+        const int sidx = PP == 2 ? sidx0 % 2 : sidx0;
+        const int64_t plane = plane0 + sub;
+        const int sub_off = sub * (a.st_pitch / PP);
         const int j = 64 * sidx + lane;                       // this lane's quad of every quad row
         const int Q = s.Qa + j;
-        const bool qon = j < s.nq;
+        const bool qon = j < s.nq && plane < f.NC;
         const T* llp = SCAT ? nullptr : f.ll + (size_t)plane * f.ll_plane_stride + 2 * Q;
         const T* hp = SCAT ? nullptr : f.highs + (size_t)plane * 6 * qplane * 2 + 2 * Q;
         // SCAT: my quad column of dZ[n, k, c], drdx[n, o, c], drdy[n, o, c]; entries k / o are C planes apart
@@ -378,13 +385,13 @@ struct WlDtInv1Strip {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int p = 2 * Q + c;
-            cdst[c] = cell_off(a, p - s.px0);
+            cdst[c] = cell_off(a, p - s.px0) + sub_off;
             int e = -1000000;
             if (f.ext != WL_EXT_ZERO && qon) {
                 if (p < M && -1 - p >= s.e_lo) e = -1 - p;
                 if (p >= f.W - M && 2 * f.W - 1 - p <= e_hi) e = 2 * f.W - 1 - p;
             }
-            mdst[c] = e == -1000000 ? -1 : cell_off(a, e - s.px0);
+            mdst[c] = e == -1000000 ? -1 : cell_off(a, e - s.px0) + sub_off;
         }
         auto load = [&](int h, Quad& qd) {
             bool flip;
@@ -498,10 +505,13 @@ struct WlDtInv1Strip {
         ya = a0.x + a0.y; yb = b0.x + b0.y;
     }
 
-    static WL_DEV void compute(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int cw, int lane) {
+    static WL_DEV void compute(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane0, int cw0, int lane) {
         const WlDtInv1Args<T>& f = a.f;
+        const int sub = PP == 2 ? cw0 / 2 : 0;
+        const int cw = PP == 2 ? cw0 % 2 : cw0;
+        const int64_t plane = plane0 + sub;
         const int q = s.q0 + 64 * cw + lane;
-        const bool active = q < s.q1;
+        const bool active = q < s.q1 && plane < f.NC;
         Wave R;
 #pragma unroll
         for (int t = 0; t < L0; ++t) R.r0[t] = wl_uniform_v2(wl_v2{(float)f.g0[t], (float)f.g0[t]});
@@ -514,8 +524,8 @@ struct WlDtInv1Strip {
             const float v1 = t1 >= 0 && t1 < L1 ? (float)f.g1[t1 >= 0 && t1 < L1 ? t1 : 0] : 0.f;
             R.cc[t] = wl_uniform_v2(wl_v2{v0, v1});
         }
-        const int soff = (active ? q - s.q0 : 0) * 16;         // cell (e_lo - px0) + 2 (q - q0) + u: see cell_off (e_lo - px0 = M & 1)
-        const int hp2 = a.st_pitch / 2;
+        const int soff = (active ? q - s.q0 : 0) * 16 + sub * (a.st_pitch / PP);   // cell (e_lo - px0) + 2 (q - q0) + u: see cell_off (e_lo - px0 = M & 1)
+        const int hp2 = a.st_pitch / (2 * PP);
         char* const yp = reinterpret_cast<char*>(f.y + (size_t)plane * f.H * f.W);
         const unsigned rowb = (unsigned)f.W * SZ, colb = (unsigned)(2 * q) * SZ;
         wl_v2 wa[LW], wb[LW];
@@ -556,8 +566,9 @@ struct WlDtInv1Strip {
         const int wave = wl_uniform(tid >> 6), lane = tid & 63;
         const int64_t lbid = wl_xcd_remap(ctx.bid, a.nblocks);
         const int per_plane = a.nstrips * a.nseg;
-        const int64_t plane = lbid / per_plane;
-        const int rem = (int)(lbid - plane * per_plane);
+        const int64_t pidx = lbid / per_plane;
+        const int64_t plane = pidx * PP;                      // (PP = 2: the first of the workgroup's two planes)
+        const int rem = (int)(lbid - pidx * per_plane);
         const int seg = rem / a.nstrips, strip = rem - seg * a.nstrips;
         const Strip s = geometry(a, strip, seg);
         for (int i = tid * 16; i < a.lds_bytes; i += kThreads * 16) {
@@ -570,7 +581,7 @@ struct WlDtInv1Strip {
             __builtin_amdgcn_s_setprio(2);
 #endif
             stager(a, s, ctx, plane, lane, wave - CW);
-        } else if (64 * wave < s.q1 - s.q0) {
+        } else if (64 * (PP == 2 ? wave % 2 : wave) < s.q1 - s.q0) {
             compute(a, s, ctx, plane, wave, lane);
         } else {
             for (int hb = 0; hb < s.nhb; ++hb) ctx.sync();

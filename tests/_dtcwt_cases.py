@@ -119,11 +119,12 @@ def check_scat_backward_streaming(dev, shapes, tol=1e-5):
         sl = pw.ScatLayer().to(dev).to(dtype)
         xg = torch.tensor(x, dtype=dtype, device=dev).requires_grad_(True)
         z = sl(xg)
-        t = 6e-3 if dtype == torch.float16 else tol
+        t = 1e-2 if dtype == torch.float16 else tol   # (float16: dZ, the saved quotients and the result are each rounded to 11 bits; the maximum over 10^7 samples)
         assert float(np.abs(z.detach().cpu().double().numpy() - Z).max()) <= t * float(np.abs(Z).max())
         c0 = pw.launch_count()
         g, = torch.autograd.grad(z, xg, torch.tensor(dZ, dtype=dtype, device=dev))
         ks = pw.kernels_since(c0)
-        assert any('WlDtInv1Strip' in k and k.rstrip('>').endswith(', 1') for k in ks), ks
+        # <T, L0, L1, SCAT = 1 (, PP = 2 for planes of up to 256 columns)>
+        assert any('WlDtInv1Strip<' in k and [a.strip() for a in k[k.index('<') + 1:k.rindex('>')].split(',')][3:4] == ['1'] for k in ks), ks
         assert g.shape == want.shape
         assert float(np.abs(g.detach().cpu().double().numpy() - want).max()) <= t * float(np.abs(want).max()), (shape, dtype)

@@ -463,7 +463,7 @@ def test_scatlayer_backward_on_the_streaming_inverse():
     torch.set_default_dtype(torch.float32)
     try:
         with emu_backend.emulated():
-            D.check_scat_backward_streaming('cpu', [((1, 2, 64, 256), torch.float32), ((1, 3, 36, 1160), torch.float32),
+            D.check_scat_backward_streaming('cpu', [((1, 2, 64, 256), torch.float32), ((1, 3, 36, 256), torch.float32), ((1, 3, 36, 1160), torch.float32),
                                                     ((2, 1, 128, 512), torch.float32), ((1, 2, 64, 512), torch.float16)], tol=3e-6)
     finally:
         torch.set_default_dtype(prev)
