@@ -411,11 +411,13 @@ def main():
 
     # HBM traffic of the dominant kernels: only from a PMC summary measured on THIS build of the sources
     traffic = {}
-    tpath = os.path.join(ROOT, 'profiles', 'r03_hbm_traffic.json' if wl.key == 'dwt' else 'r03_%s_hbm_traffic.json' % wl.key)
-    if os.path.exists(tpath) and not emu:
+    import glob
+    tpaths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_hbm_traffic.json' if wl.key == 'dwt'
+                                           else 'r[0-9][0-9]_%s_hbm_traffic.json' % wl.key)), reverse=True)
+    for tpath in ([] if emu else tpaths):      # newest round first; a file counts only if it was measured on this build
         try:
             tj = json.load(open(tpath))
-            if tj.get('source_digest') == source_digest():
+            if tj.get('source_digest') == source_digest() and not traffic:
                 for k, v in tj.get('kernels', {}).items():   # rocprof prints defaulted template arguments too
                     for p in parts:                          # (several instantiations may share the prefix: the largest one is the part's kernel)
                         if k.strip().startswith(kernel[p].rstrip('>')) and (v.get('hbm_bytes_corrected') or 0) > (traffic.get(p) or 0):

@@ -1,11 +1,12 @@
-"""Turn the outputs of tools/gpu_round3.sh (one gpurun call) into the tracked summaries under profiles/:
+"""Turn the outputs of tools/gpu_round4.sh / gpu_round3.sh (one gpurun call) into the tracked summaries under profiles/
+(RND = the round prefix, 'r04' unless given; the counter files are written only when the call made the PMC passes):
    <tag>_bench_line.json, <tag>_bench_{dtcwt,scat,cfg5}.json   the JSON lines of the four bench commands
    <tag>_kernel_durations.csv, <tag>_{dtcwt,scat,cfg5}_kernel_durations.csv   per (kernel, grid) launch count / mean / min / max (us)
-   r03_hbm_traffic.json        FETCH_SIZE / WRITE_SIZE of the metric's kernels (gfx950 correction) + the digest of the sources
+   RND_hbm_traffic.json        FETCH_SIZE / WRITE_SIZE of the metric's kernels (gfx950 correction) + the digest of the sources
                                (bench.py quotes it only on a match)
    <tag>_{dtcwt,scat,cfg5}_hbm_traffic.json   the same for the other configs
-   r03_cfg5_pmc_summary.json   SQ counters of the two config-5 kernels and what they say about the bound
-usage: python tools/make_round3_profiles.py <tag>"""
+   RND_cfg5_pmc_summary.json   SQ counters of the two config-5 kernels and what they say about the bound
+usage: python tools/make_round_profiles.py <tag> [<round prefix>]"""
 import collections
 import csv
 import json
@@ -18,6 +19,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 tag = sys.argv[1]
+RND = sys.argv[2] if len(sys.argv) > 2 else 'r04'
 G = os.path.join(ROOT, 'gpurun_out')
 P = os.path.join(ROOT, 'profiles')
 
@@ -100,7 +102,7 @@ def traffic(pmc, out):
     return kernels
 
 
-for src, dst in (('bench_line.json', 'bench_line.json'), ('bench_dtcwt.json', 'bench_dtcwt.json'), ('bench_scat.json', 'bench_scat.json'),
+for src, dst in (('bench_line.json', 'bench_line.json'), ('bench_line_20.json', 'bench_line_20.json'), ('bench_dtcwt.json', 'bench_dtcwt.json'), ('bench_scat.json', 'bench_scat.json'),
                  ('bench_cfg5.json', 'bench_cfg5.json'), ('box.txt', 'box.txt')):
     p = os.path.join(G, tag, src)
     if os.path.exists(p):
@@ -110,33 +112,34 @@ for src, dst in (('bench_line.json', 'bench_line.json'), ('bench_dtcwt.json', 'b
 durations(os.path.join(G, tag, 'prof', 'bench_kernel_trace.csv'), os.path.join(P, tag + '_kernel_durations.csv'))
 for c in ('dtcwt', 'scat', 'cfg5'):
     durations(os.path.join(G, tag, 'prof_' + c, 'bench_kernel_trace.csv'), os.path.join(P, '%s_%s_kernel_durations.csv' % (tag, c)))
-traffic(os.path.join(G, 'pmc_%s_bench' % tag, 'pmc_summary.json'), os.path.join(P, 'r03_hbm_traffic.json'))
-for c in ('dtcwt', 'scat', 'cfg5'):
-    t = traffic(os.path.join(G, 'pmc_%s_%s' % (tag, c), 'pmc_summary.json'), os.path.join(P, 'r03_%s_hbm_traffic.json' % c))
-# config 5: what the SQ counters say about the bound of the two strip kernels (level-1 dispatch = the largest)
-pmc = json.load(open(os.path.join(G, 'pmc_%s_cfg5' % tag, 'pmc_summary.json')))
-out = {'source_digest': bench.source_digest(), 'tag': tag,
-       'how': 'rocprofv3 --pmc passes (counters + kernel trace only) around `python bench.py --config cfg5`; values of the largest '
-              'dispatch of each kernel (level 1: 32x16x2048x2048 float16), summed over the chip by rocprofv3', 'kernels': {}}
-for k, c in pmc.items():
-    if 'Strip' not in k or 'SQ_INSTS_VALU' not in c:
-        continue
-    name = short(pretty(k))
-    m = {n: c[n]['max'] for n in c}
-    waves, valu = m['SQ_WAVES'], m['SQ_INSTS_VALU']
-    cycles = m['GRBM_GUI_ACTIVE'] / 8.0            # the counter is summed over the 8 XCDs
-    d = {'counters_level1_dispatch': m,
-         'kernel_cycles': round(cycles),
-         'valu_instructions_per_wave': round(valu / waves, 1),
-         # a wave64 VALU instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs
-         'valu_pipe_utilisation': round(4 * valu / (1024 * cycles), 4),
-         'lds_bank_conflict_fraction_of_lds_active': round(m['SQ_LDS_BANK_CONFLICT'] / max(m['SQ_LDS_IDX_ACTIVE'], 1), 4),
-         'salu_per_valu': round(m['SQ_INSTS_SALU'] / valu, 3), 'lds_per_valu': round(m['SQ_INSTS_LDS'] / valu, 3),
-         'wait_inst_any_fraction_of_wave_cycles': round(m['SQ_WAIT_INST_ANY'] / m['SQ_WAVE_CYCLES'], 4),   # (both in units of 4 cycles)
-         'hbm_bytes_corrected': t.get(name, {}).get('hbm_bytes_corrected')}
-    out['kernels'][name] = d
-out['reading'] = ('Both kernels are bound by vector-ALU issue, not by HBM: a wave64 VALU instruction occupies its SIMD for 4 cycles, so '
-                  '4 x SQ_INSTS_VALU / (SIMDs x kernel cycles) is the VALU-pipe utilisation.  See DESIGN.md 4.6 / 5 for the derivation '
-                  'of the VALU roofline of config 5 (1.24 ms for the four levels against 1.07 ms at the HBM peak).')
-json.dump(out, open(os.path.join(P, 'r03_cfg5_pmc_summary.json'), 'w'), indent=1)
-print('wrote r03_cfg5_pmc_summary.json')
+if os.path.exists(os.path.join(G, 'pmc_%s_bench' % tag, 'pmc_summary.json')):
+    traffic(os.path.join(G, 'pmc_%s_bench' % tag, 'pmc_summary.json'), os.path.join(P, RND + '_hbm_traffic.json'))
+    for c in ('dtcwt', 'scat', 'cfg5'):
+        t = traffic(os.path.join(G, 'pmc_%s_%s' % (tag, c), 'pmc_summary.json'), os.path.join(P, '%s_%s_hbm_traffic.json' % (RND, c)))
+    # config 5: what the SQ counters say about the bound of the two strip kernels (level-1 dispatch = the largest)
+    pmc = json.load(open(os.path.join(G, 'pmc_%s_cfg5' % tag, 'pmc_summary.json')))
+    out = {'source_digest': bench.source_digest(), 'tag': tag,
+           'how': 'rocprofv3 --pmc passes (counters + kernel trace only) around `python bench.py --config cfg5`; values of the largest '
+                  'dispatch of each kernel (level 1: 32x16x2048x2048 float16), summed over the chip by rocprofv3', 'kernels': {}}
+    for k, c in pmc.items():
+        if 'Strip' not in k or 'SQ_INSTS_VALU' not in c:
+            continue
+        name = short(pretty(k))
+        m = {n: c[n]['max'] for n in c}
+        waves, valu = m['SQ_WAVES'], m['SQ_INSTS_VALU']
+        cycles = m['GRBM_GUI_ACTIVE'] / 8.0            # the counter is summed over the 8 XCDs
+        d = {'counters_level1_dispatch': m,
+             'kernel_cycles': round(cycles),
+             'valu_instructions_per_wave': round(valu / waves, 1),
+             # a wave64 VALU instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs
+             'valu_pipe_utilisation': round(4 * valu / (1024 * cycles), 4),
+             'lds_bank_conflict_fraction_of_lds_active': round(m['SQ_LDS_BANK_CONFLICT'] / max(m['SQ_LDS_IDX_ACTIVE'], 1), 4),
+             'salu_per_valu': round(m['SQ_INSTS_SALU'] / valu, 3), 'lds_per_valu': round(m['SQ_INSTS_LDS'] / valu, 3),
+             'wait_inst_any_fraction_of_wave_cycles': round(m['SQ_WAIT_INST_ANY'] / m['SQ_WAVE_CYCLES'], 4),   # (both in units of 4 cycles)
+             'hbm_bytes_corrected': t.get(name, {}).get('hbm_bytes_corrected')}
+        out['kernels'][name] = d
+    out['reading'] = ('Both kernels are bound by vector-ALU issue, not by HBM: a wave64 VALU instruction occupies its SIMD for 4 cycles, so '
+                      '4 x SQ_INSTS_VALU / (SIMDs x kernel cycles) is the VALU-pipe utilisation.  See DESIGN.md 4.6 / 5 for the derivation '
+                      'of the VALU roofline of config 5 (1.24 ms for the four levels against 1.07 ms at the HBM peak).')
+    json.dump(out, open(os.path.join(P, RND + '_cfg5_pmc_summary.json'), 'w'), indent=1)
+    print('wrote r03_cfg5_pmc_summary.json')
