@@ -261,6 +261,17 @@ int wl_corr1d(const void* x, void* y0, void* y1, int dtype, int64_t outer, int n
               int K, const void* h0, const void* h1, int tap_offset, int tap_stride, int ntaps, int start, int step,
               int tap_step, int ext, int out_offset, int out_stride, void* stream);
 
+/* One level of the 2-D stationary (undecimated) transform in ONE launch (csrc/wl_swt2d.h) = afb2d_atrous
+ * (dwt/lowlevel.py:475-521: afb1d_atrous :175-223 along W, then along H; the level of SWTForward.forward,
+ * dwt/transform2d.py:186-212): x (planes,H,W) through the plane stride x_ps (elements; rows dense - the ll channels of a
+ * previous level are every 4th plane of its output) -> y (planes,4,H,W) dense with sub-band 2 r + b (r: band along W,
+ * b: band along H) = the (N,4C,H,W) tensor the reference returns.  Taps: the stored (reversed) filters, Lw / Lh of them,
+ * dilated by `dilation`; `ext` as for wl_corr1d (0 zero, 1 symmetric, 2 reflect, 3 periodic, 5 replicate).  Returns
+ * WL_ERR_UNSUPPORTED for odd L * dilation and for dilated filters too long for a tile in LDS: callers then chain wl_corr1d. */
+int wl_swt2d_level(const void* x, int64_t x_ps, void* y, int dtype, int64_t planes, int H, int W,
+                   const void* h_w_lo, const void* h_w_hi, const void* h_h_lo, const void* h_h_hi, int Lw, int Lh,
+                   int dilation, int ext, void* stream);
+
 /* 1-D two-channel synthesis bank along the middle axis = sfb1d (dwt/lowlevel.py:226-271; SFB1D.forward :697-727 and
  * AFB1D.backward :409-424): lo, hi (outer, K, inner) [hi may be NULL = zeros] -> y (outer, ny, inner) with
  * ny <= 2K-L+2 (2K for periodization, whose single fold of the wrapped tail is reproduced literally). */

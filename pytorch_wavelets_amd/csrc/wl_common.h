@@ -102,6 +102,29 @@ template <typename T> WL_DEV void wl_store_stream(T* p, T v) {
 #else
 template <typename T> inline void wl_store_stream(T* p, T v) { *p = v; }
 #endif
+// Two adjacent elements (a, b) to sbase + voff: sbase is wave-uniform (a scalar register pair), voff this lane's 32-bit byte
+// offset - the "scalar base + vector offset" form of global_store.  Written as a pointer sum the compiler widens voff to a
+// 64-bit vector address per store (a v_lshl_add_u64 each: 12 per half-batch in the 16-tap strip kernel); float16 pairs are
+// converted two at a time (v_cvt_pk_f16_f32, gfx950) instead of two conversions + v_perm.
+#if defined(__HIPCC__)
+WL_DEV void wl_store2_s(char* sbase, unsigned voff, float a, float b, float*) {
+    wl_v2 v = {a, b};
+    asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+WL_DEV void wl_store2_s(char* sbase, unsigned voff, float a, float b, _Float16*) {
+    typedef _Float16 H2 __attribute__((ext_vector_type(2)));
+    const wl_v2 f = {a, b};
+    const unsigned p = __builtin_bit_cast(unsigned, __builtin_convertvector(f, H2));     // v_cvt_pk_f16_f32 (gfx950)
+    asm volatile("global_store_dword %0, %1, %2" :: "v"(voff), "v"(p), "s"(sbase) : "memory");
+}
+WL_DEV void wl_store2_s(char* sbase, unsigned voff, float a, float b, double*) {
+    double* q = reinterpret_cast<double*>(sbase + voff); q[0] = a; q[1] = b;
+}
+#else
+template <typename T> inline void wl_store2_s(char* sbase, unsigned voff, float a, float b, T*) {
+    T* q = reinterpret_cast<T*>(sbase + voff); q[0] = (T)a; q[1] = (T)b;
+}
+#endif
 #if defined(__HIPCC__)
 WL_DEV int wl_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 WL_DEV float wl_uniform_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }

@@ -61,15 +61,17 @@ struct WlDwt1dFused {
     // constant - indexed by a run-time level they would live in scratch memory)
     template <int j> static WL_HD void geo_level(const Args& a, Geo& g, int k0, bool last) {
         if constexpr (j >= 1) {
+            // (every element of g is assigned at ONE place with a compile-time index: assigned in both arms of a branch the
+            // compiler merged the stores into one with a run-time offset and the arrays went to scratch memory)
             const int J = a.J;
-            if (j > J) { g.clo[j] = g.chi[j] = g.olo[j] = g.ohi[j] = g.org[j] = 0; }
-            else {
+            int clo = 0, chi = 0, olo = 0, ohi = 0, org = 0;
+            if (j <= J) {
                 const int sh = J - j;
                 int lo = k0 << sh, hi = last ? a.n[j] : ((k0 + a.chunk) << sh);
                 if (lo > a.n[j]) lo = a.n[j];
                 if (hi > a.n[j]) hi = a.n[j];
-                g.olo[j] = lo; g.ohi[j] = hi;
-                g.clo[j] = lo; g.chi[j] = hi;
+                olo = lo; ohi = hi;
+                clo = lo; chi = hi;
                 if constexpr (j < WL_DWT1D_MAXJ) {
                     if (j < J) {
                         // what level j + 1 reads of level j, inside the signal
@@ -77,13 +79,14 @@ struct WlDwt1dFused {
                         if (g.chi[j + 1] <= g.clo[j + 1]) { ilo = lo; ihi = hi; }
                         if (ilo < 0) ilo = 0;
                         if (ihi > a.n[j]) ihi = a.n[j];
-                        g.clo[j] = lo < ilo ? lo : ilo;
-                        g.chi[j] = hi > ihi ? hi : ihi;
-                        if (a.nchunks == 1) { g.clo[j] = 0; g.chi[j] = a.n[j]; }
+                        clo = lo < ilo ? lo : ilo;
+                        chi = hi > ihi ? hi : ihi;
+                        if (a.nchunks == 1) { clo = 0; chi = a.n[j]; }
                     }
                 }
-                g.org[j] = floor4(g.clo[j]);
+                org = floor4(clo);
             }
+            g.clo[j] = clo; g.chi[j] = chi; g.olo[j] = olo; g.ohi[j] = ohi; g.org[j] = org;
             geo_level<j - 1>(a, g, k0, last);
         }
     }

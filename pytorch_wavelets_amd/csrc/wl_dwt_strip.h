@@ -42,6 +42,9 @@
 #ifndef WL_STRIP_DIRECT
 #define WL_STRIP_DIRECT 1        // stagers load straight into registers (0: through an LDS-DMA ring, the first version; A/B builds)
 #endif
+#ifndef WL_STRIP_PF
+#define WL_STRIP_PF 2           // register sets of a direct stager (rows in flight + the one being staged)
+#endif
 #ifndef WL_STRIP_D
 #define WL_STRIP_D 3            // half-batches of LDS-DMA in flight = slots of the DMA ring
 #endif
@@ -305,6 +308,7 @@ struct WlAfbStrip {
     // sets, and stages the other.  No DMA ring in LDS, no counted waits (the compiler tracks ordinary loads), no DMA
     // instruction issue - which cost a stager ~250 cycles apiece under load.
     static const int MAXG = 6;             // 4-cell groups per lane and row: strips of up to 6 x 64 x 4 cells
+    static const int PF = WL_STRIP_PF;
     // (element-aligned: rows of any width and pitch; gfx950 takes unaligned vector loads)
     typedef T Quad4 __attribute__((ext_vector_type(4), aligned(sizeof(T)), may_alias));
     struct RowRegs { Quad4 g[MAXG]; T h[2]; };
@@ -409,16 +413,23 @@ struct WlAfbStrip {
                     if (hdst[u] >= 0) *reinterpret_cast<float*>(srow0 + hdst[u]) = zero ? 0.f : (float)rr.h[u];
             }
         };
-        RowRegs ra, rb;
-        load(0, ra);
-        for (int hb = 0; hb < s.nhb; hb += 2) {
-            if (hb + 1 < s.nhb) load(hb + 1, rb);
-            stage(hb, ra);
-            ctx.sync();
-            if (hb + 1 >= s.nhb) break;
-            if (hb + 2 < s.nhb) load(hb + 2, ra);
-            stage(hb + 1, rb);
-            ctx.sync();
+        // PF register sets: the rows of the next PF - 1 half-batches are in flight while one is staged.  Measured on config 5
+        // (round 4, same box): 2, 3 and 4 sets run the same 2.18 ms - the rows arrive in time with two; so did a stager with
+        // every per-row branch hoisted out of its loop (2.20 ms) and one with aligned, conflict-free staging writes (2.13 ms,
+        // a timing build): the level-1 kernel is bound by what the compute waves issue (VALU 0.67 of the cycles) next to a
+        // memory system that is moving 4 TB/s, not by its stagers
+        RowRegs rr[PF];
+#pragma unroll
+        for (int u = 0; u < PF - 1; ++u)
+            if (u < s.nhb) load(u, rr[u]);
+        for (int hb = 0; hb < s.nhb; hb += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (hb + u >= s.nhb) break;
+                if (hb + u + PF - 1 < s.nhb) load(hb + u + PF - 1, rr[(u + PF - 1) % PF]);
+                stage(hb + u, rr[u]);
+                ctx.sync();
+            }
         }
     }
 
@@ -506,17 +517,11 @@ struct WlAfbStrip {
             s[2 * u + 1] = wl_v2{t.z, t.w};
         }
     }
-    // the two columns of a lane: one aligned 2-element store when the geometry makes every pair aligned (even band
-    // width), else element stores (an odd band width has rows on odd element offsets and a last lane with one column)
-    static WL_DEV void store_pair(const Wave& R, char* p, float va, float vb) {
-        if (R.pair_ok) {
-            typedef T Vec2 __attribute__((ext_vector_type(2)));
-            Vec2 v = {(T)va, (T)vb};
-            *reinterpret_cast<Vec2*>(p) = v;
-        } else {
-            *reinterpret_cast<T*>(p) = (T)va;
-            if (R.two) *reinterpret_cast<T*>(p + SZ) = (T)vb;
-        }
+    // the two columns of a lane: one aligned 2-element store (wl_store2_s) when the geometry makes every pair aligned (even
+    // band width), else element stores (an odd band width has rows on odd element offsets and a last lane with one column)
+    static WL_DEV void store_single(const Wave& R, char* p, float va, float vb) {
+        *reinterpret_cast<T*>(p) = (T)va;
+        if (R.two) *reinterpret_cast<T*>(p + SZ) = (T)vb;
     }
 
     static WL_DEV void compute(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int cw, int lane) {
@@ -538,8 +543,13 @@ struct WlAfbStrip {
         R.two = kA + 1 < s.k1;
         R.pair_ok = a.pair_ok != 0;
         const int soff = s.lane_off + 16 * (active ? jp : 0);
-        unsigned ob = (unsigned)s.o_lo * R.rowb + (unsigned)kA * SZ;          // this lane's next output sample in a band plane
-        unsigned obl = (unsigned)s.o_lo * R.llrowb + (unsigned)kA * SZ;
+        // the next output row of the four planes as wave-uniform pointers (scalar registers, advanced by scalar adds) + ONE
+        // 32-bit lane offset: the stores address as scalar base + vector offset, no 64-bit vector adds per store
+        const unsigned voff = (unsigned)kA * SZ;
+        char* pll = R.llp + (size_t)((unsigned)s.o_lo * R.llrowb);
+        char* ph0 = R.hp0 + (size_t)((unsigned)s.o_lo * R.rowb);
+        char* ph1 = R.hp1 + (size_t)((unsigned)s.o_lo * R.rowb);
+        char* ph2 = R.hp2 + (size_t)((unsigned)s.o_lo * R.rowb);
         wl_v2 wa[LW], wb[LW];                                                 // circular windows of the two columns
 #pragma unroll
         for (int t = 0; t < LW; ++t) wa[t] = wb[t] = wl_v2{0.f, 0.f};
@@ -581,15 +591,29 @@ struct WlAfbStrip {
                                 col_pass(R, wa, first, cla, cha);
                                 col_pass(R, wb, first, clb, chb);
                                 if (!(WL_STRIP_ABLATE & 4) || cla.x + clb.y + cha.x + chb.y == 1.2345e30f) {
-                                    store_pair(R, R.llp + obl, cla.x, clb.x);
-                                    store_pair(R, R.hp0 + ob, cla.y, clb.y);
-                                    store_pair(R, R.hp1 + ob, cha.x, chb.x);
-                                    store_pair(R, R.hp2 + ob, cha.y, chb.y);
+                                    // (the second feed's row is one further down when the first feed emitted one too)
+                                    const unsigned k = (i == 1 && fed >= WARM) ? 1u : 0u;
+                                    char* const q0 = pll + (size_t)(k * R.llrowb);
+                                    char* const q1 = ph0 + (size_t)(k * R.rowb);
+                                    char* const q2 = ph1 + (size_t)(k * R.rowb);
+                                    char* const q3 = ph2 + (size_t)(k * R.rowb);
+                                    if (R.pair_ok) {          // (one branch per row, not one per store)
+                                        wl_store2_s(q0, voff, cla.x, clb.x, (T*)nullptr); wl_store2_s(q1, voff, cla.y, clb.y, (T*)nullptr);
+                                        wl_store2_s(q2, voff, cha.x, chb.x, (T*)nullptr); wl_store2_s(q3, voff, cha.y, chb.y, (T*)nullptr);
+                                    } else {
+                                        store_single(R, q0 + voff, cla.x, clb.x); store_single(R, q1 + voff, cla.y, clb.y);
+                                        store_single(R, q2 + voff, cha.x, chb.x); store_single(R, q3 + voff, cha.y, chb.y);
+                                    }
                                 }
-                                ob += R.rowb; obl += R.llrowb;
                             }
                         }
                     }
+                }
+                {   // rows emitted in this half-batch: the row pointers advance outside the lanes' branch (they stay scalar)
+                    int em = fed + n - WARM;
+                    em = em < 0 ? 0 : em > n ? n : em;
+                    pll += (size_t)((unsigned)em * R.llrowb); ph0 += (size_t)((unsigned)em * R.rowb);
+                    ph1 += (size_t)((unsigned)em * R.rowb); ph2 += (size_t)((unsigned)em * R.rowb);
                 }
                 fed += n;
                 tmath += WL_STICK() - c1;

@@ -236,16 +236,20 @@ struct WlSfbStrip {
                 if (tdst >= 0) *reinterpret_cast<float*>(sslot + r * a.st_pitch + tdst) = (float)rr.t[r];
             }
         };
-        RowRegs<NGL> ra, rb;
-        load(0, ra);
-        for (int hb = 0; hb < s.nhb; hb += 2) {
-            if (hb + 1 < s.nhb) load(hb + 1, rb);
-            stage(hb, ra);
-            ctx.sync();
-            if (hb + 1 >= s.nhb) break;
-            if (hb + 2 < s.nhb) load(hb + 2, ra);
-            stage(hb + 1, rb);
-            ctx.sync();
+        // PF register sets (WL_STRIP_PF, see wl_dwt_strip.h): the coefficient rows of PF - 1 half-batches in flight
+        static const int PF = WL_STRIP_PF;
+        RowRegs<NGL> rr[PF];
+#pragma unroll
+        for (int u = 0; u < PF - 1; ++u)
+            if (u < s.nhb) load(u, rr[u]);
+        for (int hb = 0; hb < s.nhb; hb += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (hb + u >= s.nhb) break;
+                if (hb + u + PF - 1 < s.nhb) load(hb + u + PF - 1, rr[(u + PF - 1) % PF]);
+                stage(hb + u, rr[u]);
+                ctx.sync();
+            }
         }
     }
 

@@ -373,6 +373,14 @@ def afb2d_atrous(x, filts, mode='periodization', dilation=1):
             h0_col, h1_col, h0_row, h1_row = filts
     else:
         raise ValueError("Unknown form for input filts")
+    if mode not in _ATROUS_EXT:
+        raise ValueError("Unkown pad type: {}".format(mode))
+    if FUSED_LEVELS and x.dim() == 4:
+        # one launch per level (csrc/wl_swt2d.h): x read once, the four sub-bands written once in the returned layout
+        y = ops.swt2d_level(x, _as_taps(h0_row, x), _as_taps(h1_row, x), _as_taps(h0_col, x), _as_taps(h1_col, x), dilation,
+                            _ATROUS_EXT[mode])
+        if y is not None:
+            return y
     lohi = afb1d_atrous(x, h0_row, h1_row, mode=mode, dim=3, dilation=dilation)
     return afb1d_atrous(lohi, h0_col, h1_col, mode=mode, dim=2, dilation=dilation)
 

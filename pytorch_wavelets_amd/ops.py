@@ -606,6 +606,34 @@ def afb1d_fused(x, h0, h1, mode, J):
     return lo, his
 
 
+def swt2d_level(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, dilation, ext):
+    """One level of the stationary transform in ONE launch (wl_swt2d_level): x (N,C,H,W) - dense, or uniformly spaced planes
+    of dense rows such as the ll channels `y[:, 0::4]` of the previous level - -> (N,4C,H,W) with channel 4c + 2r + b
+    (r: band along W, b: band along H); taps = the stored (reversed) ones, dilated by `dilation`; `ext` an EXT_* code.
+    None when the kernel does not cover the configuration (callers chain corr1d)."""
+    _check_tensor(x, 'x')
+    N, C, H, W = x.shape
+    Lw, Lh = h_w_lo.numel(), h_h_lo.numel()
+    if h_w_hi.numel() != Lw or h_h_hi.numel() != Lh or x.numel() == 0:
+        return None
+    key = ('swt2d', x.device, x.dtype, H, W, Lw, Lh, dilation)
+    if key in _FUSED_DECLINED:
+        return None
+    st = _plane_strides(x)
+    if st is None or st[1] != W:
+        x = x.contiguous()
+        st = (H * W, W)
+    taps = [_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi)]
+    y = torch.empty((N, 4 * C, H, W), dtype=x.dtype, device=x.device)
+    rc = _call('wl_swt2d_level', x, x.data_ptr(), st[0], y.data_ptr(), _DTYPES[x.dtype], N * C, H, W,
+               taps[0].data_ptr(), taps[1].data_ptr(), taps[2].data_ptr(), taps[3].data_ptr(), Lw, Lh, dilation, ext, _stream(x))
+    if rc == -3:
+        _remember_decline(key)
+        return None
+    _lib.check(rc, 'wl_swt2d_level')
+    return y
+
+
 def sfb1d(lo, hi, g0, g1, mode, dim, out_len=None):
     """One synthesis level along one axis (hi may be None = zeros); out_len crops (analysis backward)."""
     _check_tensor(lo, 'lo')

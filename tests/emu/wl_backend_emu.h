@@ -5,6 +5,8 @@
 // wave semantics are exact.  The visiting order of the fibres alternates forward / backward between barrier
 // phases so that a MISSING barrier in a kernel shows up as a wrong result instead of passing by luck.  LDS is
 // poisoned with NaNs.
+// The library is built from several translation units side by side (tests/emu/build.sh, like the four units of the HIP
+// build): everything at namespace scope here is `inline`, so the units share one kernel log and one current-block pointer.
 #pragma once
 #include <stdlib.h>
 #include <string.h>
@@ -15,13 +17,13 @@
 #define WL_BACKEND_NAME "emu"
 
 // a deliberately tiny "chip" so that persistent kernels walk several tiles per workgroup in the tests
-static int wl_num_cus() { return 2; }
-static const char* wl_last_kernel_ptr = "";
-static const char* wl_last_kernel_name() { return wl_last_kernel_ptr; }
-static const char* wl_kernel_log_buf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-static long long wl_kernel_log_n = 0;
-static long long wl_launch_count_value() { return wl_kernel_log_n; }
-static const char* wl_kernel_history_name(int back) {
+inline int wl_num_cus() { return 2; }
+inline const char* wl_last_kernel_ptr = "";
+inline const char* wl_last_kernel_name() { return wl_last_kernel_ptr; }
+inline const char* wl_kernel_log_buf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+inline long long wl_kernel_log_n = 0;
+inline long long wl_launch_count_value() { return wl_kernel_log_n; }
+inline const char* wl_kernel_history_name(int back) {
     if (back < 0 || back >= 8 || back >= wl_kernel_log_n) return "";
     return wl_kernel_log_buf[(wl_kernel_log_n - 1 - back) & 7];
 }
@@ -40,15 +42,15 @@ struct WlEmuBlock {
     ~WlEmuBlock() { for (size_t i = 0; i < stacks.size(); ++i) free(stacks[i]); }
 };
 
-static thread_local WlEmuBlock* wl_emu_cur_block = nullptr;
+inline thread_local WlEmuBlock* wl_emu_cur_block = nullptr;
 
-static void wl_emu_sync(void* arg) {
+inline void wl_emu_sync(void* arg) {
     WlEmuBlock* b = (WlEmuBlock*)arg;
     b->state[b->cur] = 1;
     swapcontext(&b->fib[b->cur], &b->main);
 }
 
-static float wl_emu_shuffle(float v, int src) {
+inline float wl_emu_shuffle(float v, int src) {
     WlEmuBlock* b = wl_emu_cur_block;
     const int me = b->cur;
     b->shfl_in[me] = v;
@@ -57,11 +59,11 @@ static float wl_emu_shuffle(float v, int src) {
     swapcontext(&b->fib[me], &b->main);
     return b->shfl_out[me];
 }
-float wl_shfl_up1(float v) { return wl_emu_shuffle(v, -1); }
-float wl_shfl(float v, int src_lane) { return wl_emu_shuffle(v, src_lane & 63); }
+inline float wl_shfl_up1(float v) { return wl_emu_shuffle(v, -1); }
+inline float wl_shfl(float v, int src_lane) { return wl_emu_shuffle(v, src_lane & 63); }
 
 // LDS-DMA: the copy lands only when the issuing lane's wl_wait_vm<N> releases it (oldest first)
-static void wl_emu_dma(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on, int len) {
+inline void wl_emu_dma(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on, int len) {
     WlEmuBlock* b = wl_emu_cur_block;
     WlEmuBlock::Dma d;
     d.dst = lane_on ? ctx.smem + lds_off + len * (ctx.tid & 63) : nullptr;   // off lanes keep the per-wave count
@@ -69,11 +71,11 @@ static void wl_emu_dma(const WlCtx& ctx, unsigned lds_off, const void* gsrc, boo
     d.len = len;
     b->dma[b->cur].push_back(d);
 }
-void wl_dma16(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on) { wl_emu_dma(ctx, lds_off, gsrc, lane_on, 16); }
-void wl_dma4(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on) { wl_emu_dma(ctx, lds_off, gsrc, lane_on, 4); }
+inline void wl_dma16(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on) { wl_emu_dma(ctx, lds_off, gsrc, lane_on, 16); }
+inline void wl_dma4(const WlCtx& ctx, unsigned lds_off, const void* gsrc, bool lane_on) { wl_emu_dma(ctx, lds_off, gsrc, lane_on, 4); }
 // The counter is per WAVE: the wait is a wave-level rendezvous (all lanes have issued the same loads; all their
 // copies have landed before any lane goes on), like the lockstep execution of the hardware.
-void wl_emu_wait_vm(int n) {
+inline void wl_emu_wait_vm(int n) {
     WlEmuBlock* b = wl_emu_cur_block;
     wl_emu_shuffle(0.f, b->cur & 63);
     std::vector<WlEmuBlock::Dma>& q = b->dma[b->cur];
@@ -93,7 +95,7 @@ struct WlEmuJob {
 };
 
 template <typename K>
-static void wl_emu_entry(unsigned lo, unsigned hi) {
+inline void wl_emu_entry(unsigned lo, unsigned hi) {
     WlEmuJob<K>* job = (WlEmuJob<K>*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
     WlEmuBlock* b = job->blk;
     WlCtx ctx;

@@ -1,0 +1,3 @@
+// libwl_emu.so, unit 'api': the same kernel bodies and C ABI as the matching unit of libwavelets_hip.so, executed on the host.
+#include "wl_backend_emu.h"
+#include "../../pytorch_wavelets_amd/csrc/wl_api.inc"

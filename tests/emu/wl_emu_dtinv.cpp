@@ -1,0 +1,4 @@
+// libwl_emu.so, unit 'dtinv': the same kernel bodies and C ABI as the matching unit of libwavelets_hip.so, executed on the host.
+#include "wl_backend_emu.h"
+#include "../../pytorch_wavelets_amd/csrc/wl_dtinv_api.inc"
+#include "../../pytorch_wavelets_amd/csrc/wl_dwt1d_api.inc"

@@ -16,7 +16,7 @@ _H = None
 def handle():
     global _H
     if _H is None:
-        srcs = [os.path.join(_DIR, f) for f in ('wl_emu.cpp', 'wl_backend_emu.h')]
+        srcs = [os.path.join(_DIR, f) for f in os.listdir(_DIR) if f.endswith(('.cpp', '.h', '.sh'))]
         csrc = os.path.join(os.path.dirname(_DIR), '..', 'pytorch_wavelets_amd', 'csrc')
         srcs += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(('.h', '.inc'))]
         if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):

@@ -388,7 +388,9 @@ def test_grayscale_channels_last_strides_are_not_trusted(fused):
 STRIP_CASES = [('db4', 'symmetric', (2, 1, 64, 64)), ('db4', 'zero', (1, 2, 40, 72)), ('db8', 'periodization', (1, 1, 64, 128)),
                ('db2', 'reflect', (1, 1, 33, 48)), ('db3', 'periodic', (1, 1, 50, 64)), ('haar', 'zero', (1, 1, 16, 16)),
                ('db8', 'periodization', (1, 1, 37, 1024)), ('db10', 'symmetric', (1, 1, 70, 600)), ('db6', 'periodization', (1, 1, 37, 96)),
-               ('db4', 'symmetric', (1, 1, 300, 1320)), ('db7', 'reflect', (1, 1, 64, 256)), ('db9', 'zero', (1, 1, 64, 256))]
+               ('db4', 'symmetric', (1, 1, 300, 1320)), ('db7', 'reflect', (1, 1, 64, 256)), ('db9', 'zero', (1, 1, 64, 256)),
+               # wide strips that start inside the row / wrap: odd widths, tails of 1-3 columns
+               ('db5', 'reflect', (1, 1, 24, 1323)), ('db8', 'periodic', (1, 1, 24, 1100)), ('db2', 'symmetric', (1, 1, 12, 2050))]
 
 
 @pytest.mark.parametrize('wave,mode,shape', STRIP_CASES)

@@ -44,6 +44,51 @@ def test_swt_second_level_is_the_dilated_bank_on_ll_and_bad_modes_raise():
     assert np.abs(y[0].numpy() - o1).max() < 1e-12 and np.abs(y[1].numpy() - o2).max() < 1e-12
 
 
+SWT_KERNEL_CASES = [('db2', 'periodic', 1, (1, 2, 20, 24), torch.float64), ('db2', 'symmetric', 2, (2, 1, 37, 70), torch.float32),
+                    ('db4', 'reflect', 4, (1, 1, 45, 130), torch.float32), ('haar', 'zero', 1, (1, 3, 5, 7), torch.float32),
+                    ('db3', 'replicate', 2, (1, 2, 33, 65), torch.float16), ('db7', 'constant', 1, (1, 1, 40, 64), torch.float32),
+                    ('db10', 'symmetric', 2, (1, 1, 36, 30), torch.float32), ('db4', 'symmetric', 2, (1, 1, 36, 30), torch.float64), ('db5', 'periodic', 3, (1, 1, 16, 200), torch.float32)]
+
+
+@pytest.mark.parametrize('wave,mode,dil,shape,dtype', SWT_KERNEL_CASES)
+def test_swt_level_kernel_vs_oracle(wave, mode, dil, shape, dtype):
+    """wl_swt2d_level (csrc/wl_swt2d.h: one launch per level) against the oracle: every pad mode of the reference's mypad,
+    dilations 1-4 (3: an odd one), tiles with ragged edges, compile-time and run-time tap counts (db7 = 14 taps), the three
+    storage types, and the ll channels of a previous level as a strided view (no copy)."""
+    import pytorch_wavelets_amd as pw
+    from pytorch_wavelets_amd import filters
+    from pytorch_wavelets_amd.dwt import lowlevel as ll
+    rng = np.random.RandomState(11)
+    h0, h1 = filters.dwt_analysis_taps(wave)
+    N, C, H, W = shape
+    big = rng.randn(N, 4 * C, H, W)
+    tol = {torch.float64: 1e-12, torch.float32: 2e-6, torch.float16: 3e-3}[dtype]
+    with emu_backend.emulated():
+        filts = tuple(torch.tensor(np.asarray(v)) for v in (h0, h1, h0, h1))          # the stored (reversed) taps, as tensors
+        xb = torch.tensor(big).to(dtype)
+        for x in (xb[:, :C].contiguous(), xb[:, 0::4]):                  # dense planes; every 4th plane of a level's output
+            c0 = pw.launch_count()
+            y = ll.afb2d_atrous(x, filts, mode, dil)
+            assert pw.kernels_since(c0)[0].startswith('WlSwtLevel'), pw.kernels_since(c0)
+            ref = wo.afb2d_atrous(x.double().numpy(), h0, h1, h0, h1, 'zero' if mode == 'constant' else mode, dil)
+            assert y.shape == ref.shape and y.dtype == dtype
+            assert np.abs(y.double().numpy() - ref).max() <= tol * max(1.0, np.abs(ref).max())
+
+
+def test_swt_level_kernel_declines_what_it_does_not_cover():
+    """Dilated filters too long for a tile in LDS run on the single-axis kernels, with the same result."""
+    import pytorch_wavelets_amd as pw
+    from pytorch_wavelets_amd import filters
+    from pytorch_wavelets_amd.dwt import lowlevel as ll
+    h0, h1 = filters.dwt_analysis_taps('db10')
+    x = np.random.RandomState(2).randn(1, 1, 24, 40)
+    with emu_backend.emulated():
+        c0 = pw.launch_count()
+        y = ll.afb2d_atrous(torch.tensor(x), tuple(torch.tensor(np.asarray(v)) for v in (h0, h1, h0, h1)), 'periodic', 8)
+        assert not any(k.startswith('WlSwtLevel') for k in pw.kernels_since(c0))
+    assert np.abs(y.numpy() - wo.afb2d_atrous(x, h0, h1, h0, h1, 'periodic', 8)).max() < 1e-11
+
+
 @pytest.mark.parametrize('name', E.NONSEP_CASES)
 def test_nonseparable_banks(name):
     with emu_backend.emulated():

@@ -22,6 +22,36 @@ def test_swt_level_and_dilated_bank(name):
     E.check_swt(name, DEV, torch.float32, 1e-5)
 
 
+@pytest.mark.parametrize('wave,mode,dil,shape,dtype', [('db2', 'periodic', 2, (3, 2, 131, 200), torch.float32),
+                                                       ('db4', 'symmetric', 4, (2, 3, 256, 256), torch.float32),
+                                                       ('db3', 'replicate', 1, (2, 2, 70, 330), torch.float16),
+                                                       ('db7', 'reflect', 2, (1, 2, 96, 129), torch.float64)])
+def test_swt_level_kernel_vs_oracle_and_single_axis_path(wave, mode, dil, shape, dtype):
+    """wl_swt2d_level (one launch per level, csrc/wl_swt2d.h) through the C ABI: against the oracle and against the
+    single-axis path it replaces, on dense planes and on the ll channels of a previous level (a strided view)."""
+    import pytorch_wavelets_amd as pw
+    from pytorch_wavelets_amd import filters
+    from pytorch_wavelets_amd.dwt import lowlevel as dwl
+    h0, h1 = filters.dwt_analysis_taps(wave)
+    N, C, H, W = shape
+    torch.manual_seed(4)
+    xb = torch.randn(N, 4 * C, H, W, device=DEV).to(dtype)
+    filts = tuple(torch.tensor(np.asarray(v), device=DEV) for v in (h0, h1, h0, h1))
+    tol = {torch.float64: 1e-11, torch.float32: 1e-5, torch.float16: 3e-3}[dtype]
+    for x in (xb[:, :C].contiguous(), xb[:, 0::4]):
+        c0 = pw.launch_count()
+        y = dwl.afb2d_atrous(x, filts, mode, dil)
+        assert pw.kernels_since(c0)[0].startswith('WlSwtLevel'), pw.kernels_since(c0)
+        ref = wo.afb2d_atrous(x.double().cpu().numpy(), h0, h1, h0, h1, mode, dil)
+        assert np.abs(y.double().cpu().numpy() - ref).max() <= tol * max(1.0, np.abs(ref).max())
+        dwl.FUSED_LEVELS = False
+        try:
+            y2 = dwl.afb2d_atrous(x, filts, mode, dil)
+        finally:
+            dwl.FUSED_LEVELS = True
+        assert float((y.double() - y2.double()).abs().max()) <= tol * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize('name', E.NONSEP_CASES)
 def test_nonseparable_banks(name):
     E.check_nonsep(name, DEV, torch.float32, 1e-5)
