@@ -261,6 +261,18 @@ int wl_corr1d(const void* x, void* y0, void* y1, int dtype, int64_t outer, int n
               int K, const void* h0, const void* h1, int tap_offset, int tap_stride, int ntaps, int start, int step,
               int tap_step, int ext, int out_offset, int out_stride, void* stream);
 
+/* Level 1 of the rotationally symmetric DTCWT (biort 'near_sym_b_bp': a third, band-pass pair for the diagonal sub-band)
+ * in ONE launch (csrc/wl_dtcwt_rot.h) = fwd_j1_rot (dtcwt/transform_funcs.py:124-149: three rowfilter, four colfilter,
+ * three q2c, two stack), orientations along dim 1 as ScatLayerj1_rot_f uses it (scatternet/lowlevel.py:140-182):
+ *   scat == 0: x (N,C,H,W) -> ll (N,C,H,W), re / im (N,6,C,H/2,W/2);
+ *   scat == 1: x -> re = Z (N,7,C,H/2,W/2): Z[:,0] = the 2x2 average of ll, Z[:,1+o] = sqrt(re_o^2 + im_o^2 + b^2) - b
+ *              (ScatLayerj1_rot_f.forward without combine_colour; ll and im unused).
+ * h0 / h1 / h2: odd lengths up to 19; mode 1 = symmetric extension, anything else zero padding (dtcwt/lowlevel.py:75-79);
+ * even H and W (the modules pad first), else WL_ERR_UNSUPPORTED: callers then chain wl_corr1d. */
+int wl_dtcwt_fwd_level1_rot(const void* x, void* ll, void* re, void* im, int dtype, int64_t N, int C, int H, int W,
+                            const void* h0, int L0, const void* h1, int L1, const void* h2, int L2, int mode,
+                            int scat, double magbias, void* stream);
+
 /* One level of the 2-D stationary (undecimated) transform in ONE launch (csrc/wl_swt2d.h) = afb2d_atrous
  * (dwt/lowlevel.py:475-521: afb1d_atrous :175-223 along W, then along H; the level of SWTForward.forward,
  * dwt/transform2d.py:186-212): x (planes,H,W) through the plane stride x_ps (elements; rows dense - the ll channels of a

@@ -298,6 +298,9 @@ class INV_J21(Function):
 # the fused hot path: each level is the reference's own decomposition into seven single-axis filters, every one a
 # launch of the engine's correlation kernel (dtcwt/lowlevel.py here), plus q2c / c2q index shuffles.
 # ---------------------------------------------------------------------------------------------------------------------
+FUSED_ROT = True   # level 1 of the band-pass variants in one launch (False: the seven single-axis filters; A/B measurements)
+
+
 def highs_to_orientations(lh, hl, hh, o_dim):
     """Three quad sub-bands -> six orientations 15..165 degrees, stacked along o_dim (reference :61-73)."""
     from .lowlevel import q2c
@@ -324,6 +327,10 @@ def fwd_j1_rot(x, h0, h1, h2, skip_hps, o_dim, mode):
     from .lowlevel import colfilter, rowfilter
     if skip_hps:
         return colfilter(rowfilter(x, h0, mode), h0, mode), x.new_zeros([]), x.new_zeros([])
+    if o_dim == 1 and FUSED_ROT:
+        res = ops.dtcwt_fwd1_rot(x, h0, h1, h2, mode == 'symmetric')      # one launch (csrc/wl_dtcwt_rot.h)
+        if res is not None:
+            return res
     lo = rowfilter(x, h0, mode)
     hi = rowfilter(x, h1, mode)
     ba = rowfilter(x, h2, mode)

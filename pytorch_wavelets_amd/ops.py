@@ -687,6 +687,37 @@ def dtcwt_fwd1(x, h0, h1, mode, skip_hps=False):
     return ll, highs
 
 
+def dtcwt_fwd1_rot(x, h0, h1, h2, symmetric, scat=False, magbias=0.0):
+    """Level 1 with the band-pass diagonal in one launch (wl_dtcwt_fwd_level1_rot): x (N,C,H,W) -> (ll (N,C,H,W),
+    re (N,6,C,H/2,W/2), im) - or, scat=True, Z (N,7,C,H/2,W/2) of ScatLayerj1_rot_f.forward.  None when the kernel does
+    not cover the configuration (odd sizes, filters longer than 19 taps): callers chain the single-axis filters."""
+    _check_tensor(x, 'x')
+    if x.dim() != 4 or x.numel() == 0:
+        return None
+    N, C, H, W = x.shape
+    key = ('dtrot', x.device, x.dtype, H, W, h0.numel(), h1.numel(), h2.numel())
+    if key in _FUSED_DECLINED:
+        return None
+    x = x.contiguous()
+    t0, t1, t2 = _taps(h0, x), _taps(h1, x), _taps(h2, x)
+    h2_, w2_ = H // 2, W // 2
+    if scat:
+        ll = im = None
+        re = torch.empty((N, 7, C, h2_, w2_), dtype=x.dtype, device=x.device)
+    else:
+        ll = torch.empty((N, C, H, W), dtype=x.dtype, device=x.device)
+        re = torch.empty((N, 6, C, h2_, w2_), dtype=x.dtype, device=x.device)
+        im = torch.empty_like(re)
+    rc = _call('wl_dtcwt_fwd_level1_rot', x, x.data_ptr(), None if ll is None else ll.data_ptr(), re.data_ptr(),
+               None if im is None else im.data_ptr(), _DTYPES[x.dtype], N, C, H, W, t0.data_ptr(), t0.numel(), t1.data_ptr(),
+               t1.numel(), t2.data_ptr(), t2.numel(), 1 if symmetric else 0, 1 if scat else 0, float(magbias), _stream(x))
+    if rc == -3:
+        _remember_decline(key)
+        return None
+    _lib.check(rc, 'wl_dtcwt_fwd_level1_rot')
+    return re if scat else (ll, re, im)
+
+
 def dtcwt_fwd12(x, h0o, h1o, h0a, h0b, h1a, h1b, mode, force=False):
     """Levels 1 and 2 of the forward in one launch (wl_dtcwt_fwd_level12: the level-1 lowpass stays on chip):
     x (N,C,H,W) -> (highs1 (N,C,6,H/2,W/2,2), ll2 (N,C,H/2,W/2), highs2 (N,C,6,H/4,W/4,2)), or None when the engine

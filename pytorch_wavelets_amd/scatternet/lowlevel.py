@@ -129,7 +129,13 @@ def scat_layer_j2(x, h0o, h1o, h0a, h0b, h1a, h1b, mode, bias, combine_colour):
 def scat_layer_j1_rot(x, h0o, h1o, h2o, mode, bias, combine_colour):
     """ScatLayerj1_rot_f (reference scatternet/lowlevel.py:140-203): the ScatLayer with the rotationally symmetric
     13/19-tap filters (third band-pass pair for the diagonals), as a chain of differentiable pieces."""
+    from ..dtcwt import transform_funcs as _tf
     from ..dtcwt.transform_funcs import FWD_J1_ROT
+    if _tf.FUSED_ROT and not combine_colour and not (torch.is_grad_enabled() and x.requires_grad):
+        # inference: the averaged lowpass and the magnitudes come out of the same launch (wl_dtcwt_fwd_level1_rot, scat = 1)
+        z = ops.dtcwt_fwd1_rot(x, h0o, h1o, h2o, int_to_mode(mode) == 'symmetric', scat=True, magbias=bias)
+        if z is not None:
+            return z
     ll, reals, imags = FWD_J1_ROT.apply(x, h0o, h1o, h2o, mode)
     ll = F.avg_pool2d(ll, 2)
     if combine_colour:

@@ -5,6 +5,7 @@ import numpy as np
 import torch
 
 import _golden as G
+from oracle import wavelet_oracle as wo
 import pytorch_wavelets_amd as pw
 from pytorch_wavelets_amd import filters
 from pytorch_wavelets_amd.dtcwt import lowlevel as dtl
@@ -149,6 +150,24 @@ def check_rot(name, dev, dtype, tol):
     assert G.relerr(Z.detach().cpu().numpy(), g, 'Z') < tol
     dx, = torch.autograd.grad((Z * _t(g['gz'], dev, dtype)).sum(), x)
     assert G.relerr(dx.cpu().numpy(), g, 'dx') < tol
+    with torch.no_grad():
+        assert G.relerr(m(x.detach()).cpu().numpy(), g, 'Z') < tol   # no-grad path (ScatLayer: magnitudes from the same launch)
+
+
+def rot_level1_reference(x, h0, h1, h2, mode):
+    """fwd_j1_rot (reference dtcwt/transform_funcs.py:124-149) from the oracle's single-axis filters: ll (N,C,H,W) and the six
+    orientations (N,6,C,H/2,W/2) as (real, imaginary)."""
+    lo, hi, ba = (wo.rowfilter(x, h, mode) for h in (h0, h1, h2))
+    ll, lh, hl, hh = wo.colfilter(lo, h0, mode), wo.colfilter(lo, h1, mode), wo.colfilter(hi, h0, mode), wo.colfilter(ba, h2, mode)
+
+    def q2c(y):
+        y = y / np.sqrt(2)
+        a, b, c, d = y[:, :, 0::2, 0::2], y[:, :, 0::2, 1::2], y[:, :, 1::2, 0::2], y[:, :, 1::2, 1::2]
+        return (a - d, b + c), (a + d, b - c)
+    (r15, i15), (r165, i165) = q2c(lh)
+    (r45, i45), (r135, i135) = q2c(hh)
+    (r75, i75), (r105, i105) = q2c(hl)
+    return ll, np.stack([r15, r45, r75, r105, r135, r165], 1), np.stack([i15, i45, i75, i105, i135, i165], 1)
 
 
 DWT1D_CASES = sorted(k for k, v in G.INDEX.items() if v['kind'] == 'dwt1d')

@@ -89,6 +89,38 @@ def test_swt_level_kernel_declines_what_it_does_not_cover():
     assert np.abs(y.numpy() - wo.afb2d_atrous(x, h0, h1, h0, h1, 'periodic', 8)).max() < 1e-11
 
 
+@pytest.mark.parametrize('mode,shape,dtype', [('symmetric', (2, 3, 70, 134), torch.float32), ('zero', (1, 2, 36, 66), torch.float64),
+                                              ('symmetric', (1, 1, 20, 18), torch.float16), ('symmetric', (1, 2, 34, 64), torch.float64)])
+def test_rot_level1_kernel_vs_oracle(mode, shape, dtype):
+    """wl_dtcwt_fwd_level1_rot (csrc/wl_dtcwt_rot.h: the seven single-axis filters + q2c of fwd_j1_rot in one launch) against
+    the oracle's single-axis filters: both pad modes, ragged tiles, the (N, 6, C, h, w) layout for several planes, and the
+    ScatLayer epilogue (scat = 1) against the magnitudes computed from the oracle's coefficients."""
+    import pytorch_wavelets_amd as pw
+    from pytorch_wavelets_amd import filters, ops
+    from pytorch_wavelets_amd.dtcwt import lowlevel as dl
+    from pytorch_wavelets_amd.dtcwt import transform_funcs as tf
+    h0o, _, h1o, _, h2o, _ = filters.biort('near_sym_b_bp')
+    x = np.random.RandomState(8).randn(*shape)
+    tol = {torch.float64: 1e-12, torch.float32: 3e-6, torch.float16: 4e-3}[dtype]
+    h = [dl.prep_filt(v, 1).to(torch.float64) for v in (h0o, h1o, h2o)]
+    hn = [v.numpy().ravel() for v in h]
+    ll, re, im = E.rot_level1_reference(x if dtype != torch.float16 else x.astype(np.float16).astype(np.float64), *hn, mode)
+    with emu_backend.emulated():
+        xt = torch.tensor(x).to(dtype)
+        c0 = pw.launch_count()
+        l2, r2, i2 = tf.fwd_j1_rot(xt, *h, False, 1, mode)
+        assert pw.kernels_since(c0) == ['WlDtFwd1Rot<%s, 0>' % {torch.float64: 'double', torch.float32: 'float', torch.float16: '_Float16'}[dtype]]
+        for got, want in ((l2, ll), (r2, re), (i2, im)):
+            assert got.shape == want.shape and got.dtype == dtype
+            assert np.abs(got.double().numpy() - want).max() <= tol * max(1.0, np.abs(want).max())
+        z = ops.dtcwt_fwd1_rot(xt, *h, mode == 'symmetric', scat=True, magbias=0.01)
+        pool = ll.reshape(ll.shape[0], ll.shape[1], ll.shape[2] // 2, 2, ll.shape[3] // 2, 2).mean(axis=(3, 5))
+        want = np.concatenate([pool[:, None], np.sqrt(re ** 2 + im ** 2 + 1e-4) - 0.01], 1)
+        assert z.shape == want.shape and np.abs(z.double().numpy() - want).max() <= tol * max(1.0, np.abs(want).max())
+        # odd sizes: declined (the modules pad first), the single-axis path answers
+        assert ops.dtcwt_fwd1_rot(torch.randn(1, 1, 9, 8).to(dtype), *h, True) is None
+
+
 @pytest.mark.parametrize('name', E.NONSEP_CASES)
 def test_nonseparable_banks(name):
     with emu_backend.emulated():

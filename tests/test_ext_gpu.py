@@ -52,6 +52,43 @@ def test_swt_level_kernel_vs_oracle_and_single_axis_path(wave, mode, dil, shape,
         assert float((y.double() - y2.double()).abs().max()) <= tol * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize('mode,shape,dtype', [('symmetric', (3, 2, 130, 200), torch.float32), ('zero', (2, 3, 64, 64), torch.float32),
+                                              ('symmetric', (2, 2, 96, 258), torch.float16), ('symmetric', (1, 2, 50, 66), torch.float64)])
+def test_rot_level1_kernel_vs_oracle_and_single_axis_path(mode, shape, dtype):
+    """wl_dtcwt_fwd_level1_rot (one launch, csrc/wl_dtcwt_rot.h) through the C ABI: against the oracle's single-axis filters and
+    against the seven-launch path it replaces; the ScatLayer epilogue (scat = 1) against the module's differentiable chain."""
+    import pytorch_wavelets_amd as pw
+    from pytorch_wavelets_amd import filters
+    from pytorch_wavelets_amd.dtcwt import lowlevel as dl
+    from pytorch_wavelets_amd.dtcwt import transform_funcs as tf
+    h0o, _, h1o, _, h2o, _ = filters.biort('near_sym_b_bp')
+    torch.manual_seed(6)
+    x = torch.randn(*shape, device=DEV).to(dtype)
+    h = [dl.prep_filt(v, 1).to(DEV).to(torch.float64) for v in (h0o, h1o, h2o)]
+    tol = {torch.float64: 1e-11, torch.float32: 1e-5, torch.float16: 4e-3}[dtype]
+    want = E.rot_level1_reference(x.double().cpu().numpy(), *[v.cpu().numpy().ravel() for v in h], mode)
+    c0 = pw.launch_count()
+    got = tf.fwd_j1_rot(x, *h, False, 1, mode)
+    assert pw.kernels_since(c0)[0].startswith('WlDtFwd1Rot'), pw.kernels_since(c0)
+    tf.FUSED_ROT = False
+    try:
+        old = tf.fwd_j1_rot(x, *h, False, 1, mode)
+    finally:
+        tf.FUSED_ROT = True
+    for g, w, o in zip(got, want, old):
+        scale = max(1.0, np.abs(w).max())
+        assert np.abs(g.double().cpu().numpy() - w).max() <= tol * scale
+        assert float((g.double() - o.double()).abs().max()) <= 2 * tol * scale
+    if dtype != torch.float64:
+        m = pw.ScatLayer(biort='near_sym_b_bp', mode=mode).to(DEV).to(dtype)
+        with torch.no_grad():
+            c0 = pw.launch_count()
+            z = m(x)
+            assert pw.kernels_since(c0) == ['WlDtFwd1Rot<%s, 1>' % ('float' if dtype == torch.float32 else '_Float16')]
+        z2 = m(x.clone().requires_grad_(True))                       # the differentiable chain (kernel + tensor-library magnitudes)
+        assert float((z.float() - z2.float()).abs().max()) <= 2 * tol * max(1.0, float(z2.float().abs().max()))
+
+
 @pytest.mark.parametrize('name', E.NONSEP_CASES)
 def test_nonseparable_banks(name):
     E.check_nonsep(name, DEV, torch.float32, 1e-5)
