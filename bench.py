@@ -534,13 +534,19 @@ def time_seq_fn(fn, n, sync, prefill_ms=4.0):
     for _ in range(10):
         fn()
     sync()
-    prefill(prefill_ms)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
+    was_on = gc.isenabled()      # (the probes under tools/ call this outside main(): a full collection inside a 20-call loop
+    gc.disable()                 # reads as 2 ms per call - round 4 chased that through four GPU calls)
+    try:
+        prefill(prefill_ms)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+    finally:
+        if was_on:
+            gc.enable()
     return e0.elapsed_time(e1) / n
 
 
@@ -625,8 +631,11 @@ def other_configs(pw, dev, sync):
         t2 = time_seq_fn(lambda: s2(xs2), 20, sync)
         sr = pw.ScatLayer(biort='near_sym_b_bp').to(dev)
         tr = time_seq_fn(lambda: sr(xs2), 20, sync)
-        other['scatlayerj2_64x3x256x256_fp32'] = {'fwd_ms': round(t2, 4), 'mpix_s': round(xs2.numel() / t2 / 1e3, 1)}
-        other['scatlayer_rot_near_sym_b_bp_64x3x256x256_fp32'] = {'fwd_ms': round(tr, 4), 'mpix_s': round(xs2.numel() / tr / 1e3, 1)}
+        other['scatlayerj2_64x3x256x256_fp32'] = {'fwd_ms': round(t2, 4), 'mpix_s': round(xs2.numel() / t2 / 1e3, 1),
+                                                  'fwd_kernels': names(lambda: s2(xs2))}
+        other['scatlayer_rot_near_sym_b_bp_64x3x256x256_fp32'] = {
+            'fwd_ms': round(tr, 4), 'mpix_s': round(xs2.numel() / tr / 1e3, 1),
+            'frac_of_hbm_peak_at_11B_per_px': frac(11 * xs2.numel(), tr), 'fwd_kernels': names(lambda: sr(xs2))}
         del xs, xs2
         # f3: 1-D DWT and the stationary transform (generic single-axis kernels)
         x1 = torch.randn(64, 16, 65536, device=dev)
@@ -639,10 +648,13 @@ def other_configs(pw, dev, sync):
         xw = torch.randn(16, 3, 512, 512, device=dev)
         sw = SWTForward(J=2, wave='db2', mode='periodic').to(dev)
         tw = time_seq_fn(lambda: sw(xw), 20, sync)
-        other['swt_j2_db2_periodic_16x3x512x512_fp32'] = {'fwd_ms': round(tw, 4), 'mpix_s': round(xw.numel() / tw / 1e3, 1)}
+        other['swt_j2_db2_periodic_16x3x512x512_fp32'] = {'fwd_ms': round(tw, 4), 'mpix_s': round(xw.numel() / tw / 1e3, 1),
+                                                          'frac_of_hbm_peak_at_20B_per_px_and_level': frac(2 * 20 * xw.numel(), tw),
+                                                          'fwd_kernels': names(lambda: sw(xw))}
         del xw
         # outside the fused streaming envelope of round 2: wider images, longer filters
         for tag, shape, wave, L in (('dwt_j3_db4_16x3x1024x1024_fp32', (16, 3, 1024, 1024), 'db4', 8),
+                                    ('dwt_j3_db4_64x3x1024x1024_fp32', (64, 3, 1024, 1024), 'db4', 8),
                                     ('dwt_j3_db8_128x3x512x512_fp32', (128, 3, 512, 512), 'db8', 16)):
             xl = torch.randn(*shape, device=dev)
             fx, fi = pw.DWTForward(J=3, wave=wave, mode='symmetric').to(dev), pw.DWTInverse(wave=wave, mode='symmetric').to(dev)
