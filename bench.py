@@ -652,6 +652,15 @@ def other_configs(pw, dev, sync):
                                                           'frac_of_hbm_peak_at_20B_per_px_and_level': frac(2 * 20 * xw.numel(), tw),
                                                           'fwd_kernels': names(lambda: sw(xw))}
         del xw
+        # CNN-feature-map shapes (many small planes): the several-planes-per-workgroup kernels of round 4 (csrc/wl_dwt_small.h)
+        xm = torch.randn(512, 16, 32, 32, device=dev)
+        fm, im = pw.DWTForward(J=2, wave='db2', mode='symmetric').to(dev), pw.DWTInverse(wave='db2', mode='symmetric').to(dev)
+        cm = fm(xm)
+        tfm, tim = time_seq_fn(lambda: fm(xm), 30, sync), time_seq_fn(lambda: im(cm), 30, sync)
+        bm = algorithmic_bytes_fwd(512, 16, 32, 32, 2, 4, 4)
+        other['dwt_j2_db2_512x16x32x32_fp32'] = {'fwd_ms': round(tfm, 4), 'inv_ms': round(tim, 4), 'fwd_frac': frac(bm, tfm), 'inv_frac': frac(bm, tim),
+                                                 'fwd_kernels': names(lambda: fm(xm)), 'inv_kernels': names(lambda: im(cm))}
+        del xm, cm
         # outside the fused streaming envelope of round 2: wider images, longer filters
         for tag, shape, wave, L in (('dwt_j3_db4_16x3x1024x1024_fp32', (16, 3, 1024, 1024), 'db4', 8),
                                     ('dwt_j3_db4_64x3x1024x1024_fp32', (64, 3, 1024, 1024), 'db4', 8),

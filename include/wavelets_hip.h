@@ -261,6 +261,25 @@ int wl_corr1d(const void* x, void* y0, void* y1, int dtype, int64_t outer, int n
               int K, const void* h0, const void* h1, int tap_offset, int tap_stride, int ntaps, int start, int step,
               int tap_step, int ext, int out_offset, int out_stride, void* stream);
 
+/* nlev (1..4) analysis levels of SMALL planes (up to about 72 x 72: CNN feature maps, CIFAR-sized images) in ONE launch with
+ * several planes per workgroup (csrc/wl_dwt_small.h) = the level loop of DWTForward.forward (dwt/transform2d.py:63-74) where
+ * the streaming kernel of wl_dwt2d_analysis_fused would give each 32 x 32 plane a workgroup of its own.  Same contract as
+ * wl_dwt2d_analysis_fused (x (planes,H,W) dense -> yl, yh[j] (planes,3,Kh_j,Kw_j), sizes by wl_dwt_coeff_len); every mode,
+ * up to 20 taps, any sizes, float32 / float16.  WL_ERR_UNSUPPORTED: larger planes, float64, a periodization level shorter
+ * than the filter. */
+int wl_dwt2d_analysis_small(const void* x, void* yl, void* const* yh, int dtype, int64_t planes, int H, int W, int nlev,
+                            const void* h_w_lo, const void* h_w_hi, const void* h_h_lo, const void* h_h_hi, int L, int mode,
+                            void* stream);
+
+/* The inverse of the above: nlev (1..4) synthesis levels of small planes in ONE launch, several planes per workgroup
+ * (csrc/wl_dwt_small.h) = the level loop of DWTInverse.forward (dwt/transform2d.py:131-148 incl. the 'unpad' crop of
+ * :141-146) and the backward of the analysis (AFB2D.backward, dwt/lowlevel.py:350-365, with the analysis taps).  yl
+ * (planes,yl_h,yl_w) dense, yh[j] (planes,3,Kh[j],Kw[j]) finest first (NULL = zeros), y (planes,OH,OW) with OH = 2 Kh[0] - L + 2
+ * (2 Kh[0] for periodization); the caller crops.  Same envelope and declines as wl_dwt2d_analysis_small; even L. */
+int wl_dwt2d_synthesis_small(const void* yl, int yl_h, int yl_w, const void* const* yh, const int* Kh, const int* Kw, void* y,
+                             int dtype, int64_t planes, int nlev, const void* g_w_lo, const void* g_w_hi, const void* g_h_lo,
+                             const void* g_h_hi, int L, int mode, void* stream);
+
 /* Level 1 of the rotationally symmetric DTCWT (biort 'near_sym_b_bp': a third, band-pass pair for the diagonal sub-band)
  * in ONE launch (csrc/wl_dtcwt_rot.h) = fwd_j1_rot (dtcwt/transform_funcs.py:124-149: three rowfilter, four colfilter,
  * three q2c, two stack), orientations along dim 1 as ScatLayerj1_rot_f uses it (scatternet/lowlevel.py:140-182):

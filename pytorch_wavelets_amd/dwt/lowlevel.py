@@ -109,10 +109,13 @@ class SFB2DMulti(Function):
         ll_shapes = [None] * J          # the low-pass handed to level j, before the 'unpad'
         ll, j = yl, J - 1
         while j >= 0:
-            n = 0                       # levels j, j-1, .. that the streaming kernel can take together
-            while n < 3 and j - n >= 0 and yh[j - n] is not None:
+            n = 0                       # levels j, j-1, .. that one launch can take together
+            while n < 4 and j - n >= 0 and yh[j - n] is not None:
                 n += 1
-            res = None
+            # small planes (CNN feature maps): several planes per workgroup, up to four levels in LDS
+            res = ops.sfb2d_small(ll, list(yh[j - n + 1:j + 1]), g0_row, g1_row, g0_col, g1_col, mode) if FUSED_LEVELS and n else None
+            if res is None:
+                n = min(n, 3)
             while FUSED_LEVELS and n >= 1 and res is None:
                 res = ops.sfb2d_fused(ll, list(yh[j - n + 1:j + 1]), g0_row, g1_row, g0_col, g1_col, mode)
                 if res is None:
@@ -122,7 +125,8 @@ class SFB2DMulti(Function):
                 sh = tuple(ll.shape[-2:])
                 for i in range(j, j - n, -1):
                     ll_shapes[i] = sh
-                    sh = (2 * yh[i].shape[-2] - L + 2, 2 * yh[i].shape[-1] - L + 2)
+                    sh = ((2 * yh[i].shape[-2], 2 * yh[i].shape[-1]) if mode == 2
+                          else (2 * yh[i].shape[-2] - L + 2, 2 * yh[i].shape[-1] - L + 2))
                 ll, j = res, j - n
                 continue
             h = yh[j]
@@ -179,8 +183,11 @@ class AFB2DMulti(Function):
         ctx.mode = mode
         shapes, yh, ll, done = [], [], x, 0
         while done < J:
-            n = min(3, J - done)
-            res = None
+            n = min(4, J - done)
+            # small planes (CNN feature maps, CIFAR-sized images): several planes per workgroup, up to four levels in LDS
+            res = ops.afb2d_small(ll, h0_row, h1_row, h0_col, h1_col, mode, n) if FUSED_LEVELS else None
+            if res is None:
+                n = min(3, J - done)
             while FUSED_LEVELS and n >= 1 and res is None:   # e.g. periodization: one level per streaming launch
                 res = ops.afb2d_fused(ll, h0_row, h1_row, h0_col, h1_col, mode, n)
                 if res is None:
@@ -209,8 +216,12 @@ class AFB2DMulti(Function):
             while j >= 0:
                 # the crop to the input size of each level is the 'unpad' of the inverse transform: up to three levels
                 # in one launch of the streaming synthesis kernel, the last crop as a view
-                n = min(3, j + 1)
-                res = None
+                n = min(4, j + 1)
+                grp = list(dyh[j - n + 1:j + 1])
+                res = (ops.sfb2d_small(dx, grp, h0_row, h1_row, h0_col, h1_col, ctx.mode)
+                       if FUSED_LEVELS and all(g is not None for g in grp) else None)
+                if res is None:
+                    n = min(3, j + 1)
                 while FUSED_LEVELS and n >= 1 and res is None:
                     grp = list(dyh[j - n + 1:j + 1])
                     ok = all(g is not None for g in grp)

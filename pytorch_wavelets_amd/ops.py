@@ -295,6 +295,78 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None):
     return yl, yh
 
 
+SMALL_PLANES = True   # planes of up to ~72 x 72 go to the several-planes-per-workgroup kernel first (False: A/B measurements)
+
+
+def afb2d_small(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev):
+    """`nlev` (1..4) analysis levels of small planes in ONE launch, several planes per workgroup (wl_dwt2d_analysis_small):
+    x (N,C,H,W) -> (yl, [yh_0..]) like afb2d_fused, or None when the kernel does not cover the configuration."""
+    import ctypes
+    _check_tensor(x, 'x')
+    N, C, H, W = x.shape
+    L = h_w_lo.numel()
+    if (not SMALL_PLANES or FUSED_STRIPS or STREAM_FORCE or x.dtype == torch.float64 or nlev < 1 or nlev > 4 or h_h_lo.numel() != L or L > 20 or x.numel() == 0
+            or H * W > 5184 or mode not in _MODE_TO_EXT):
+        return None
+    key = ('afbsm', x.device, x.dtype, N * C, H, W, L, mode, nlev)
+    if key in _FUSED_DECLINED:
+        return None
+    x = x.contiguous()
+    hwl, hwh, hhl, hhh = (_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi))
+    yh = []
+    h, w = H, W
+    for _ in range(nlev):
+        h, w = coeff_len(h, L, mode), coeff_len(w, L, mode)
+        yh.append(torch.empty((N, C, 3, h, w), dtype=x.dtype, device=x.device))
+    yl = torch.empty((N, C, h, w), dtype=x.dtype, device=x.device)
+    ptrs = (ctypes.c_void_p * nlev)(*[t.data_ptr() for t in yh])
+    rc = _call('wl_dwt2d_analysis_small', x, x.data_ptr(), yl.data_ptr(), ptrs, _DTYPES[x.dtype], N * C, H, W, nlev,
+               hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(), hhh.data_ptr(), L, mode, _stream(x))
+    if rc == -3:
+        _remember_decline(key)
+        return None
+    _lib.check(rc, 'wl_dwt2d_analysis_small')
+    return yl, yh
+
+
+def sfb2d_small(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode):
+    """All len(yh) (1..4) synthesis levels of small planes in ONE launch, several planes per workgroup
+    (wl_dwt2d_synthesis_small): yl (N,C,h,w), yh = [finest .. coarsest] of (N,C,3,Kh_j,Kw_j) -> x (N,C,OH,OW) like sfb2d_fused,
+    or None when the kernel does not cover the configuration."""
+    import ctypes
+    _check_tensor(yl, 'yl')
+    nlev = len(yh)
+    N, C, h, w = yl.shape
+    L = g_w_lo.numel()
+    if (not SMALL_PLANES or FUSED_STRIPS or STREAM_FORCE or yl.dtype == torch.float64 or nlev < 1 or nlev > 4
+            or g_h_lo.numel() != L or L % 2 or L > 20 or yl.numel() == 0 or mode not in _MODE_TO_EXT
+            or any(t is None or t.dim() != 5 or t.dtype != yl.dtype or t.shape[:3] != (N, C, 3) or t.numel() == 0 for t in yh)):
+        return None
+    kh0, kw0 = yh[0].shape[3], yh[0].shape[4]
+    OH, OW = (2 * kh0, 2 * kw0) if mode == 2 else (2 * kh0 - L + 2, 2 * kw0 - L + 2)
+    if OH < 1 or OW < 1 or OH * OW > 5184:
+        return None
+    key = ('sfbsm', yl.device, yl.dtype, N * C, h, w, tuple(tuple(t.shape[3:]) for t in yh), L, mode)
+    if key in _FUSED_DECLINED:
+        return None
+    yl = yl.contiguous()
+    yh = [t.contiguous() for t in yh]
+    for t in yh:
+        _same_device(yl, t)
+    gwl, gwh, ghl, ghh = (_taps(g, yl) for g in (g_w_lo, g_w_hi, g_h_lo, g_h_hi))
+    y = torch.empty((N, C, OH, OW), dtype=yl.dtype, device=yl.device)
+    ptrs = (ctypes.c_void_p * nlev)(*[t.data_ptr() for t in yh])
+    khs = (ctypes.c_int * nlev)(*[t.shape[3] for t in yh])
+    kws = (ctypes.c_int * nlev)(*[t.shape[4] for t in yh])
+    rc = _call('wl_dwt2d_synthesis_small', yl, yl.data_ptr(), h, w, ptrs, khs, kws, y.data_ptr(), _DTYPES[yl.dtype], N * C, nlev,
+               gwl.data_ptr(), gwh.data_ptr(), ghl.data_ptr(), ghh.data_ptr(), L, mode, _stream(yl))
+    if rc == -3:
+        _remember_decline(key)
+        return None
+    _lib.check(rc, 'wl_dwt2d_synthesis_small')
+    return y
+
+
 def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
     """All len(yh) (1..3) synthesis levels in ONE launch of the streaming kernel: yl (N,C,h,w) [may be a strided crop],
     yh = [finest .. coarsest] of (N,C,3,Kh_j,Kw_j) -> x (N,C,OH,OW).  The intermediate low-passes never leave the
@@ -429,6 +501,10 @@ def sfb2d_best(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None):
 def afb2d_best(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, pad_ll=False):
     """One analysis level on whichever single-level kernel the engine prefers for the shape: the streaming strip kernel
     (rows of 2 KiB and more, enough workgroups for the chip), else the tile kernels."""
+    if x.dim() == 4:                                                             # small planes: several per workgroup
+        res = afb2d_small(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, 1)
+        if res is not None:
+            return res[0], res[1][0]
     res = afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=STREAM_FORCE)
     return res if res is not None else afb2d(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, pad_ll=pad_ll)
 

@@ -112,6 +112,155 @@ def test_streaming_kernel_fp32_goldens_on_emulator(name, strips):
         assert G.relerr(yh[j].numpy(), g, 'yh%d' % j) < 1e-5
 
 
+@pytest.mark.parametrize('seed', range(8))
+def test_small_plane_kernel_vs_oracle_random_shapes(seed):
+    """wl_dwt2d_analysis_small (csrc/wl_dwt_small.h: several planes per workgroup, up to four levels in LDS) against the
+    oracle: plane sizes 2-70 (odd ones too), every mode incl. periodization, 2-20 taps (compile-time and run-time tap counts),
+    J = 1-4, plane counts that do not divide by the planes per workgroup, float32 and float16; what it declines (planes too
+    large, a periodization level shorter than the filter) never answers wrongly."""
+    from oracle import wavelet_oracle as wo
+    from pytorch_wavelets_amd import filters, ops
+    from pytorch_wavelets_amd.dwt import lowlevel as ll
+    rng = np.random.RandomState(900 + seed)
+    wave = ['haar', 'db2', 'db3', 'db4', 'db5', 'db7', 'db10', 'bior2.2'][seed]
+    h0, h1 = filters.dwt_analysis_taps(wave)
+    L = len(h0)
+    th = [torch.tensor(np.asarray(v), dtype=torch.float32) for v in (h0, h1, h0, h1)]
+    with emu_backend.emulated():
+        for mode in ('zero', 'symmetric', 'reflect', 'periodic', 'periodization'):
+            for rep in range(2):
+                J = int(rng.randint(1, 5))
+                H, W = int(rng.randint(2, 71)), int(rng.randint(2, 71))
+                if rep:
+                    H = W = [8, 16, 32, 64][int(rng.randint(0, 4))]
+                N, C = int(rng.randint(1, 8)), int(rng.randint(1, 6))
+                x = torch.tensor(rng.randn(N, C, H, W), dtype=torch.float32)
+                c0 = pw_launch_count()
+                res = ops.afb2d_small(x, *th, ll.mode_to_int(mode), J)
+                oyl, oyh = wo.dwt_forward(x.double().numpy(), J, h0, h1, h0, h1, mode)
+                if res is None:
+                    # declined (a level shorter than the filter: more than one fold; planes too large): the module answers
+                    # through the other kernels
+                    hh, ww, short = H, W, False
+                    for _ in range(J):
+                        short |= min(hh, ww) < L
+                        hh, ww = ll_len(hh, L, mode), ll_len(ww, L, mode)
+                    assert short or H * W > 4096, (wave, mode, H, W, J)
+                    import pytorch_wavelets_amd as pw
+                    res = pw.DWTForward(J=J, wave=wave, mode=mode).float()(x)
+                yl, yh = res
+                for got, want in zip([yl] + list(yh), [oyl] + list(oyh)):
+                    assert got.shape == want.shape, (wave, mode, H, W, J)
+                    assert np.abs(got.numpy() - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), (wave, mode, H, W, J)
+        # more groups of planes than resident workgroups (the emulated chip has two CUs): a workgroup walks over several groups,
+        # the next one's planes in registers while this one's levels run
+        x = torch.tensor(rng.randn(37, 9, 6, 10), dtype=torch.float32)
+        res = ops.afb2d_small(x, *th, 1, 1)
+        if res is not None:
+            oyl, oyh = wo.dwt_forward(x.double().numpy(), 1, h0, h1, h0, h1, 'symmetric')
+            assert np.abs(res[0].numpy() - oyl).max() <= 2e-5 * max(1.0, np.abs(oyl).max())
+            assert np.abs(res[1][0].numpy() - oyh[0]).max() <= 2e-5 * max(1.0, np.abs(oyh[0]).max())
+        x = torch.tensor(rng.randn(3, 5, 32, 32), dtype=torch.float32).half()
+        res = ops.afb2d_small(x, *th, 1, 2)
+        oyl, oyh = wo.dwt_forward(x.double().numpy(), 2, h0, h1, h0, h1, 'symmetric')
+        for got, want in zip([res[0]] + list(res[1]), [oyl] + list(oyh)):
+            assert got.dtype == torch.float16 and np.abs(got.double().numpy() - want).max() <= 3e-3 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_small_plane_synthesis_kernel_vs_oracle_random_shapes(seed):
+    """wl_dwt2d_synthesis_small against the oracle: the coefficients of a forward transform (so every 'unpad' case occurs), and
+    random coefficient pyramids, every mode incl. periodization, 2-20 taps, J = 1-4, float32 / float16; the module path
+    (DWTInverse, and the gradient of DWTForward = an inverse with the analysis taps) agrees with the per-level path."""
+    from oracle import wavelet_oracle as wo
+    from pytorch_wavelets_amd import filters, ops
+    from pytorch_wavelets_amd.dwt import lowlevel as ll
+    rng = np.random.RandomState(1300 + seed)
+    wave = ['haar', 'db2', 'db3', 'db4', 'db5', 'db7', 'db10', 'bior2.2'][seed]
+    h0, h1 = filters.dwt_analysis_taps(wave)
+    g0, g1 = filters.dwt_synthesis_taps(wave)
+    L = len(g0)
+    tg = [torch.tensor(np.asarray(v), dtype=torch.float32) for v in (g0, g1, g0, g1)]
+    took = 0
+    with emu_backend.emulated():
+        for mode in ('zero', 'symmetric', 'reflect', 'periodic', 'periodization'):
+            for rep in range(2):
+                J = int(rng.randint(1, 5))
+                H, W = int(rng.randint(2 * L, 71)) if 2 * L < 71 else 70, int(rng.randint(max(4, L), 71))
+                if rep:
+                    H = W = [16, 32, 64][int(rng.randint(0, 3))]
+                N, C = int(rng.randint(1, 7)), int(rng.randint(1, 5))
+                x = rng.randn(N, C, H, W)
+                oyl, oyh = wo.dwt_forward(x, J, h0, h1, h0, h1, mode)
+                want = wo.dwt_inverse(oyl, oyh, g0, g1, g0, g1, mode)
+                yl = torch.tensor(oyl, dtype=torch.float32)
+                yh = [torch.tensor(h, dtype=torch.float32) for h in oyh]
+                res = ops.sfb2d_small(yl, yh, *tg, ll.mode_to_int(mode))
+                if res is None:
+                    continue
+                took += 1
+                assert res.shape == want.shape, (wave, mode, H, W, J)
+                assert np.abs(res.numpy() - want).max() <= 3e-5 * max(1.0, np.abs(want).max()), (wave, mode, H, W, J)
+        assert took >= 3
+        # float16 storage, a None level through the module, and the gradient of the forward transform
+        import pytorch_wavelets_amd as pw
+        x = torch.tensor(rng.randn(3, 4, 32, 32), dtype=torch.float32)
+        xfm, ifm = pw.DWTForward(J=2, wave=wave, mode='symmetric').float(), pw.DWTInverse(wave=wave, mode='symmetric').float()
+        yl, yh = xfm(x)
+        c0 = pw.launch_count()
+        rec = ifm((yl, yh))
+        assert pw.kernels_since(c0) == ['WlSfbSmall<float>'], pw.kernels_since(c0)
+        ifm16 = pw.DWTInverse(wave=wave, mode='symmetric').half()      # (a module of its own: .half() rounds the taps in place)
+        rec16 = ifm16((yl.half(), [h.half() for h in yh]))
+        assert rec16.dtype == torch.float16 and float((rec16.float() - rec).abs().max()) <= 4e-3 * max(1.0, float(rec.abs().max()))
+        xg = x.clone().requires_grad_(True)
+        yl, yh = xfm(xg)
+        g, = torch.autograd.grad(yl.sum() + sum((h * h).sum() for h in yh), xg)
+        ops.SMALL_PLANES = False
+        try:
+            rec2 = ifm((yl.detach(), [h.detach() for h in yh]))
+            xg2 = x.clone().requires_grad_(True)
+            yl2, yh2 = xfm(xg2)
+            g2, = torch.autograd.grad(yl2.sum() + sum((h * h).sum() for h in yh2), xg2)
+        finally:
+            ops.SMALL_PLANES = True
+        assert float((rec - rec2).abs().max()) < 1e-5 * max(1.0, float(rec2.abs().max()))
+        assert float((g - g2).abs().max()) < 1e-4 * max(1.0, float(g2.abs().max()))
+
+
+def ll_len(n, L, mode):
+    return (n + 1) // 2 if mode == 'periodization' else (n + L - 1) // 2
+
+
+def pw_launch_count():
+    import pytorch_wavelets_amd as pw
+    return pw.launch_count()
+
+
+def test_small_planes_take_the_small_plane_kernel_through_the_modules():
+    """DWTForward on CNN-feature-map shapes: one launch of WlAfbSmall for all levels, forward and gradient equal to the
+    per-level path."""
+    import pytorch_wavelets_amd as pw
+    from pytorch_wavelets_amd import ops
+    torch.manual_seed(3)
+    x = torch.randn(4, 6, 32, 32, dtype=torch.float32).requires_grad_(True)
+    with emu_backend.emulated():
+        m = pw.DWTForward(J=2, wave='db2', mode='symmetric').float()
+        c0 = pw.launch_count()
+        yl, yh = m(x)
+        assert pw.kernels_since(c0) == ['WlAfbSmall<float, 4>']
+        g, = torch.autograd.grad(yl.sum() + sum((h * h).sum() for h in yh), x)
+        ops.SMALL_PLANES = False
+        try:
+            x2 = x.detach().clone().requires_grad_(True)
+            yl2, yh2 = m(x2)
+            g2, = torch.autograd.grad(yl2.sum() + sum((h * h).sum() for h in yh2), x2)
+        finally:
+            ops.SMALL_PLANES = True
+    assert float((yl - yl2).abs().max()) < 1e-5 and all(float((a - b).abs().max()) < 1e-5 for a, b in zip(yh, yh2))
+    assert float((g - g2).abs().max()) < 1e-4
+
+
 @pytest.mark.parametrize('seed', range(6))
 def test_streaming_kernel_vs_oracle_random_shapes(seed):
     """Random heights (odd ones too), widths in multiples of four up to the ten-wave limit, every supported tap count

@@ -320,6 +320,64 @@ def test_streaming_kernel_vs_oracle(wave, mode, J, shape):
             assert rel(a.float(), b) < 3e-3
 
 
+@pytest.mark.parametrize('wave,mode,J,shape,dtype', [('db2', 'symmetric', 2, (64, 16, 32, 32), torch.float32), ('haar', 'zero', 1, (33, 7, 32, 32), torch.float32),
+                                                     ('db4', 'periodization', 3, (20, 3, 64, 64), torch.float32), ('db3', 'reflect', 4, (9, 5, 47, 61), torch.float32),
+                                                     ('db5', 'periodic', 2, (128, 3, 16, 16), torch.float16), ('db10', 'symmetric', 2, (16, 4, 40, 24), torch.float32),
+                                                     ('bior2.2', 'symmetric', 2, (256, 8, 8, 8), torch.float32)])
+def test_small_plane_analysis_kernel(wave, mode, J, shape, dtype):
+    """wl_dwt2d_analysis_small (several planes per workgroup, all levels in LDS) through the C ABI: DWTForward on feature-map
+    shapes against the oracle (sampled planes) and against the per-level kernels (every plane), and its gradient."""
+    from pytorch_wavelets_amd import ops
+    torch.manual_seed(21)
+    x = torch.randn(*shape, device=DEV).to(dtype)
+    m = pw.DWTForward(J=J, wave=wave, mode=mode).to(DEV).to(dtype)
+    tol = 1e-5 if dtype == torch.float32 else 3e-3
+    with torch.no_grad():
+        c0 = pw.launch_count()
+        yl, yh = m(x)
+        assert pw.kernels_since(c0)[0].startswith('WlAfbSmall<'), pw.kernels_since(c0)
+        ops.SMALL_PLANES = False
+        try:
+            yl2, yh2 = m(x)
+        finally:
+            ops.SMALL_PLANES = True
+    for a, b in zip([yl] + list(yh), [yl2] + list(yh2)):
+        assert a.shape == b.shape and float((a.float() - b.float()).abs().max()) <= 2 * tol * max(1.0, float(b.float().abs().max()))
+    h0, h1 = F.dwt_analysis_taps(wave)
+    sel = [0, shape[0] - 1]
+    oyl, oyh = wo.dwt_forward(x[sel].double().cpu().numpy(), J, h0, h1, h0, h1, mode)
+    for got, want in zip([yl[sel]] + [h[sel] for h in yh], [oyl] + list(oyh)):
+        assert np.abs(got.double().cpu().numpy() - want).max() <= tol * max(1.0, np.abs(want).max())
+    # the inverse (wl_dwt2d_synthesis_small) on the same coefficients: against the oracle and the per-level kernels
+    im = pw.DWTInverse(wave=wave, mode=mode).to(DEV).to(dtype)
+    with torch.no_grad():
+        c0 = pw.launch_count()
+        rec = im((yl, yh))
+        assert pw.kernels_since(c0)[0].startswith('WlSfbSmall<'), pw.kernels_since(c0)
+        ops.SMALL_PLANES = False
+        try:
+            rec2 = im((yl, yh))
+        finally:
+            ops.SMALL_PLANES = True
+    assert rec.shape == rec2.shape and float((rec.float() - rec2.float()).abs().max()) <= 2 * tol * max(1.0, float(rec2.float().abs().max()))
+    g0, g1 = F.dwt_synthesis_taps(wave)
+    want = wo.dwt_inverse(yl[sel].double().cpu().numpy(), [h[sel].double().cpu().numpy() for h in yh], g0, g1, g0, g1, mode)
+    assert np.abs(rec[sel].double().cpu().numpy() - want).max() <= tol * max(1.0, np.abs(want).max())
+    if dtype == torch.float32:
+        xg = x.clone().requires_grad_(True)
+        yl, yh = m(xg)
+        g, = torch.autograd.grad(yl.sum() + sum((h * h).sum() for h in yh), xg)
+        assert pw.last_kernel().startswith('WlSfbSmall<'), pw.last_kernel()
+        ops.SMALL_PLANES = False
+        try:
+            xg2 = x.clone().requires_grad_(True)
+            yl2, yh2 = m(xg2)
+            g2, = torch.autograd.grad(yl2.sum() + sum((h * h).sum() for h in yh2), xg2)
+        finally:
+            ops.SMALL_PLANES = True
+        assert float((g - g2).abs().max()) <= 1e-4 * max(1.0, float(g2.abs().max()))
+
+
 STRIP_GPU_CASES = [('db8', 'periodization', (4, 16, 1024, 2048), torch.float16), ('db4', 'symmetric', (3, 3, 1024, 1024), torch.float32),
                    ('db8', 'symmetric', (8, 3, 512, 512), torch.float32), ('db10', 'reflect', (2, 2, 300, 1320), torch.float32),
                    ('db2', 'zero', (2, 3, 640, 4096), torch.float16), ('db3', 'periodic', (5, 1, 257, 768), torch.float32),
