@@ -17,6 +17,14 @@ for shape in ((2048, 3, 32, 32), (1024, 3, 64, 64), (256, 3, 128, 128), (512, 16
         c0 = pw.launch_count(); sl(x); k = pw.kernels_since(c0)
         t = bench.time_seq_fn(lambda: sl(x), 30, sync)
         print('%s ScatLayer: %.4f ms = %.3f of 8 TB/s at 11 B/px %s' % (shape, t, 11 * P / t / 8e9, k), flush=True)
+
+        def step():
+            xg = x.detach().requires_grad_(True)
+            return torch.autograd.grad(sl(xg).sum(), xg)
+        with torch.enable_grad():
+            c0 = pw.launch_count(); step(); k = pw.kernels_since(c0)
+            t = bench.time_seq_fn(step, 20, sync)
+        print('%s ScatLayer fwd+bwd: %.4f ms = %.3f at 46 B/px %s' % (shape, t, 46 * P / t / 8e9, k), flush=True)
         for J in (1, 2):
             fx, fi = pw.DWTForward(J=J, wave='db2', mode='symmetric').to(dev), pw.DWTInverse(wave='db2', mode='symmetric').to(dev)
             c = fx(x)
