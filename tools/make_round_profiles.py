@@ -102,15 +102,17 @@ def traffic(pmc, out):
     return kernels
 
 
-for src, dst in (('bench_line.json', 'bench_line.json'), ('bench_line_20.json', 'bench_line_20.json'), ('bench_dtcwt.json', 'bench_dtcwt.json'), ('bench_scat.json', 'bench_scat.json'),
+ONLY_TRAFFIC = len(sys.argv) > 3 and sys.argv[3] == 'traffic'    # on the GPU box, between the counter passes and the bench lines
+for src, dst in () if ONLY_TRAFFIC else (('bench_line.json', 'bench_line.json'), ('bench_line_20.json', 'bench_line_20.json'), ('bench_dtcwt.json', 'bench_dtcwt.json'), ('bench_scat.json', 'bench_scat.json'),
                  ('bench_cfg5.json', 'bench_cfg5.json'), ('box.txt', 'box.txt')):
     p = os.path.join(G, tag, src)
     if os.path.exists(p):
         lines = [l for l in open(p) if l.startswith('{')] if src.endswith('.json') else None
         with open(os.path.join(P, tag + '_' + dst), 'w') as f:
             f.write(lines[-1] if lines else open(p).read())
-durations(os.path.join(G, tag, 'prof', 'bench_kernel_trace.csv'), os.path.join(P, tag + '_kernel_durations.csv'))
-for c in ('dtcwt', 'scat', 'cfg5'):
+if not ONLY_TRAFFIC:
+    durations(os.path.join(G, tag, 'prof', 'bench_kernel_trace.csv'), os.path.join(P, tag + '_kernel_durations.csv'))
+for c in () if ONLY_TRAFFIC else ('dtcwt', 'scat', 'cfg5'):
     durations(os.path.join(G, tag, 'prof_' + c, 'bench_kernel_trace.csv'), os.path.join(P, '%s_%s_kernel_durations.csv' % (tag, c)))
 if os.path.exists(os.path.join(G, 'pmc_%s_bench' % tag, 'pmc_summary.json')):
     traffic(os.path.join(G, 'pmc_%s_bench' % tag, 'pmc_summary.json'), os.path.join(P, RND + '_hbm_traffic.json'))
@@ -142,4 +144,4 @@ if os.path.exists(os.path.join(G, 'pmc_%s_bench' % tag, 'pmc_summary.json')):
                       '4 x SQ_INSTS_VALU / (SIMDs x kernel cycles) is the VALU-pipe utilisation.  See DESIGN.md 4.6 / 5 for the derivation '
                       'of the VALU roofline of config 5 (1.24 ms for the four levels against 1.07 ms at the HBM peak).')
     json.dump(out, open(os.path.join(P, RND + '_cfg5_pmc_summary.json'), 'w'), indent=1)
-    print('wrote r03_cfg5_pmc_summary.json')
+    print('wrote', RND + '_cfg5_pmc_summary.json')
