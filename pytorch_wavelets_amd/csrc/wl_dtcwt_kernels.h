@@ -46,6 +46,8 @@ struct WlDtFwd1Args {
     int run_len, runs_x;   // specialised kernel: tiles per workgroup along x, ceil(tiles_x / run_len)
     int combine;     // ScatLayer combine_colour (C == 3)
     A magbias;
+    // small-plane kernel (wl_dtcwt_small.h): ceil(2^32 / d) (0 for d = 1) for d = (H + 2M)(W + 2M), W + 2M, W, (H/2)(W/2), W/2
+    unsigned mg_q, mg_w, mg_w2, nblocks_q, mg_qc;
 };
 
 template <typename T>

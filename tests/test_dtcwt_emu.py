@@ -467,3 +467,47 @@ def test_scatlayer_backward_on_the_streaming_inverse():
                                                     ((2, 1, 128, 512), torch.float32), ((1, 2, 64, 512), torch.float16)], tol=3e-6)
     finally:
         torch.set_default_dtype(prev)
+
+
+@pytest.mark.parametrize('shape,biort,mode,dtype,grad', [((6, 3, 32, 32), 'near_sym_a', 'symmetric', torch.float32, True),
+                                                          ((2, 9, 16, 24), 'near_sym_b', 'symmetric', torch.float32, False),
+                                                          ((5, 4, 36, 28), 'legall', 'zero', torch.float32, True),
+                                                          ((20, 1, 8, 8), 'near_sym_a', 'symmetric', torch.float16, False),
+                                                          ((300, 1, 4, 6), 'antonini', 'symmetric', torch.float32, False)])
+def test_small_plane_level1_kernel(shape, biort, mode, dtype, grad):
+    """WlDtFwd1Small (csrc/wl_dtcwt_small.h: several small planes per workgroup) behind ScatLayer and DTCWTForward(J=1): against
+    the oracle and against the tile kernels (wl_set_option no_stream); the training forward saves what the backward consumes."""
+    from oracle import wavelet_oracle as wo
+    from pytorch_wavelets_amd import filters
+    from pytorch_wavelets_amd.dtcwt import lowlevel as dl
+    torch.manual_seed(1)
+    x = torch.randn(*shape, dtype=dtype)
+    h = emu_backend.handle()
+    h0o, _, h1o, _ = filters.biort(biort)
+    hp = [dl.prep_filt(v, 1).numpy().ravel() for v in (h0o, h1o)]
+    out = {}
+    with emu_backend.emulated():
+        sl = pw.ScatLayer(biort=biort, mode=mode).to(dtype)
+        xf = pw.DTCWTForward(J=1, biort=biort, mode=mode).to(dtype)
+        try:
+            for ns in (0, 1):
+                h.wl_set_option(b'no_stream', ns)
+                xg = x.clone().requires_grad_(grad)
+                c0 = pw.launch_count()
+                z = sl(xg)
+                ks = pw.kernels_since(c0)
+                assert ('WlDtFwd1Small' in ks[0]) == (ns == 0), ks
+                out[ns] = [z.detach()]
+                if grad:
+                    g, = torch.autograd.grad((z * z).sum(), xg)
+                    out[ns].append(g)
+                yl, yh = xf(x)
+                out[ns] += [yl, yh[0]]
+        finally:
+            h.wl_set_option(b'no_stream', 0)
+    tol = 5e-3 if dtype == torch.float16 else 3e-6
+    for u, v in zip(out[0], out[1]):
+        assert u.shape == v.shape
+        assert float((u.float() - v.float()).abs().max()) <= tol * max(1.0, float(v.float().abs().max()))
+    want = wo.scat_layer_forward(x.double().numpy(), hp[0], hp[1], mode)
+    assert np.abs(out[0][0].double().numpy() - want).max() <= (5e-3 if dtype == torch.float16 else 1e-5) * max(1.0, np.abs(want).max())

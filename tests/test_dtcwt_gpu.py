@@ -410,3 +410,46 @@ def test_scatlayer_backward_on_the_streaming_inverse_gpu():
     """config 4's plane size (256 x 256, enough images for the engine's own policy to pick the streaming kernel) and wider planes."""
     D.check_scat_backward_streaming(DEV, [((64, 3, 256, 256), torch.float32), ((32, 3, 512, 512), torch.float32),
                                           ((64, 2, 132, 1160), torch.float32), ((64, 3, 256, 512), torch.float16)])
+
+
+@pytest.mark.parametrize('shape,biort,mode,dtype,grad', [((512, 3, 32, 32), 'near_sym_a', 'symmetric', torch.float32, True),
+                                                          ((128, 3, 32, 32), 'near_sym_b', 'symmetric', torch.float32, True),
+                                                          ((64, 16, 16, 16), 'legall', 'zero', torch.float32, False),
+                                                          ((256, 3, 32, 32), 'near_sym_a', 'symmetric', torch.float16, False)])
+def test_small_plane_level1_kernel(shape, biort, mode, dtype, grad):
+    """WlDtFwd1Small (several small planes per workgroup: CIFAR / Tiny-ImageNet shapes) behind ScatLayer and DTCWTForward(J=1):
+    against the tile kernels on every plane (wl_set_option no_stream), against the oracle on sampled planes, and the training step
+    (the saved (re, im) / r feed the fused backward)."""
+    from pytorch_wavelets_amd import _lib
+    from pytorch_wavelets_amd.dtcwt import lowlevel as dl
+    torch.manual_seed(2)
+    x = torch.randn(*shape, device=DEV).to(dtype)
+    sl = pw.ScatLayer(biort=biort, mode=mode).to(DEV).to(dtype)
+    xf = pw.DTCWTForward(J=1, biort=biort, mode=mode).to(DEV).to(dtype)
+    lib = _lib.get()
+    out = {}
+    try:
+        for ns in (0, 1):
+            lib.wl_set_option(b'no_stream', ns)
+            xg = x.clone().requires_grad_(grad)
+            c0 = pw.launch_count()
+            z = sl(xg)
+            ks = pw.kernels_since(c0)
+            assert ('WlDtFwd1Small' in ks[0]) == (ns == 0), ks
+            out[ns] = [z.detach()]
+            if grad:
+                g, = torch.autograd.grad((z * z).sum(), xg)
+                out[ns].append(g)
+            yl, yh = xf(x)
+            out[ns] += [yl, yh[0]]
+    finally:
+        lib.wl_set_option(b'no_stream', 0)
+    tol = 5e-3 if dtype == torch.float16 else 3e-6
+    for u, v in zip(out[0], out[1]):
+        assert u.shape == v.shape
+        assert float((u.float() - v.float()).abs().max()) <= tol * max(1.0, float(v.float().abs().max()))
+    h0o, _, h1o, _ = F.biort(biort)
+    hp = [dl.prep_filt(v, 1).numpy().ravel() for v in (h0o, h1o)]
+    sel = [0, shape[0] - 1]
+    want = wo.scat_layer_forward(x[sel].double().cpu().numpy(), hp[0], hp[1], mode)
+    assert np.abs(out[0][0][sel].double().cpu().numpy() - want).max() <= (5e-3 if dtype == torch.float16 else 1e-5) * max(1.0, np.abs(want).max())
