@@ -641,8 +641,14 @@ def other_configs(pw, dev, sync):
         x1 = torch.randn(64, 16, 65536, device=dev)
         d1 = pw.DWT1DForward(J=3, wave='db4', mode='symmetric').to(dev)
         t1 = time_seq_fn(lambda: d1(x1), 20, sync)
-        other['dwt1d_j3_db4_64x16x65536_fp32'] = {'fwd_ms': round(t1, 4), 'msamples_s': round(x1.numel() / t1 / 1e3, 1),
-                                                  'frac_of_hbm_peak_at_8B_per_sample': frac(8 * x1.numel(), t1)}
+        i1 = pw.DWT1DInverse(wave='db4', mode='symmetric').to(dev)
+        c1 = d1(x1)
+        t1i = time_seq_fn(lambda: i1(c1), 20, sync)
+        other['dwt1d_j3_db4_64x16x65536_fp32'] = {'fwd_ms': round(t1, 4), 'inv_ms': round(t1i, 4), 'msamples_s': round(x1.numel() / t1 / 1e3, 1),
+                                                  'frac_of_hbm_peak_at_8B_per_sample': frac(8 * x1.numel(), t1),
+                                                  'inv_frac_of_hbm_peak_at_8B_per_sample': frac(8 * x1.numel(), t1i),
+                                                  'fwd_kernels': names(lambda: d1(x1)), 'inv_kernels': names(lambda: i1(c1))}
+        del c1
         del x1
         from pytorch_wavelets_amd.dwt.transform2d import SWTForward
         xw = torch.randn(16, 3, 512, 512, device=dev)

@@ -247,6 +247,14 @@ int wl_dwt2d_synthesis_nonsep_bwd(const void* dy, void* dc, int dtype, int64_t p
 int wl_dwt1d_analysis_fused(const void* x, void* lo, void* const* highs, int dtype, int64_t rows, int N, int J,
                             const void* h0, const void* h1, int L, int mode, void* stream);
 
+/* The inverse: J (1..4) levels of the 1-D synthesis bank in ONE launch (csrc/wl_idwt1d_fused.h) = DWT1DInverse.forward's level
+ * loop (dwt/transform1d.py:97-115 -> SFB1D.forward, dwt/lowlevel.py:697-727, incl. the 'unpad' of a lowpass one sample longer
+ * than the next highpass) and the backward of the 1-D analysis (AFB1D.backward :409-424: analysis taps, crop to the input length
+ * = out_len): lo (rows,n_lo), highs[j] (rows,n_hi[j]) finest first (NULL = zeros) -> y (rows,out_len), out_len <= 2 n_hi[0] - L + 2.
+ * Even L <= 20, float32 / float16, every mode but periodization.  WL_ERR_UNSUPPORTED otherwise: callers chain wl_synth1d. */
+int wl_dwt1d_synthesis_fused(const void* lo, int n_lo, const void* const* highs, const int* n_hi, void* y, int out_len, int dtype,
+                             int64_t rows, int J, const void* g0, const void* g1, int L, int mode, void* stream);
+
 /* ---- single-axis building blocks -------------------------------------------------------------------------------
  * One strided / dilated correlation with boundary extension along the middle axis of a dense (outer, n, inner) tensor:
  *   y[o, out_offset + out_stride*k, i] = sum_{t<ntaps} h[tap_offset + tap_stride*t] * ext(x[o,:,i], start + step*k + tap_step*t)

@@ -37,6 +37,7 @@ PROTOTYPES = {
     'wl_dwt2d_synthesis_small': (I, [P, I, I, C.POINTER(P), C.POINTER(I), C.POINTER(I), P, I, L, I, P, P, P, P, I, I, P]),
     'wl_dtcwt_fwd_level1_rot': (I, [P, P, P, P, I, L, I, I, I, P, I, P, I, P, I, I, I, C.c_double, P]),
     'wl_swt2d_level': (I, [P, L, P, I, L, I, I, P, P, P, P, I, I, I, I, P]),
+    'wl_dwt1d_synthesis_fused': (I, [P, I, C.POINTER(P), C.POINTER(I), P, I, I, L, I, P, P, I, I, P]),
     'wl_corr1d': (I, [P, P, P, I, L, I, L, L, I, P, P, I, I, I, I, I, I, I, I, I, P]),
     'wl_synth1d': (I, [P, P, P, I, L, I, L, I, P, P, I, I, P]),
     'wl_scat_bwd_level1': (I, [P, P, P, P, I, L, I, I, I, P, I, P, I, I, I, P]),

@@ -1,0 +1,104 @@
+// Multi-level 1-D DWT synthesis in ONE launch: DWT1DInverse.forward's level loop (reference dwt/transform1d.py:97-115 = J x
+// SFB1D.forward, dwt/lowlevel.py:697-727 -> sfb1d :226-271, incl. the 'unpad' of a lowpass one sample longer than the next
+// highpass) and the backward of the 1-D analysis (AFB1D.backward :409-424, with the analysis taps and the crop to the input
+// length) for signals along the last axis of dense (rows, n) tensors.  One level on the single-axis kernel (wl_synth1d) reads
+// its two inputs through the caches and round-trips the reconstructed lowpass: J = 3 ran at 0.075 of the HBM roofline
+// (64 x 16 x 65536 float32).  Here a workgroup owns a chunk of `chunk` OUTPUT samples of a row (a multiple of 2^J) and keeps the
+// levels in LDS.  Per axis, as wl_synth1d evaluates it (every mode but periodization):
+//     y[p] = sum_k g0[p + L - 2 - 2k] lo[k] + g1[p + L - 2 - 2k] hi[k]   =>   the output pair (2q, 2q + 1) reads k = q .. q + L/2 - 1:
+//     (y[2q], y[2q+1]) = sum_{i < L/2} (g[L-2-2i], g[L-1-2i]) c[q + i]          - one packed FMA per coefficient and bank.
+// Level j needs coefficients [base_j, base_j + span_j) with base_j = c chunk / 2^j and span_j = span_{j-1} / 2 + L/2 - 1 (rounded
+// up to even): all highpass ranges and the coarsest lowpass range are loaded into LDS first (zeros beyond a level's end: no tap
+// ever tests a boundary), then level J .. 1 run out of LDS, each writing the next finer level's lowpass (zeros from that level's
+// highpass length on: the 'unpad') - and level 1 the output.  HBM traffic = every coefficient once (+ the (L/2 - 1)-coefficient
+// halos per level and chunk) + every output once.
+#pragma once
+#include "wl_common.h"
+#include "wl_dwt_rows.h"   // wl_pk_fma_x, wl_uniform_v2
+
+#define WL_IDWT1D_MAXJ 4
+#ifndef WL_IDWT1D_CHUNK
+#define WL_IDWT1D_CHUNK 4096   // output samples per chunk
+#endif
+
+template <typename T>
+struct WlIdwt1dArgs {
+    const T* lo;                       // (rows, n_lo) dense: the coarsest lowpass (n_lo = n_hi[J-1] or one more)
+    const T* hi[WL_IDWT1D_MAXJ];       // (rows, n_hi[j]) dense, finest first; nullptr = zeros
+    T* y;                              // (rows, out_len) dense
+    const float* g0; const float* g1;  // stored synthesis taps, L each
+    int64_t rows, nblocks;
+    int J, n_lo, out_len, chunk, nchunks;
+    int n_hi[WL_IDWT1D_MAXJ];
+    int span[WL_IDWT1D_MAXJ + 1];      // span[0] = chunk, span[j] = coefficients of level j a chunk needs (even)
+    int hi_off[WL_IDWT1D_MAXJ], lo_off[WL_IDWT1D_MAXJ];   // LDS byte offsets of level j + 1's highpass / lowpass buffers
+    int lds_bytes;
+};
+
+template <typename T, int LT>
+struct WlIdwt1dFused {
+    typedef WlIdwt1dArgs<T> Args;
+    static const int kThreads = 256;
+    static const int kMinWaves = 2;
+    static const int HL = LT / 2;
+    // n floats of src[base ..] -> dst, zeros from position `len` on (src may be null = zeros)
+    static WL_DEV void load_range(float* dst, const T* src, int base, int n, int len, int tid) {
+        for (int i = tid; i < n; i += kThreads) {
+            const int k = base + i;
+            dst[i] = (src && k < len) ? (float)src[k] : 0.f;
+        }
+    }
+    static WL_DEV void run(const Args& a, const WlCtx& ctx) {
+        const int tid = ctx.tid;
+        const int64_t row = ctx.bid / a.nchunks;
+        const int c = (int)(ctx.bid - row * a.nchunks);
+        const int J = a.J;
+        wl_v2 p0[HL], p1[HL];                                    // (g[L-2-2i], g[L-1-2i]) of either bank: scalar registers
+#pragma unroll
+        for (int i = 0; i < HL; ++i) {
+            p0[i] = wl_uniform_v2(wl_v2{a.g0[LT - 2 - 2 * i], a.g0[LT - 1 - 2 * i]});
+            p1[i] = wl_uniform_v2(wl_v2{a.g1[LT - 2 - 2 * i], a.g1[LT - 1 - 2 * i]});
+        }
+        // ---- every coefficient the chunk needs
+        for (int j = 0; j < J; ++j) {
+            const int base = (c * a.chunk) >> (j + 1);
+            float* hb = reinterpret_cast<float*>(ctx.smem + a.hi_off[j]);
+            load_range(hb, a.hi[j] ? a.hi[j] + (size_t)row * a.n_hi[j] : nullptr, base, a.span[j + 1], a.n_hi[j], tid);
+            if (j == J - 1) {
+                float* lb = reinterpret_cast<float*>(ctx.smem + a.lo_off[j]);
+                // (the coarsest lowpass may be one sample longer than its highpass: the surplus sample is dropped)
+                load_range(lb, a.lo + (size_t)row * a.n_lo, base, a.span[j + 1], a.n_hi[j] < a.n_lo ? a.n_hi[j] : a.n_lo, tid);
+            }
+        }
+        ctx.sync();
+        // ---- levels J .. 1
+        for (int j = J - 1; j >= 0; --j) {
+            const float* lb = reinterpret_cast<const float*>(ctx.smem + a.lo_off[j]);
+            const float* hb = reinterpret_cast<const float*>(ctx.smem + a.hi_off[j]);
+            const int npairs = a.span[j] >> 1;                   // output pairs of this level
+            const int obase = (c * a.chunk) >> j;                // position of output 0 in the level's output signal
+            float* nxt = j > 0 ? reinterpret_cast<float*>(ctx.smem + a.lo_off[j - 1]) : nullptr;
+            const int lim = j > 0 ? a.n_hi[j - 1] : a.out_len;   // outputs from here on are dropped ('unpad' / crop)
+            T* const yp = a.y + (size_t)row * a.out_len;
+            for (int q = tid; q < npairs; q += kThreads) {
+                wl_v2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < HL; ++i) {
+                    const wl_v2 sl = {lb[q + i], 0.f}, sh = {hb[q + i], 0.f};
+                    wl_pk_fma_x(acc0, p0[i], sl);
+                    wl_pk_fma_x(acc1, p1[i], sh);
+                }
+                const float v0 = acc0.x + acc1.x, v1 = acc0.y + acc1.y;
+                const int p = obase + 2 * q;
+                if (nxt) {
+                    nxt[2 * q] = p < lim ? v0 : 0.f;
+                    nxt[2 * q + 1] = p + 1 < lim ? v1 : 0.f;
+                } else {
+                    if (p < lim) yp[p] = (T)v0;
+                    if (p + 1 < lim) yp[p + 1] = (T)v1;
+                }
+            }
+            ctx.sync();
+        }
+    }
+};

@@ -290,10 +290,72 @@ class AFB1DMulti(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             h0, h1 = ctx.saved_tensors
-            dx = dlo
-            for dh, n in zip(dhis[::-1], ctx.lens[::-1]):
-                dx = ops.sfb1d(dx, dh, h0, h1, ctx.mode, 2, out_len=n)
+            dx = None
+            if FUSED_LEVELS and len(dhis) <= 4 and all(d is not None for d in dhis):
+                # one launch (csrc/wl_idwt1d_fused.h): the crops to the levels' input lengths are its 'unpad' / output length
+                dx = ops.sfb1d_fused(dlo, list(dhis), h0, h1, ctx.mode, out_len=ctx.lens[0])
+            if dx is None:
+                dx = dlo
+                for dh, n in zip(dhis[::-1], ctx.lens[::-1]):
+                    dx = ops.sfb1d(dx, dh, h0, h1, ctx.mode, 2, out_len=n)
         return dx, None, None, None, None
+
+
+class SFB1DMulti(Function):
+    """All levels of DWT1DInverse as ONE autograd node: ``SFB1DMulti.apply(x0, g0, g1, mode_int, *highs) -> x`` with highs finest
+    first, ``None`` entries = zeros (the level loop of DWT1DInverse.forward, reference dwt/transform1d.py:97-115, incl. the 'unpad'
+    of a lowpass one sample longer than the next highpass).  One launch of the fused 1-D synthesis kernel where the engine takes
+    it (ops.sfb1d_fused), the per-level launches otherwise; backward = the chain of SFB1D.backward steps (analysis with the stored
+    synthesis taps, dwt/lowlevel.py:729-743), finest level first; a dropped sample gets a zero gradient."""
+
+    @staticmethod
+    def forward(ctx, x0, g0, g1, mode, *highs):
+        _check_bank_mode(mode)
+        ctx.save_for_backward(g0, g1)
+        ctx.mode = mode
+        ctx.has_highs = [h is not None for h in highs]
+        J = len(highs)
+        lo_lens = [None] * J            # length of the lowpass handed to level j, before the 'unpad'
+        res = None
+        if FUSED_LEVELS and 1 <= J <= 4 and all(ctx.has_highs):
+            res = ops.sfb1d_fused(x0, list(highs), g0, g1, mode)
+            if res is not None:
+                L = g0.numel()
+                n = x0.shape[-1]
+                for j in range(J - 1, -1, -1):
+                    lo_lens[j] = n
+                    n = 2 * highs[j].shape[-1] - L + 2
+        if res is None:
+            res = x0
+            for j in range(J - 1, -1, -1):
+                x1 = highs[j]
+                lo_lens[j] = res.shape[-1]
+                if x1 is None:
+                    x1 = torch.zeros_like(res)
+                if res.shape[-1] > x1.shape[-1]:
+                    res = res[..., :-1]
+                res = ops.sfb1d(res, x1, g0, g1, mode, 2)
+        ctx.lo_lens = lo_lens
+        return res
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        J = len(ctx.has_highs)
+        grads = [None] * J
+        d = None
+        if ctx.needs_input_grad[0] or any(ctx.needs_input_grad[4 + j] for j in range(J)):
+            g0, g1 = ctx.saved_tensors
+            d = dy
+            for j in range(J):
+                d, dh = ops.afb1d(d, g0, g1, ctx.mode, 2)
+                if ctx.has_highs[j] and ctx.needs_input_grad[4 + j]:
+                    grads[j] = dh
+                if d.shape[-1] < ctx.lo_lens[j]:         # the forward dropped the last sample of this lowpass
+                    d = torch.nn.functional.pad(d, (0, ctx.lo_lens[j] - d.shape[-1]))
+            if not ctx.needs_input_grad[0]:
+                d = None
+        return (d, None, None, None) + tuple(grads)
 
 
 class SFB1D(Function):

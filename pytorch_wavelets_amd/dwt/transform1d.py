@@ -61,10 +61,11 @@ class DWT1DInverse(nn.Module):
         x0, highs = coeffs
         assert x0.ndim == 3, "Can only handle 3d inputs (N, C, L)"
         mode = lowlevel.mode_to_int(self.mode)
-        for x1 in highs[::-1]:
-            if x1 is None:
-                x1 = torch.zeros_like(x0)
-            if x0.shape[-1] > x1.shape[-1]:   # 'unpad' the extra sample an odd-length finer level produced
-                x0 = x0[..., :-1]
-            x0 = lowlevel.SFB1D.apply(x0, x1, self.g0, self.g1, mode)
+        highs = list(highs)
+        # all levels are one autograd node / (where the engine takes it) one kernel launch; more than four levels: in fours,
+        # coarsest first.  (A `None` level in a group: the per-level path inside the node, 'unpad' included.)
+        while highs:
+            grp = highs[-4:]
+            highs = highs[:-4]
+            x0 = lowlevel.SFB1DMulti.apply(x0, self.g0, self.g1, mode, *grp)
         return x0

@@ -710,6 +710,50 @@ def swt2d_level(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, dilation, ext):
     return y
 
 
+def sfb1d_fused(lo, his, g0, g1, mode, out_len=None):
+    """All len(his) (1..4) synthesis levels along the LAST axis in ONE launch (wl_dwt1d_synthesis_fused): lo (..., n_lo), his =
+    [finest .. coarsest] (None = zeros) -> y (..., out_len) (default: the full reconstruction 2 n_hi[0] - L + 2), or None when
+    the kernel does not cover the configuration (callers go level by level on sfb1d)."""
+    import ctypes
+    _check_tensor(lo, 'lo')
+    J, L = len(his), g0.numel()
+    if (lo.dtype == torch.float64 or J < 1 or J > 4 or L % 2 or L > 20 or g1.numel() != L or lo.numel() == 0 or mode == 2
+            or mode not in _MODE_TO_EXT or all(h is None for h in his)):
+        return None
+    lens = []
+    for j, h in enumerate(his):
+        if h is None:
+            # a missing level has the length its neighbours imply: the coarser level's reconstruction (or lo) cropped by nothing
+            return None
+        if h.dtype != lo.dtype or h.shape[:-1] != lo.shape[:-1]:
+            return None
+        lens.append(h.shape[-1])
+    full = 2 * lens[0] - L + 2
+    if out_len is None:
+        out_len = full
+    if out_len < 1 or out_len > full:
+        return None
+    key = ('sfb1d', lo.device, lo.dtype, lo.numel() // lo.shape[-1], lo.shape[-1], tuple(lens), L, mode, out_len)
+    if key in _FUSED_DECLINED:
+        return None
+    lo = lo.contiguous()
+    his = [h.contiguous() for h in his]
+    for h in his:
+        _same_device(lo, h)
+    rows = lo.numel() // lo.shape[-1]
+    t0, t1 = _taps(g0, lo), _taps(g1, lo)
+    y = torch.empty(lo.shape[:-1] + (out_len,), dtype=lo.dtype, device=lo.device)
+    ptrs = (ctypes.c_void_p * J)(*[h.data_ptr() for h in his])
+    ns = (ctypes.c_int * J)(*lens)
+    rc = _call('wl_dwt1d_synthesis_fused', lo, lo.data_ptr(), lo.shape[-1], ptrs, ns, y.data_ptr(), out_len, _DTYPES[lo.dtype], rows, J,
+               t0.data_ptr(), t1.data_ptr(), L, mode, _stream(lo))
+    if rc == -3:
+        _remember_decline(key)
+        return None
+    _lib.check(rc, 'wl_dwt1d_synthesis_fused')
+    return y
+
+
 def sfb1d(lo, hi, g0, g1, mode, dim, out_len=None):
     """One synthesis level along one axis (hi may be None = zeros); out_len crops (analysis backward)."""
     _check_tensor(lo, 'lo')

@@ -244,6 +244,16 @@ def check_dwt1d_fused(dev, cases=None, tol=1e-5):
         for j in range(J):
             assert yh[j].shape == oyh[j].shape and yh[j].is_contiguous()
             assert np.abs(yh[j].detach().cpu().double().numpy() - oyh[j]).max() <= t * max(np.abs(oyh[j]).max(), 1e-30), (wave, mode, J, shape, j)
+        # the inverse on the fused multi-level 1-D synthesis kernel (csrc/wl_idwt1d_fused.h): against the oracle
+        g0, g1 = F.dwt_synthesis_taps(wave)
+        ifm = pw.DWT1DInverse(wave=wave, mode=mode).to(dev).to(dtype)
+        c0 = pw.launch_count()
+        rec = ifm((yl.detach(), [h.detach() for h in yh]))
+        if mode != 'periodization':
+            assert pw.kernels_since(c0)[0].startswith('WlIdwt1dFused'), (wave, mode, J, shape, pw.kernels_since(c0))
+        orec = wo.dwt1d_inverse(yl.detach().cpu().double().numpy(), [h.detach().cpu().double().numpy() for h in yh], g0, g1, mode)
+        assert rec.shape == orec.shape
+        assert np.abs(rec.cpu().double().numpy() - orec).max() <= (6e-3 if dtype == torch.float16 else 2 * tol) * max(1.0, np.abs(orec).max()), (wave, mode, J, shape, 'rec')
         if dtype == torch.float32:
             ws = [torch.randn_like(yl)] + [torch.randn_like(h) for h in yh]
             ((yl * ws[0]).sum() + sum((h * w).sum() for h, w in zip(yh, ws[1:]))).backward()
