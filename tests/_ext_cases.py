@@ -229,7 +229,9 @@ def check_dwt1d_fused(dev, cases=None, tol=1e-5):
                       ('sym10', 'zero', 2, (1, 1, 8191), torch.float32), ('db2', 'periodization', 3, (2, 2, 1000), torch.float32),
                       ('db5', 'periodic', 2, (1, 3, 777), torch.float32), ('db6', 'periodization', 1, (2, 1, 333), torch.float32),
                       ('db4', 'symmetric', 1, (4, 4, 64), torch.float32), ('coif2', 'reflect', 4, (1, 1, 16384), torch.float32),
-                      ('db4', 'symmetric', 3, (2, 2, 8192), torch.float16), ('db7', 'zero', 3, (1, 2, 5001), torch.float32)]
+                      ('db4', 'symmetric', 3, (2, 2, 8192), torch.float16), ('db7', 'zero', 3, (1, 2, 5001), torch.float32),
+                      # many rows (more workgroups than the emulated chip holds at once)
+                      ('db3', 'symmetric', 2, (40, 2, 6000), torch.float32), ('db2', 'zero', 1, (60, 1, 9001), torch.float32)]
     for wave, mode, J, shape, dtype in cases:
         h0, h1 = F.dwt_analysis_taps(wave)
         x = torch.tensor(rng.randn(*shape), dtype=dtype, device=dev)
