@@ -215,3 +215,43 @@ def test_fused_multilevel_dwt1d_vs_oracle():
             E.check_dwt1d_fused('cpu', tol=3e-6)
     finally:
         torch.set_default_dtype(prev)
+
+
+def test_dwt1d_deep_pyramids_in_groups_of_four():
+    """J = 6: DWT1DForward runs its levels four + two, DWT1DInverse two + four from the coarse end (SFB1DMulti per group, a `None`
+    level inside a group on the per-level path); forward, inverse and the gradient of the inverse against the oracle / the
+    per-level path."""
+    import pytorch_wavelets_amd as pw
+    from pytorch_wavelets_amd import filters
+    from pytorch_wavelets_amd.dwt import lowlevel as ll
+    rng = np.random.RandomState(4)
+    x = rng.randn(2, 3, 3000)
+    h0, h1 = filters.dwt_analysis_taps('db3')
+    g0, g1 = filters.dwt_synthesis_taps('db3')
+    oyl, oyh = wo.dwt1d_forward(x, 6, h0, h1, 'symmetric')
+    orec = wo.dwt1d_inverse(oyl, oyh, g0, g1, 'symmetric')
+    with emu_backend.emulated():
+        xfm, ifm = pw.DWT1DForward(J=6, wave='db3', mode='symmetric').float(), pw.DWT1DInverse(wave='db3', mode='symmetric').float()
+        yl, yh = xfm(torch.tensor(x, dtype=torch.float32))
+        assert np.abs(yl.numpy() - oyl).max() < 2e-5 * np.abs(oyl).max()
+        ylr = yl.clone().requires_grad_(True)
+        yhr = [h.clone().requires_grad_(True) for h in yh]
+        rec = ifm((ylr, yhr))
+        assert rec.shape == orec.shape and np.abs(rec.detach().numpy() - orec).max() < 5e-5 * np.abs(orec).max()
+        gr = torch.autograd.grad((rec * rec).sum(), [ylr] + yhr)
+        ll.FUSED_LEVELS = False
+        try:
+            yl2 = yl.clone().requires_grad_(True)
+            yh2 = [h.clone().requires_grad_(True) for h in yh]
+            rec2 = ifm((yl2, yh2))
+            gr2 = torch.autograd.grad((rec2 * rec2).sum(), [yl2] + yh2)
+        finally:
+            ll.FUSED_LEVELS = True
+        assert float((rec - rec2).abs().max()) < 1e-5 * float(rec2.abs().max())
+        for a, b in zip(gr, gr2):
+            assert float((a - b).abs().max()) < 1e-4 * max(1.0, float(b.abs().max()))
+        # (a `None` level is zeros of the LOWPASS length, upstream too: only where that equals the level's own length - here the
+        # coarsest - does the pyramid still fit together)
+        rec_none = ifm((yl, list(yh[:5]) + [None]))
+        want = wo.dwt1d_inverse(oyl, list(oyh[:5]) + [None], g0, g1, 'symmetric')
+        assert rec_none.shape == want.shape and np.abs(rec_none.numpy() - want).max() < 5e-5 * max(1.0, np.abs(want).max())
