@@ -26,7 +26,12 @@ struct WlSmallArgs {
     int nlev, L, ext, G;
     int h[WL_SMALL_MAXLEV + 1], w[WL_SMALL_MAXLEV + 1];   // h[0] x w[0] = the plane, h[j] x w[j] = level j's sub-bands
     int base_h[WL_SMALL_MAXLEV], base_w[WL_SMALL_MAXLEV];
-    unsigned mg_rk[WL_SMALL_MAXLEV], mg_k[WL_SMALL_MAXLEV], mg_ik[WL_SMALL_MAXLEV];   // ceil(2^32 / d) (0 for d = 1): d = h[j] w[j+1], w[j+1], h[j+1] w[j+1]
+    unsigned mg_k[WL_SMALL_MAXLEV];    // ceil(2^32 / d) (0 for d = 1): d = w[j+1]
+    // The outputs of an axis whose L samples lie inside the plane (k in [kf, kf + ki)) and the others (nb = K - ki of them, at
+    // either end) are separate loops: a wave runs either the unrolled interior form or the extension form, never both.
+    int kf_w[WL_SMALL_MAXLEV], ki_w[WL_SMALL_MAXLEV], kf_h[WL_SMALL_MAXLEV], ki_h[WL_SMALL_MAXLEV];
+    unsigned mg_r1[WL_SMALL_MAXLEV], mg_k1[WL_SMALL_MAXLEV], mg_r2[WL_SMALL_MAXLEV], mg_k2[WL_SMALL_MAXLEV];   // d = h ki_w, ki_w, h nb_w, nb_w
+    unsigned mg_c1[WL_SMALL_MAXLEV], mg_c2[WL_SMALL_MAXLEV];   // d = ki_h w[j+1], nb_h w[j+1]
     int buf_off[2], mid_off, tap_off, lds_bytes;
     int vec_ok;                        // the chunk of a workgroup starts on a 16-byte boundary and H W is a multiple of 4 elements
 };
@@ -66,63 +71,89 @@ struct WlAfbSmall {
             const float* const src = reinterpret_cast<const float*>(ctx.smem + a.buf_off[j & 1]);
             float* const nxt = reinterpret_cast<float*>(ctx.smem + a.buf_off[(j + 1) & 1]);
             wl_f2* const mid = reinterpret_cast<wl_f2*>(ctx.smem + a.mid_off);
-            // ---- row pass
-            const int nr = np * h * Kw, hK = h * Kw;
-            for (int idx = tid; idx < nr; idx += kThreads) {
-                const int p = (int)divm(idx, a.mg_rk[j]);
-                const int rem = idx - p * hK;
-                const int r = (int)divm(rem, a.mg_k[j]);
-                const int k = rem - r * Kw;
-                const float* row = src + (p * h + r) * w;
-                const int s = 2 * k + a.base_w[j];
-                float lo = 0.f, hi = 0.f;
-                if (s >= 0 && s + L <= w) {
+            const int hK = h * Kw;
+            // ---- row pass, interior outputs: every sample inside the row
+            {
+                const int ki = a.ki_w[j], kf = a.kf_w[j], hki = h * ki;
+                for (int idx = tid; idx < np * hki; idx += kThreads) {
+                    const int p = (int)divm(idx, a.mg_r1[j]);
+                    const int rem = idx - p * hki;
+                    const int r = (int)divm(rem, a.mg_k1[j]);
+                    const int k = kf + (rem - r * ki);
+                    const float* row = src + (p * h + r) * w + 2 * k + a.base_w[j];
+                    float lo = 0.f, hi = 0.f;
                     if (LT) {
 #pragma unroll
-                        for (int t = 0; t < (LT ? LT : 1); ++t) { const float v = row[s + t]; lo = __builtin_fmaf(tw0[t], v, lo); hi = __builtin_fmaf(tw1[t], v, hi); }
+                        for (int t = 0; t < (LT ? LT : 1); ++t) { const float v = row[t]; lo = __builtin_fmaf(tw0[t], v, lo); hi = __builtin_fmaf(tw1[t], v, hi); }
                     } else {
-                        for (int t = 0; t < L; ++t) { const float v = row[s + t]; lo = __builtin_fmaf(tw0[t], v, lo); hi = __builtin_fmaf(tw1[t], v, hi); }
+                        for (int t = 0; t < L; ++t) { const float v = row[t]; lo = __builtin_fmaf(tw0[t], v, lo); hi = __builtin_fmaf(tw1[t], v, hi); }
                     }
-                } else {
+                    wl_f2 q; q.x = lo; q.y = hi;
+                    mid[p * hK + r * Kw + k] = q;                   // [p][r][k]
+                }
+                // ---- row pass, the outputs at either end of a row: samples through the extension rule
+                const int nb = Kw - ki, hnb = h * nb;
+                for (int idx = tid; idx < np * hnb; idx += kThreads) {
+                    const int p = (int)divm(idx, a.mg_r2[j]);
+                    const int rem = idx - p * hnb;
+                    const int r = (int)divm(rem, a.mg_k2[j]);
+                    const int kb = rem - r * nb;
+                    const int k = kb < kf ? kb : kb + ki;
+                    const float* row = src + (p * h + r) * w;
+                    const int s = 2 * k + a.base_w[j];
+                    float lo = 0.f, hi = 0.f;
                     for (int t = 0; t < L; ++t) {
                         const int c = ext_once(s + t, w, a.ext);
                         const float v = c < 0 ? 0.f : row[c];
                         lo = __builtin_fmaf(tw0[t], v, lo); hi = __builtin_fmaf(tw1[t], v, hi);
                     }
+                    wl_f2 q; q.x = lo; q.y = hi;
+                    mid[p * hK + r * Kw + k] = q;
                 }
-                wl_f2 q; q.x = lo; q.y = hi;
-                mid[idx] = q;                                       // [p][r][k]
             }
             ctx.sync();
-            // ---- column pass, stores
+            // ---- column pass, stores: interior rows, then the rows at either end
             const bool last = j + 1 == a.nlev;
-            const int nc = np * Kh * Kw, KK = Kh * Kw;
+            const int KK = Kh * Kw;
             T* const hp = a.yh[j] + (size_t)plane0 * 3 * KK;
             T* const lp = a.yl + (size_t)plane0 * KK;
-            for (int idx = tid; idx < nc; idx += kThreads) {
-                const int p = (int)divm(idx, a.mg_ik[j]);
-                const int rem = idx - p * KK;
-                const int i = (int)divm(rem, a.mg_k[j]);
-                const int k = rem - i * Kw;
-                const wl_f2* col = mid + p * hK + k;
-                const int s = 2 * i + a.base_h[j];
-                float ll = 0.f, hl = 0.f, lh = 0.f, hh = 0.f;         // hl: W-hi / H-lo, lh: W-lo / H-hi
-                if (s >= 0 && s + L <= h) {
+            {
+                const int ki = a.ki_h[j], kf = a.kf_h[j], kiK = ki * Kw;
+                for (int idx = tid; idx < np * kiK; idx += kThreads) {
+                    const int p = (int)divm(idx, a.mg_c1[j]);
+                    const int rem = idx - p * kiK;
+                    const int ii = (int)divm(rem, a.mg_k[j]);
+                    const int k = rem - ii * Kw, i = kf + ii;
+                    const wl_f2* col = mid + p * hK + (2 * i + a.base_h[j]) * Kw + k;
+                    float ll = 0.f, hl = 0.f, lh = 0.f, hh = 0.f;     // hl: W-hi / H-lo, lh: W-lo / H-hi
                     if (LT) {
 #pragma unroll
                         for (int t = 0; t < (LT ? LT : 1); ++t) {
-                            const wl_f2 v = col[(s + t) * Kw];
+                            const wl_f2 v = col[t * Kw];
                             ll = __builtin_fmaf(th0[t], v.x, ll); hl = __builtin_fmaf(th0[t], v.y, hl);
                             lh = __builtin_fmaf(th1[t], v.x, lh); hh = __builtin_fmaf(th1[t], v.y, hh);
                         }
                     } else {
                         for (int t = 0; t < L; ++t) {
-                            const wl_f2 v = col[(s + t) * Kw];
+                            const wl_f2 v = col[t * Kw];
                             ll = __builtin_fmaf(th0[t], v.x, ll); hl = __builtin_fmaf(th0[t], v.y, hl);
                             lh = __builtin_fmaf(th1[t], v.x, lh); hh = __builtin_fmaf(th1[t], v.y, hh);
                         }
                     }
-                } else {
+                    const int o1 = i * Kw + k;
+                    T* o = hp + (size_t)p * 3 * KK + o1;
+                    o[0] = (T)lh; o[KK] = (T)hl; o[2 * KK] = (T)hh;
+                    if (last) lp[p * KK + o1] = (T)ll; else nxt[p * KK + o1] = ll;     // [p][i][k]: the next level's planes, dense
+                }
+                const int nb = Kh - ki, nbK = nb * Kw;
+                for (int idx = tid; idx < np * nbK; idx += kThreads) {
+                    const int p = (int)divm(idx, a.mg_c2[j]);
+                    const int rem = idx - p * nbK;
+                    const int ib = (int)divm(rem, a.mg_k[j]);
+                    const int k = rem - ib * Kw, i = ib < kf ? ib : ib + ki;
+                    const wl_f2* col = mid + p * hK + k;
+                    const int s = 2 * i + a.base_h[j];
+                    float ll = 0.f, hl = 0.f, lh = 0.f, hh = 0.f;
                     for (int t = 0; t < L; ++t) {
                         const int r = ext_once(s + t, h, a.ext);
                         wl_f2 v; v.x = v.y = 0.f;
@@ -130,10 +161,11 @@ struct WlAfbSmall {
                         ll = __builtin_fmaf(th0[t], v.x, ll); hl = __builtin_fmaf(th0[t], v.y, hl);
                         lh = __builtin_fmaf(th1[t], v.x, lh); hh = __builtin_fmaf(th1[t], v.y, hh);
                     }
+                    const int o1 = i * Kw + k;
+                    T* o = hp + (size_t)p * 3 * KK + o1;
+                    o[0] = (T)lh; o[KK] = (T)hl; o[2 * KK] = (T)hh;
+                    if (last) lp[p * KK + o1] = (T)ll; else nxt[p * KK + o1] = ll;
                 }
-                T* o = hp + (size_t)p * 3 * KK + rem;
-                o[0] = (T)lh; o[KK] = (T)hl; o[2 * KK] = (T)hh;
-                if (last) lp[idx] = (T)ll; else nxt[idx] = ll;        // [p][i][k]: the next level's planes, dense
             }
             ctx.sync();
         }
@@ -224,13 +256,19 @@ struct WlSmallSynArgs {
     int llh, llw;
     int Kh[WL_SMALL_MAXLEV], Kw[WL_SMALL_MAXLEV], OH[WL_SMALL_MAXLEV], OW[WL_SMALL_MAXLEV];
     unsigned mg_pk[WL_SMALL_MAXLEV], mg_k[WL_SMALL_MAXLEV], mg_pq[WL_SMALL_MAXLEV], mg_q[WL_SMALL_MAXLEV];   // d = OH Kw, Kw, OH OW, OW
+    unsigned mg2_pk[WL_SMALL_MAXLEV], mg2_pq[WL_SMALL_MAXLEV], mg2_q[WL_SMALL_MAXLEV];   // pair form: d = ceil(OH/2) Kw, OH ceil(OW/2), ceil(OW/2)
     int h_off[WL_SMALL_MAXLEV];        // LDS byte offset of level j's high-pass planes ([p][3][Kh][Kw])
     int ll_off[2], mid_off, tap_off, lds_bytes;
 };
 
-template <typename T>
+// LT = compile-time tap count (2, 4, 6, 8; every mode but periodization): the PAIR form - the output pair (2q, 2q + 1) of an axis
+// reads coefficients q .. q + L/2 - 1, (y[2q], y[2q+1]) += (g[L-2-2i], g[L-1-2i]) c[q + i], taps in registers, no search for the
+// tap range per output (the general form below spent more on its loop bounds than on its two or four taps: the synthesis ran
+// at half the fraction of the analysis on feature-map shapes).  LT = 0: any even L, periodization included.
+template <typename T, int LT = 0>
 struct WlSfbSmall {
     typedef WlSmallSynArgs<T> Args;
+    static const int HL = LT / 2;
     static const int kThreads = 256;
     static const int kMinWaves = 2;
     static WL_HD unsigned divm(unsigned n, unsigned magic) { return magic ? (unsigned)(((unsigned long long)n * magic) >> 32) : n; }
@@ -285,8 +323,64 @@ struct WlSfbSmall {
             float* const nxt = reinterpret_cast<float*>(ctx.smem + a.ll_off[(J - j) & 1]);
             const float* const hb = reinterpret_cast<const float*>(ctx.smem + a.h_off[j]);
             wl_f2* const mid = reinterpret_cast<wl_f2*>(ctx.smem + a.mid_off);
+            const int OK = OH * Kw, OO = OH * OW;
+            T* const yp = a.y + (size_t)plane0 * OO;
+            if (LT) {
+                float ch0[LT ? LT : 1], ch1[LT ? LT : 1], cw0[LT ? LT : 1], cw1[LT ? LT : 1];
+#pragma unroll
+                for (int t = 0; t < (LT ? LT : 1); ++t) { ch0[t] = tp[2 * L + t]; ch1[t] = tp[3 * L + t]; cw0[t] = tp[t]; cw1[t] = tp[L + t]; }
+                // ---- along H, two output rows per item
+                const int OH2 = (OH + 1) >> 1, O2K = OH2 * Kw;
+                for (int idx = tid; idx < np * O2K; idx += kThreads) {
+                    const int p = (int)divm(idx, a.mg2_pk[j]);
+                    const int rem = idx - p * O2K;
+                    const int rq = (int)divm(rem, a.mg_k[j]);
+                    const int k = rem - rq * Kw;
+                    const float* lp = ll + p * llh * llw + k;
+                    const float* hp = hb + p * 3 * KK + k;
+                    float lo0 = 0.f, lo1 = 0.f, hi0 = 0.f, hi1 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < (LT ? HL : 1); ++i) {
+                        const int kk = rq + i;
+                        if (kk < Kh) {
+                            const float vll = lp[kk * llw], vlh = hp[kk * Kw], vhl = hp[KK + kk * Kw], vhh = hp[2 * KK + kk * Kw];
+                            const float a0 = ch0[LT - 2 - 2 * i], a1 = ch0[LT - 1 - 2 * i], b0 = ch1[LT - 2 - 2 * i], b1 = ch1[LT - 1 - 2 * i];
+                            lo0 += a0 * vll + b0 * vlh; lo1 += a1 * vll + b1 * vlh;
+                            hi0 += a0 * vhl + b0 * vhh; hi1 += a1 * vhl + b1 * vhh;
+                        }
+                    }
+                    wl_f2 u0; u0.x = lo0; u0.y = hi0;
+                    mid[p * OK + (2 * rq) * Kw + k] = u0;
+                    if (2 * rq + 1 < OH) { wl_f2 u1; u1.x = lo1; u1.y = hi1; mid[p * OK + (2 * rq + 1) * Kw + k] = u1; }
+                }
+                ctx.sync();
+                // ---- along W, two output columns per item
+                const int OW2 = (OW + 1) >> 1, OHW2 = OH * OW2;
+                for (int idx = tid; idx < np * OHW2; idx += kThreads) {
+                    const int p = (int)divm(idx, a.mg2_pq[j]);
+                    const int rem = idx - p * OHW2;
+                    const int r = (int)divm(rem, a.mg2_q[j]);
+                    const int cq = rem - r * OW2;
+                    const wl_f2* m2 = mid + p * OK + r * Kw + cq;
+                    float y0 = 0.f, y1 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < (LT ? HL : 1); ++i) {
+                        if (cq + i < Kw) {
+                            const wl_f2 v = m2[i];
+                            y0 += cw0[LT - 2 - 2 * i] * v.x + cw1[LT - 2 - 2 * i] * v.y;
+                            y1 += cw0[LT - 1 - 2 * i] * v.x + cw1[LT - 1 - 2 * i] * v.y;
+                        }
+                    }
+                    const int o = p * OO + r * OW + 2 * cq;
+                    if (j == 0) { yp[o] = (T)y0; if (2 * cq + 1 < OW) yp[o + 1] = (T)y1; }
+                    else { nxt[o] = y0; if (2 * cq + 1 < OW) nxt[o + 1] = y1; }
+                }
+                ctx.sync();
+                llh = OH; llw = OW;
+                continue;
+            }
             // ---- along H: (ll, lh) -> lo, (hl, hh) -> hi at every column k < Kw (the crop of a larger ll is the index range)
-            const int ncol = np * OH * Kw, OK = OH * Kw;
+            const int ncol = np * OH * Kw;
             for (int idx = tid; idx < ncol; idx += kThreads) {
                 const int p = (int)divm(idx, a.mg_pk[j]);
                 const int rem = idx - p * OK;
@@ -302,8 +396,7 @@ struct WlSfbSmall {
             }
             ctx.sync();
             // ---- along W
-            const int nout = np * OH * OW, OO = OH * OW;
-            T* const yp = a.y + (size_t)plane0 * OO;
+            const int nout = np * OH * OW;
             for (int idx = tid; idx < nout; idx += kThreads) {
                 const int p = (int)divm(idx, a.mg_pq[j]);
                 const int rem = idx - p * OO;

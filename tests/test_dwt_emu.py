@@ -209,7 +209,7 @@ def test_small_plane_synthesis_kernel_vs_oracle_random_shapes(seed):
         yl, yh = xfm(x)
         c0 = pw.launch_count()
         rec = ifm((yl, yh))
-        assert pw.kernels_since(c0) == ['WlSfbSmall<float>'], pw.kernels_since(c0)
+        assert len(pw.kernels_since(c0)) == 1 and pw.kernels_since(c0)[0].startswith('WlSfbSmall<float'), pw.kernels_since(c0)
         ifm16 = pw.DWTInverse(wave=wave, mode='symmetric').half()      # (a module of its own: .half() rounds the taps in place)
         rec16 = ifm16((yl.half(), [h.half() for h in yh]))
         assert rec16.dtype == torch.float16 and float((rec16.float() - rec).abs().max()) <= 4e-3 * max(1.0, float(rec.abs().max()))
