@@ -625,13 +625,15 @@ def other_configs(pw, dev, sync):
         other['scatlayer_256x3x256x256_fp32_one_gpu'] = {
             'fwd_ms': round(ts, 4), 'mpix_s': round(xs.numel() / ts / 1e3, 1),
             'frac_of_hbm_peak_at_11B_per_px': frac(11 * xs.numel(), ts), 'fwd_kernels': names(lambda: sl(xs))}
-        # f2: ScatLayerj2 and the rotationally symmetric variant (no fused kernel: single-axis launches)
+        # f2: ScatLayerj2 (three launches writing into its 49-entry output; 16.25 B per pixel = read x, write Z) and the
+        # rotationally symmetric variant
         xs2 = xs[:64]
         s2 = pw.ScatLayerj2().to(dev)
         t2 = time_seq_fn(lambda: s2(xs2), 20, sync)
         sr = pw.ScatLayer(biort='near_sym_b_bp').to(dev)
         tr = time_seq_fn(lambda: sr(xs2), 20, sync)
         other['scatlayerj2_64x3x256x256_fp32'] = {'fwd_ms': round(t2, 4), 'mpix_s': round(xs2.numel() / t2 / 1e3, 1),
+                                                  'frac_of_hbm_peak_at_16_25B_per_px': frac(16.25 * xs2.numel(), t2),
                                                   'fwd_kernels': names(lambda: s2(xs2))}
         other['scatlayer_rot_near_sym_b_bp_64x3x256x256_fp32'] = {
             'fwd_ms': round(tr, 4), 'mpix_s': round(xs2.numel() / tr / 1e3, 1),

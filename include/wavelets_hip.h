@@ -196,6 +196,24 @@ int wl_scat_fwd_level1(const void* x, void* z, void* drdx, void* drdy, void* ll,
                        int W, const void* h0, int L0, const void* h1, int L1, int mode, double magbias,
                        int combine_colour, void* stream);
 
+/* ScatLayerj2_f.forward (scatternet/lowlevel.py:205-295) concatenates the outputs of three transforms into its
+ * (N,49,C,H/4,W/4) tensor; these two entry points let each transform write its entries in place.  Addresses in elements of
+ * the dtype, for image n and channel c, q = the number of samples of an output plane: the averaged lowpass at
+ * z + n z_batch_stride + z_ll_offset + c q, smoothed magnitude o (0..5) at z + n z_batch_stride + z_mag_offset + (o C + c) q.
+ * z_ll_offset < 0: the averaged lowpass is not written.
+ *   wl_scat_fwd_level1_into: wl_scat_fwd_level1 without combine_colour / saved tensors, q = (He/2)(We/2)
+ *     (lowlevel.py:214-222 first scale, :255-262 second-order layer);
+ *   wl_scat_fwd_level2_into: the second scale (:237-253: fwd_j2plus of the full-resolution lowpass x (N,C,H,W), H and W
+ *     multiples of 4, then the 2x2 average of its lowpass and the magnitudes of its band-pass coefficients), q = (H/4)(W/4).
+ *     Streaming kernel only (10-tap q-shift filters, planes that fill the chip): WL_ERR_UNSUPPORTED otherwise and the
+ *     caller composes wl_dtcwt_fwd_level2 with its own epilogue. */
+int wl_scat_fwd_level1_into(const void* x, void* z, int64_t z_batch_stride, int64_t z_ll_offset, int64_t z_mag_offset,
+                            void* ll, int dtype, int64_t N, int C, int H, int W, const void* h0, int L0, const void* h1,
+                            int L1, int mode, double magbias, void* stream);
+int wl_scat_fwd_level2_into(const void* x, void* z, int64_t z_batch_stride, int64_t z_ll_offset, int64_t z_mag_offset,
+                            int dtype, int64_t N, int C, int H, int W, const void* h0a, const void* h0b, const void* h1a,
+                            const void* h1b, int L, double magbias, void* stream);
+
 /* ScatLayer backward = ScatLayerj1_f.backward (scatternet/lowlevel.py:114-137) in ONE launch: the prologue
  * (1/4 nearest-upsample of the lowpass gradient, dr*re/r, dr*im/r) is fused into the staging of the level-1 inverse.
  * dz: gradient of z, same layout as z; drdx/drdy: as written by wl_scat_fwd_level1; dx (N,C,H,W) with H, W the

@@ -32,6 +32,8 @@ PROTOTYPES = {
     'wl_dtcwt_inv_level1': (I, [P, L, I, P, P, I, L, I, I, P, I, P, I, I, P]),
     'wl_dtcwt_inv_level2': (I, [P, L, I, P, P, I, L, I, I, P, P, P, P, I, P]),
     'wl_scat_fwd_level1': (I, [P, P, P, P, P, I, L, I, I, I, P, I, P, I, I, C.c_double, I, P]),
+    'wl_scat_fwd_level1_into': (I, [P, P, L, L, L, P, I, L, I, I, I, P, I, P, I, I, C.c_double, P]),
+    'wl_scat_fwd_level2_into': (I, [P, P, L, L, L, I, L, I, I, I, P, P, P, P, I, C.c_double, P]),
     'wl_dwt1d_analysis_fused': (I, [P, P, C.POINTER(P), I, L, I, I, P, P, I, I, P]),
     'wl_dwt2d_analysis_small': (I, [P, P, C.POINTER(P), I, L, I, I, I, P, P, P, P, I, I, P]),
     'wl_dwt2d_synthesis_small': (I, [P, I, I, C.POINTER(P), C.POINTER(I), C.POINTER(I), P, I, L, I, P, P, P, P, I, I, P]),

@@ -72,21 +72,24 @@ struct WlDtFusedArgs {
 // full-resolution lowpass for ScatLayerj2), MODE 3: MODE 1 + (re, im) / r saved for the backward pass (a compile-time
 // variant: the inference kernel does not carry the pointers of the saved tensors through its scalar registers).
 // MODE 4: fwd_j2plus alone - the stagers put the rows of the level's input (and their mirrored cells: exact, no symmetry
-// assumed) straight into the ring the level-2 lanes read; no level-1 waves.
+// assumed) straight into the ring the level-2 lanes read; no level-1 waves.  MODE 5: MODE 4 with ScatLayerj2's epilogue (the
+// 2x2-averaged lowpass and the smoothed magnitudes instead of LL2 and the band-pass coefficients).
 // PP = 2 (lean level-1 kernels, planes of up to 256 columns): a workgroup owns TWO consecutive planes - level-1 waves 0, 1 the
 // first, 2, 3 the second, every stager wave its row of both (the staged rows lie side by side) - so that all four level-1
 // waves of the wide-plane kernel work (with one 256-column plane per workgroup of two level-1 waves + two stagers ScatLayer
-// ran at 0.49-0.51 of its roofline against 0.55-0.57 on 512-column planes).
+// ran at 0.49-0.51 of its roofline against 0.55-0.57 on 512-column planes).  PP = 4: planes of up to 128 columns, one per
+// level-1 wave (the second-order layer of ScatLayerj2 on 256 x 256 images: 18 planes of 128 x 128 per image).
 template <typename T, int L0, int L1, int LQ, int MODE = 2, int CW_ = 4, int PP = 1>
 struct WlDtFwd12Strip {
     typedef WlDtFusedArgs<T> Args;
-    static_assert(PP == 1 || (PP == 2 && CW_ == 4 && MODE != 2 && MODE != 4), "two planes per workgroup: lean level-1 kernels only");
+    static const bool kL2 = MODE == 4 || MODE == 5;    // fwd_j2plus alone (5: with ScatLayerj2's epilogue)
+    static_assert(PP == 1 || ((PP == 2 || PP == 4) && CW_ == 4 && MODE != 2 && MODE != 4 && MODE != 5), "several planes per workgroup: lean level-1 kernels only");
 #ifndef WL_DT12_SW
 #define WL_DT12_SW 4
 #endif
     // level-1, level-2 and stager waves (CW_ = 2: planes of up to 256 columns, two stagers of two rows each: one wave of the
     // workgroup per SIMD)
-    static const int CW = MODE == 4 ? 0 : CW_, QW = MODE == 2 || MODE == 4 ? CW_ : 0, SW = CW_ == 2 ? 2 : WL_DT12_SW;
+    static const int CW = kL2 ? 0 : CW_, QW = (MODE == 2 || kL2) ? CW_ : 0, SW = CW_ == 2 ? 2 : WL_DT12_SW;
     static const int LROWS = 4 / SW;                   // rows of a half-batch per stager wave
     static const int kWaves = CW + QW + SW;
     static const int kThreads = 64 * kWaves;
@@ -100,16 +103,16 @@ struct WlDtFwd12Strip {
     // CU) nothing spills: 0.235 ms.  The inference kernel fits 78 registers and is faster at six.)
     static const int kMinWaves = MODE == 3 ? 4 : (kScat ? WL_DT12_MINW1 : (SW == 2 && MODE == 2 ? 5 : 6));
     static const int SZ = (int)sizeof(T);
-    static const int M0 = L0 / 2, M1 = L1 / 2, M = MODE == 4 ? 0 : (M0 > M1 ? M0 : M1);   // (MODE 4: no level-1 filters)
+    static const int M0 = L0 / 2, M1 = L1 / 2, M = kL2 ? 0 : (M0 > M1 ? M0 : M1);   // (MODE 4: no level-1 filters)
     static const int LW = (2 * M + 1 + 3) / 4 * 4;
     static const int PERIOD = LW / 4;
     static const int NS = 2 + 2 * M;
     static const int NC2 = NS / 2;
-    static const int HQ = MODE == 2 || MODE == 4 ? LQ - 2 : 0;   // LL1 columns / rows level 2 reads beyond its own, either side
+    static const int HQ = (MODE == 2 || kL2) ? LQ - 2 : 0;   // LL1 columns / rows level 2 reads beyond its own, either side
     static const int HG = HQ / 4;                      // the same in 4-row groups
     static const int NW2 = 2 * LQ;                     // rows of the level-2 window
     static const int NG2 = NW2 / 4;
-    static const int WARM1 = MODE == 4 ? 0 : (2 * M + 3) / 4;   // half-batches before the first LL1 row of a segment is complete
+    static const int WARM1 = kL2 ? 0 : (2 * M + 3) / 4;   // half-batches before the first LL1 row of a segment is complete
     static const int MAXG = 3;                         // 4-cell groups per stager lane and row
 #ifndef WL_DT12_PF
 #define WL_DT12_PF 2
@@ -136,8 +139,8 @@ struct WlDtFwd12Strip {
         s.qb = s.q1 < Q ? s.q1 + HQ / 2 : Q;
         // columns the stagers provide: MODE 4 stages the ring level 2 reads (own columns + HQ either side), the others the
         // samples of the level-1 lanes
-        s.e_lo = MODE == 4 ? 2 * s.q0 - HQ : 2 * s.qa - M;
-        const int e_hi = MODE == 4 ? 2 * s.q1 - 1 + HQ : 2 * s.qb - 1 + M;
+        s.e_lo = kL2 ? 2 * s.q0 - HQ : 2 * s.qa - M;
+        const int e_hi = kL2 ? 2 * s.q1 - 1 + HQ : 2 * s.qb - 1 + M;
         s.nl = s.e_lo < 0 ? -s.e_lo : 0;
         s.nr = e_hi > a.f.W - 1 ? e_hi - (a.f.W - 1) : 0;
         s.gc0 = (s.e_lo < 0 ? 0 : s.e_lo) / 4;
@@ -163,7 +166,7 @@ struct WlDtFwd12Strip {
     // ---- stager wave: row `sidx` of every half-batch --------------------------------------------------------------------
     typedef T Quad4 __attribute__((ext_vector_type(4), aligned(sizeof(T)), may_alias));
     struct RowRegs { Quad4 g[LROWS][MAXG]; T h[LROWS]; };
-    static const int SLACK = MODE == 4 ? 0 : 4;        // staged cell of column e_lo (MODE 4: e_lo is a multiple of 4, groups start on it)
+    static const int SLACK = kL2 ? 0 : 4;        // staged cell of column e_lo (MODE 4: e_lo is a multiple of 4, groups start on it)
     template <int NGL>
     static WL_DEV void stager(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int lane, int sidx) {
         const WlDtFwd1Args<T>& f = a.f;
@@ -171,24 +174,25 @@ struct WlDtFwd12Strip {
         const int row_stride = f.W * SZ;
         // (PP = 2: groups [ng, 2 ng) are the second plane's - H W elements further on in memory, half a staged row further
         // on in LDS; an odd number of planes leaves the last workgroup's second half empty)
-        const bool two = PP == 2 && plane + 1 < f.NC;
-        const int sub_src = f.H * f.W * SZ, sub_dst = a.st_pitch / 2;
+        const int np = f.NC - plane < PP ? (int)(f.NC - plane) : PP;      // planes of this workgroup that exist
+        const int sub_src = f.H * f.W * SZ, sub_dst = a.st_pitch / PP;
         int goff[MAXG], gdst[MAXG];
 #pragma unroll
         for (int i = 0; i < MAXG; ++i) {
             const int g0 = lane + 64 * i;
-            const int sub = PP == 2 && g0 >= s.ng ? 1 : 0;
-            const int g = g0 - sub * s.ng;
+            int sub = 0, g = g0;
+#pragma unroll
+            for (int u = 1; u < PP; ++u) if (g >= s.ng) { g -= s.ng; ++sub; }
             const int col = 4 * (s.gc0 + g);
-            const bool on = g < s.ng && (sub == 0 || two);
+            const bool on = g < s.ng && sub < np;
             goff[i] = on ? col * SZ + sub * sub_src : 0;
             gdst[i] = on ? (col - s.e_lo + SLACK) * 4 + sub * sub_dst : -1;
         }
-        int hdst = -1, hoff = 0;                               // one mirrored cell per lane (PP = 2: lanes 32 .. for the second plane)
+        int hdst = -1, hoff = 0;                               // one mirrored cell per lane (PP planes: 64 / PP lanes each)
         {
-            const int sub = PP == 2 && lane >= 32 ? 1 : 0;
-            const int l = lane - 32 * sub;
-            if (l < s.nl + s.nr && (sub == 0 || two)) {
+            const int sub = PP > 1 ? lane / (64 / PP) : 0;
+            const int l = lane - (64 / PP) * sub;
+            if (l < s.nl + s.nr && sub < np) {
                 const int e = l < s.nl ? s.e_lo + l : f.W + (l - s.nl);
                 hdst = (e - s.e_lo + SLACK) * 4 + sub * sub_dst;
                 hoff = wl_ext(e, f.W, WL_EXT_SYM) * SZ + sub * sub_src;
@@ -207,7 +211,7 @@ struct WlDtFwd12Strip {
         auto stage = [&](int hb, const RowRegs& rr) {
 #pragma unroll
             for (int r4 = 0; r4 < LROWS; ++r4) {
-                char* srow = MODE == 4 ? ctx.smem + a.l1_off + ((hb & 1) * 4 + LROWS * sidx + r4) * a.l1_pitch
+                char* srow = kL2 ? ctx.smem + a.l1_off + ((hb & 1) * 4 + LROWS * sidx + r4) * a.l1_pitch
                                        : ctx.smem + a.st_off + ((hb & 1) * 4 + LROWS * sidx + r4) * a.st_pitch;
 #pragma unroll
                 for (int i = 0; i < NGL; ++i) {
@@ -295,8 +299,8 @@ struct WlDtFwd12Strip {
     // what overflows first: spilled taps come back through v_readlane + wait states).
     static WL_DEV void level1(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane0, int cw0, int lane) {
         const WlDtFwd1Args<T>& f = a.f;
-        const int sub = PP == 2 ? cw0 / (CW / 2) : 0;          // PP = 2: waves 0, 1 the first plane, 2, 3 the second
-        const int cw = PP == 2 ? cw0 % (CW / 2) : cw0;
+        const int sub = PP > 1 ? cw0 / (CW / PP) : 0;          // PP = 2: waves 0, 1 the first plane, 2, 3 the second; PP = 4: a plane each
+        const int cw = PP > 1 ? cw0 % (CW / PP) : cw0;
         const int64_t plane = plane0 + sub;
         const int q = s.qa + 64 * cw + lane;
         const bool active = q < s.qb && plane < f.NC;
@@ -313,7 +317,7 @@ struct WlDtFwd12Strip {
         for (int u = 0; u < (L0 + 1) / 2; ++u) R.c0[u] = wl_uniform_v2(wl_v2{(float)f.h0[2 * u], 2 * u + 1 < L0 ? (float)f.h0[2 * u + 1 < L0 ? 2 * u + 1 : 0] : 0.f});
 #pragma unroll
         for (int u = 0; u < (L1 + 1) / 2; ++u) R.c1[u] = wl_uniform_v2(wl_v2{(float)f.h1[2 * u], 2 * u + 1 < L1 ? (float)f.h1[2 * u + 1 < L1 ? 2 * u + 1 : 0] : 0.f});
-        const int soff = 16 + 8 * (active ? q - s.qa : 0) + (PP == 2 ? sub * (a.st_pitch / 2) : 0);
+        const int soff = 16 + 8 * (active ? q - s.qa : 0) + (PP > 1 ? sub * (a.st_pitch / PP) : 0);
         // LL1 ring: cell 0 = pixel column 2 q0 - HQ.  At the plane's edges the mirrored copies go out with the pixel pair.
         const int Q = f.W / 2;
         const int l1c = 2 * q - (2 * s.q0 - HQ);
@@ -332,7 +336,9 @@ struct WlDtFwd12Strip {
         const int64_t n_img = kScat ? plane / f.C : 0;
         const int c_img = kScat ? (int)(plane - n_img * f.C) : 0;
         const size_t zplane = (size_t)f.C * (f.H / 2) * Q * SZ;
-        char* const zbase = reinterpret_cast<char*>(f.z) + ((size_t)n_img * 7 * f.C + c_img) * ((size_t)(f.H / 2) * Q) * SZ;
+        char* const zbase = reinterpret_cast<char*>(f.z) + ((size_t)n_img * f.z_bs + (size_t)c_img * ((size_t)(f.H / 2) * Q)) * SZ;
+        const size_t zmag = (size_t)f.z_mag_off * SZ;
+        const long zll = (long)f.z_ll_off * SZ;                                 // (negative: no lowpass entry)
         const size_t dbase = ((size_t)n_img * 6 * f.C + c_img) * ((size_t)(f.H / 2) * Q) * SZ;
         wl_v2 wa[LW], wb[LW];
 #pragma unroll
@@ -417,7 +423,7 @@ struct WlDtFwd12Strip {
                         // ScatLayer: |z_o| smoothed.  re^2 + im^2 = ((v0 -+ v3)^2 + (v1 +- v2)^2) / 2
                         const float b = (float)f.magbias, b2 = b * b;
                         char* const zp = zbase + (size_t)(qrow * SZ) + voff1;       // (n, 0, c, qr, q)
-                        *reinterpret_cast<T*>(zp) = (T)((pL[0].x + pL[1].x + aL.x + bL.x) * 0.25f);
+                        if (zll >= 0) *reinterpret_cast<T*>(zp + zll) = (T)((pL[0].x + pL[1].x + aL.x + bL.x) * 0.25f);
                         const float v0[3] = {lh0, hh0, hl0}, v1[3] = {lh1, hh1, hl1}, v2[3] = {lh2, hh2, hl2}, v3[3] = {lh3, hh3, hl3};
 #pragma unroll
                         for (int u = 0; u < 3; ++u) {
@@ -427,7 +433,7 @@ struct WlDtFwd12Strip {
                                 const float d = w2i ? v0[u] + v3[u] : v0[u] - v3[u];
                                 const float e = w2i ? v1[u] - v2[u] : v1[u] + v2[u];
                                 const float r = wl_sqrt(0.5f * (d * d + e * e) + b2);
-                                *reinterpret_cast<T*>(zp + (size_t)(o6 + 1) * zplane) = (T)(r - b);
+                                *reinterpret_cast<T*>(zp + zmag + (size_t)o6 * zplane) = (T)(r - b);
                                 if (MODE == 3) {
                                     const float ir = k / r;
                                     char* const dp = reinterpret_cast<char*>(f.drdx) + dbase + (size_t)o6 * zplane + (size_t)(qrow * SZ) + voff1;
@@ -480,6 +486,13 @@ struct WlDtFwd12Strip {
         const unsigned lvoff = Cc * SZ, hvoff = (Cc / 2) * 2u * SZ + (half ? 5u * qplane2 : 0u);
         const long hstep = half ? -(long)qplane2 : (long)qplane2;               // my three orientations: 0, 1, 2 or 5, 4, 3
         typedef WlPair<T> Pair;
+        // MODE 5: image n, channel c of the (N, .., C, H/4, W/4) output: the averaged lowpass and magnitude 0 (the others C planes apart)
+        const int64_t n_img = MODE == 5 ? plane / f.C : 0;
+        const size_t zq = (size_t)(f.H / 4) * Q2;
+        char* const zimg = reinterpret_cast<char*>(f.z) + ((size_t)n_img * f.z_bs + (size_t)(plane - n_img * f.C) * zq) * SZ;
+        char* const zll = zimg + f.z_ll_off * SZ;                               // (z_ll_off < 0: no lowpass entry)
+        char* const zmg = zimg + f.z_mag_off * SZ;
+        const size_t zstep = (size_t)f.C * zq * SZ;
         const int l1lane = half * a.l1_pitch + 16 * j;
         // MODE 2: the level-1 lanes fill ring slot hb & 1 AFTER barrier hb, level 2 reads it one half-batch later; MODE 4:
         // the stagers fill it BEFORE barrier hb, level 2 reads it right after
@@ -524,7 +537,7 @@ struct WlDtFwd12Strip {
                     wl_pk_fma_x_v(xL1, tC[t], vO); wl_pk_fma_y_v(xH0, tC[t], vO);
                 }
                 if ((WL_DT12_ABLATE & 4) && xL0.x != 12345.f) continue;
-                if (active) {
+                if (active && MODE != 5) {
                     Pair p0;
                     p0.a = (T)xL0.x; p0.b = (T)xL1.x;
                     *reinterpret_cast<Pair*>(lbase + (size_t)((unsigned)(2 * kr) * (unsigned)Q * SZ) + lvoff) = p0;
@@ -551,7 +564,23 @@ struct WlDtFwd12Strip {
                     const float v0 = half ? pH0x : xH0.x, v1 = half ? pH1x : xH1.x, v2 = half ? xH0.x : pH0x, v3 = half ? xH1.x : pH1x;
                     re[2] = (v0 + sg * v3) * k; im[2] = (v1 - sg * v2) * k;
                 }
-                if (active) {
+                if (MODE == 5) {
+                    // ScatLayerj2 (scatternet/lowlevel.py:237-262): the 2x2 average of LL2 (my row's two columns + the other
+                    // parity's) and the smoothed magnitudes of my three orientations
+                    const float mine = xL0.x + xL1.x;
+                    const float avg = 0.25f * (mine + wl_shfl(mine, partner));
+                    const float b = (float)f.magbias, b2 = b * b;
+                    if (active) {
+                        const unsigned zoff = ((unsigned)kr * (unsigned)Q2 + Cc / 2) * SZ;
+                        if (!half && f.z_ll_off >= 0) *reinterpret_cast<T*>(zll + zoff) = (T)avg;
+                        char* zp = zmg + zoff + (half ? 5 * zstep : 0);
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) {
+                            *reinterpret_cast<T*>(zp) = (T)(wl_sqrt(re[u] * re[u] + im[u] * im[u] + b2) - b);
+                            zp += half ? -(long)zstep : (long)zstep;
+                        }
+                    }
+                } else if (active) {
                     char* hp = hbase + (size_t)((unsigned)kr * (unsigned)Q2 * 2u * SZ) + hvoff;
 #pragma unroll
                     for (int u = 0; u < 3; ++u) {
@@ -580,10 +609,10 @@ struct WlDtFwd12Strip {
             if (ngl <= 1) stager<1>(a, s, ctx, plane, lane, wave - CW - QW);
             else if (ngl == 2) stager<2>(a, s, ctx, plane, lane, wave - CW - QW);
             else stager<3>(a, s, ctx, plane, lane, wave - CW - QW);
-        } else if ((MODE == 2 || MODE == 4) && wave >= CW) {
+        } else if (((MODE == 2 || kL2)) && wave >= CW) {
             level2(a, s, ctx, plane, wave - CW, lane);
         } else {
-            if constexpr (MODE != 4) level1(a, s, ctx, plane, wave, lane);
+            if constexpr (!kL2) level1(a, s, ctx, plane, wave, lane);
         }
     }
 };

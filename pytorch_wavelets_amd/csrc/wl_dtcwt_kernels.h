@@ -34,6 +34,11 @@ struct WlDtFwd1Args {
     T* ll;           // (NC, He, We) or nullptr
     T* highs;        // (NC, 6, He/2, We/2, 2) or nullptr (skip_hps)
     T* z;            // ScatLayer output (N, 7, C, He/2, We/2) [or (N, 3+6, ..) when combine] or nullptr
+    // where the entries of image n go (elements; not when combining colour): the averaged lowpass of channel c at
+    // z + n z_bs + z_ll_off + c q, magnitude o at z + n z_bs + z_mag_off + (o C + c) q, q = (He/2)(We/2).  The layer's own
+    // layout is z_bs = 7 C q, z_ll_off = 0, z_mag_off = C q; ScatLayerj2 points them into its 49-entry output (z_ll_off < 0:
+    // no lowpass entry).
+    int64_t z_bs, z_ll_off, z_mag_off;
     T* drdx;         // ScatLayer saved re/r, im/r: (N, 6, C, He/2, We/2) or nullptr
     T* drdy;
     const A* h0;     // lowpass taps (L0, odd), stored order
@@ -107,12 +112,13 @@ WL_DEV void wl_dtfwd1_quad_out(const WlDtFwd1Args<T>& a, int64_t plane, int ch, 
     const A b2 = a.magbias * a.magbias;
     const A llavg = (ll[0] + ll[1] + ll[2] + ll[3]) * (A)0.25;
     if (!combine) {
-        T* zp = a.z + ((size_t)n * 7 * a.C + c) * qplane + q;
-        zp[0] = (T)llavg;
+        T* const zn = a.z + (size_t)n * a.z_bs + (size_t)c * qplane + q;
+        if (a.z_ll_off >= 0) zn[a.z_ll_off] = (T)llavg;
+        T* const zp = zn + a.z_mag_off;
 #pragma unroll
         for (int o = 0; o < 6; ++o) {
             const A r = wl_sqrt(re[o] * re[o] + im[o] * im[o] + b2);
-            zp[(size_t)(o + 1) * a.C * qplane] = (T)(r - a.magbias);
+            zp[(size_t)o * a.C * qplane] = (T)(r - a.magbias);
             if (a.drdx) {
                 const size_t so = (((size_t)n * 6 + o) * a.C + c) * qplane + q;
                 a.drdx[so] = (T)(re[o] / r);
@@ -236,6 +242,12 @@ struct WlDtFwd2Args {
     int L;
     int TH, TW, tiles_x, tiles_y;   // output (half-res) tile, multiples of 4
     int64_t nblocks;                // specialised kernel: grid size for the XCD-aware block remap (0 = off)
+    // ScatLayerj2's second scale (streaming kernel only): instead of ll / highs the 2x2-averaged lowpass and the smoothed
+    // magnitudes go to z, addressed like WlDtFwd1Args::z (q = (H/4)(W/4)); nullptr = off
+    T* z;
+    int64_t z_bs, z_ll_off, z_mag_off;
+    int C;
+    A magbias;
 };
 
 template <typename T>

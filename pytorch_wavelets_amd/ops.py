@@ -993,6 +993,48 @@ def scat_fwd1(x, h0, h1, mode, magbias, combine_colour, save, want_ll=False):
     return (z, dx, dy, ll) if want_ll else (z, dx, dy)
 
 
+def scat_fwd1_into(x, z, z_bs, z_ll_off, z_mag_off, h0, h1, mode, magbias, ll=None):
+    """ScatLayer forward of x (N,C,H,W; H, W even) with its entries written into the caller's tensor `z` (contiguous): for
+    image n, channel c the averaged lowpass at element n z_bs + z_ll_off + c q, magnitude o at n z_bs + z_mag_off + (o C + c) q,
+    q = (H/2)(W/2) (z_ll_off < 0: no lowpass entry); `ll` (N,C,H,W, optional) receives the full-resolution lowpass (wl_scat_fwd_level1_into)."""
+    _check_tensor(x, 'x')
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    q = (H // 2) * (W // 2)
+    assert H % 2 == 0 and W % 2 == 0 and z.is_contiguous() and z.dtype == x.dtype and z.device == x.device
+    last = (N - 1) * z_bs + max(z_ll_off + C * q, z_mag_off + 6 * C * q)
+    assert N == 0 or (min(z_bs, z_mag_off) >= 0 and last <= z.numel()), 'entries outside z'
+    t0, t1 = _taps(h0, x), _taps(h1, x)
+    rc = _call('wl_scat_fwd_level1_into', x, x.data_ptr(), z.data_ptr(), z_bs, z_ll_off, z_mag_off,
+               None if ll is None else ll.data_ptr(), _DTYPES[x.dtype], N, C, H, W, t0.data_ptr(), t0.numel(), t1.data_ptr(),
+               t1.numel(), mode, float(magbias), _stream(x))
+    _lib.check(rc, 'wl_scat_fwd_level1_into')
+
+
+def scat_fwd2_into(x, z, z_bs, z_ll_off, z_mag_off, h0a, h0b, h1a, h1b, magbias):
+    """Second scale of ScatLayerj2: fwd_j2plus of x (N,C,H,W; H, W multiples of 4), the 2x2 average of its lowpass and the
+    smoothed magnitudes of its band-pass coefficients written into `z` like scat_fwd1_into (q = (H/4)(W/4)).  Returns False
+    when the engine has no kernel for these taps / sizes (callers compose dtcwt_fwd2 + their own epilogue)."""
+    _check_tensor(x, 'x')
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    q = (H // 4) * (W // 4)
+    assert z.is_contiguous() and z.dtype == x.dtype and z.device == x.device
+    last = (N - 1) * z_bs + max(z_ll_off + C * q, z_mag_off + 6 * C * q)
+    assert N == 0 or (min(z_bs, z_ll_off, z_mag_off) >= 0 and last <= z.numel()), 'entries outside z'
+    key = ('scat2', x.dtype, N * C, H, W, int(h0a.numel()))
+    if H % 4 or W % 4 or key in _FUSED_DECLINED:
+        return False
+    ta, tb, tc, td = (_taps(h, x) for h in (h0a, h0b, h1a, h1b))
+    rc = _call('wl_scat_fwd_level2_into', x, x.data_ptr(), z.data_ptr(), z_bs, z_ll_off, z_mag_off, _DTYPES[x.dtype], N, C, H, W,
+               ta.data_ptr(), tb.data_ptr(), tc.data_ptr(), td.data_ptr(), ta.numel(), float(magbias), _stream(x))
+    if rc == -3:
+        _remember_decline(key)
+        return False
+    _lib.check(rc, 'wl_scat_fwd_level2_into')
+    return True
+
+
 def scat_bwd1(dz, drdx, drdy, h0, h1, mode, combine_colour):
     """ScatLayer backward in one launch: dz (gradient of Z), the saved re/r, im/r -> dx (N,C,He,We) (padded size).
     Returns None when the engine has no specialised kernel for these taps / dtype (callers compose the prologue

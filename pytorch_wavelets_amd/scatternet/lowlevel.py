@@ -98,6 +98,30 @@ def _smooth_mag(re, im, bias, sum_dim=None):
     return torch.sqrt(e + bias * bias) - bias
 
 
+FUSED_J2 = True    # inference: the three transforms of ScatLayerj2 write straight into its output (tests switch it off)
+
+
+def _scat_layer_j2_in_place(x, h0o, h1o, h0a, h0b, h1a, h1b, mode, bias):
+    """ScatLayerj2_f.forward without autograd and without colour combination: three launches, each writing its entries of the
+    (N, 49, C, H/4, W/4) output in place (reference scatternet/lowlevel.py:205-295 builds them apart and concatenates):
+      1. first scale: full-resolution lowpass s0 + first-order magnitudes (N, 6, C, H/2, W/2) (its pooled lowpass is not part
+         of the output and is not written),
+      2. second scale of s0: pooled lowpass -> entry 0, magnitudes -> entries 7..12,
+      3. second-order layer on the 6C magnitude planes: pooled -> entries 1..6, its 36 magnitudes -> entries 13..48."""
+    n, c, H, W = x.shape
+    q2, q4 = (H // 2) * (W // 2), (H // 4) * (W // 4)
+    Z = torch.empty((n, 49, c, H // 4, W // 4), dtype=x.dtype, device=x.device)
+    m1 = torch.empty((n, 6 * c, H // 2, W // 2), dtype=x.dtype, device=x.device)   # first-order magnitudes, (N, 6, C, ..) order
+    s0 = torch.empty((n, c, H, W), dtype=x.dtype, device=x.device)
+    ops.scat_fwd1_into(x, m1, 6 * c * q2, -1, 0, h0o, h1o, mode, bias, ll=s0)
+    if not ops.scat_fwd2_into(s0, Z, 49 * c * q4, 0, 7 * c * q4, h0a, h0b, h1a, h1b, bias):
+        ll2, highs = ops.dtcwt_fwd2(s0, h0a, h0b, h1a, h1b)                        # highs (N,C,6,h,w,2)
+        Z[:, 0] = F.avg_pool2d(ll2, 2)
+        Z[:, 7:13] = _smooth_mag(highs[..., 0], highs[..., 1], bias).transpose(1, 2)
+    ops.scat_fwd1_into(m1, Z, 49 * c * q4, c * q4, 13 * c * q4, h0o, h1o, mode, bias)
+    return Z
+
+
 def scat_layer_j2(x, h0o, h1o, h0a, h0b, h1a, h1b, mode, bias, combine_colour):
     """ScatLayerj2_f.forward (reference scatternet/lowlevel.py:205-295) as a chain of differentiable pieces, so that
     autograd reproduces its hand-written backward (:297-395; both are the exact adjoints - the level-1 filters are
@@ -109,6 +133,8 @@ def scat_layer_j2(x, h0o, h1o, h0a, h0b, h1a, h1b, mode, bias, combine_colour):
     from ..dtcwt.transform_funcs import FWD_J2PLUS
     if int_to_mode(mode) != 'symmetric':
         raise NotImplementedError()   # like upstream: the second scale's rowdfilt / coldfilt know only 'symmetric'
+    if FUSED_J2 and not combine_colour and not (torch.is_grad_enabled() and x.requires_grad):
+        return _scat_layer_j2_in_place(x, h0o, h1o, h0a, h0b, h1a, h1b, mode, bias)
     s0, Z1 = ScatLayerj1_ll_f.apply(x, h0o, h1o, mode, bias, combine_colour)
     ll2, highs = FWD_J2PLUS.apply(s0, h0a, h1a, h0b, h1b, False, 1, -1, mode)     # highs (N,6,C,h,w,2)
     s0 = F.avg_pool2d(ll2, 2)

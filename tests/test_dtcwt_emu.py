@@ -307,6 +307,37 @@ def test_lean_scatlayerj2_lowpass():
     assert float((out[0] - out[1]).abs().max()) <= 3e-6 * float(out[1].abs().max())
 
 
+@pytest.mark.parametrize('shape,dtype,expect', [
+    ((2, 2, 64, 256), torch.float32, ('10, 1, 4, 2>', '10, 5, 2>', '10, 1, 4, 4>')),     # pairs of planes; level 2; four 128-column planes
+    ((1, 1, 128, 256), torch.float32, ('10, 1, 2>', '10, 5, 2>', '10, 1, 4, 4>')),    # second order: 6 planes = 4 + 2
+    ((1, 3, 64, 512), torch.float32, ('10, 1>', '10, 5>', '10, 1, 4, 2>')),
+    ((2, 1, 40, 104), torch.float32, None),                                                   # small planes: tile kernels + the composed second scale
+    ((1, 2, 64, 512), torch.float16, None)])
+def test_scatlayerj2_in_place_equals_the_chain(shape, dtype, expect):
+    """ScatLayerj2 inference: three launches that write their entries of the 49-entry output in place (wl_scat_fwd_level1_into,
+    wl_scat_fwd_level2_into = WlDtFwd12Strip MODE 5, four 128-column planes per workgroup in the second-order layer) against the
+    chain of differentiable pieces + torch.cat."""
+    from pytorch_wavelets_amd.scatternet import lowlevel as sl
+    torch.manual_seed(0)
+    x = torch.randn(*shape, dtype=dtype)
+    with emu_backend.emulated():
+        m = pw.ScatLayerj2().to(dtype)
+        with torch.no_grad():
+            c0 = pw.launch_count()
+            z1 = m(x)
+            ks = pw.kernels_since(c0)
+            sl.FUSED_J2 = False
+            try:
+                z0 = m(x)
+            finally:
+                sl.FUSED_J2 = True
+    assert z1.shape == z0.shape and z1.shape[1] == 49 * shape[1]
+    if expect is not None:
+        assert len(ks) == 3 and all(e in k for e, k in zip(expect, ks)), ks
+    tol = 5e-3 if dtype == torch.float16 else 3e-6
+    assert float((z1.float() - z0.float()).abs().max()) <= tol * float(z0.float().abs().max())
+
+
 @pytest.mark.parametrize('shape,qshift,dtype', [((2, 1, 64, 256), 'qshift_a', torch.float32), ((1, 2, 72, 1024), 'qshift_a', torch.float32),
                                                 ((2, 1, 64, 256), 'qshift_b', torch.float32), ((2, 2, 64, 512), 'qshift_a', torch.float16)])
 def test_streaming_level2_inverse_equals_tile_kernel(shape, qshift, dtype):

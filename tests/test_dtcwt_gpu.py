@@ -453,3 +453,34 @@ def test_small_plane_level1_kernel(shape, biort, mode, dtype, grad):
     sel = [0, shape[0] - 1]
     want = wo.scat_layer_forward(x[sel].double().cpu().numpy(), hp[0], hp[1], mode)
     assert np.abs(out[0][0][sel].double().cpu().numpy() - want).max() <= (5e-3 if dtype == torch.float16 else 1e-5) * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize('shape,dtype,expect', [
+    ((32, 3, 256, 256), torch.float32, ('10, 1, 4, 2>', '10, 5, 2>', '10, 1, 4, 4>')),
+    ((5, 1, 256, 256), torch.float32, None),           # 30 second-order planes: the last workgroup of four holds two
+    ((16, 3, 512, 512), torch.float32, ('10, 1>', '10, 5>', '10, 1, 4, 2>')),
+    ((16, 3, 200, 136), torch.float32, None),          # padded to multiples of 8; narrow second-order planes: tile kernels
+    ((16, 3, 32, 32), torch.float32, None),            # CIFAR: the small-plane kernel writes into the 49-entry output too
+    ((8, 3, 512, 512), torch.float16, None)])
+def test_scatlayerj2_in_place_equals_the_chain(shape, dtype, expect):
+    """ScatLayerj2 inference = three launches that write their entries of the (N, 49 C, H/4, W/4) output in place
+    (wl_scat_fwd_level1_into, wl_scat_fwd_level2_into) against the chain of differentiable pieces + torch.cat, which the golden
+    tests pin to the reference; and against the float64 oracle."""
+    from pytorch_wavelets_amd.scatternet import lowlevel as sl
+    torch.manual_seed(0)
+    x = torch.randn(*shape, device=DEV, dtype=dtype)
+    m = pw.ScatLayerj2().to(DEV).to(dtype)
+    with torch.no_grad():
+        c0 = pw.launch_count()
+        z1 = m(x)
+        ks = pw.kernels_since(c0)
+        sl.FUSED_J2 = False
+        try:
+            z0 = m(x)
+        finally:
+            sl.FUSED_J2 = True
+    assert z1.shape == z0.shape and z1.shape[1] == 49 * shape[1]
+    if expect is not None:
+        assert len(ks) == 3 and all(e in k for e, k in zip(expect, ks)), ks
+    tol = 5e-3 if dtype == torch.float16 else 3e-6
+    assert float((z1.float() - z0.float()).abs().max()) <= tol * float(z0.float().abs().max())
