@@ -307,6 +307,39 @@ def test_lean_scatlayerj2_lowpass():
     assert float((out[0] - out[1]).abs().max()) <= 3e-6 * float(out[1].abs().max())
 
 
+@pytest.mark.parametrize('shape,dtype', [((2, 2, 64, 256), torch.float16), ((3, 2, 64, 128), torch.float16), ((3, 3, 40, 96), torch.float32), ((4, 2, 48, 64), torch.float32),
+                                         ((1, 5, 72, 112), torch.float32)])
+def test_narrow_and_half_precision_planes_on_the_streaming_kernels(shape, dtype):
+    """Four planes of 96-128 columns per workgroup (the last workgroup partly filled), float16 planes of 256 columns: DTCWT J = 2
+    forward / inverse and the ScatLayer training step, streaming kernels against tile kernels."""
+    from pytorch_wavelets_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(*shape).to(dtype)
+    out, names = {}, {}
+    with emu_backend.emulated():
+        xfm, ifm, sl = (m.to(dtype) for m in (pw.DTCWTForward(J=2), pw.DTCWTInverse(), pw.ScatLayer()))
+        try:
+            for ns in (0, 1):
+                ops.set_option('no_stream', ns)
+                c0 = pw.launch_count()
+                yl, yh = xfm(x)
+                y = ifm((yl, yh))
+                xg = x.clone().requires_grad_(True)
+                z = sl(xg)
+                g, = torch.autograd.grad(z, xg, torch.ones_like(z))
+                out[ns] = [yl, *yh, y, z.detach(), g]
+                names[ns] = pw.kernels_since(c0)
+        finally:
+            ops.set_option('no_stream', 0)
+    assert any('Strip' in k for k in names[0]) and not any('Strip' in k for k in names[1]), names
+    if shape[-1] <= 128:
+        assert any(k.endswith('4, 4>') for k in names[0]), names
+    tol = 6e-3 if dtype == torch.float16 else 5e-6
+    for u, v in zip(out[0], out[1]):
+        assert u.shape == v.shape
+        assert float((u.float() - v.float()).abs().max()) <= tol * float(v.float().abs().max())
+
+
 @pytest.mark.parametrize('shape,dtype,expect', [
     ((2, 2, 64, 256), torch.float32, ('10, 1, 4, 2>', '10, 5, 2>', '10, 1, 4, 4>')),     # pairs of planes; level 2; four 128-column planes
     ((1, 1, 128, 256), torch.float32, ('10, 1, 2>', '10, 5, 2>', '10, 1, 4, 4>')),    # second order: 6 planes = 4 + 2

@@ -484,3 +484,34 @@ def test_scatlayerj2_in_place_equals_the_chain(shape, dtype, expect):
         assert len(ks) == 3 and all(e in k for e, k in zip(expect, ks)), ks
     tol = 5e-3 if dtype == torch.float16 else 3e-6
     assert float((z1.float() - z0.float()).abs().max()) <= tol * float(z0.float().abs().max())
+
+
+@pytest.mark.parametrize('shape,dtype', [((64, 3, 256, 256), torch.float16), ((96, 3, 128, 128), torch.float16), ((96, 3, 128, 128), torch.float32),
+                                         ((40, 5, 96, 112), torch.float32), ((33, 3, 512, 256), torch.float16), ((128, 3, 72, 80), torch.float32)])
+def test_streaming_kernels_on_narrow_and_half_precision_planes_equal_the_tile_kernels(shape, dtype):
+    """Planes of 96-128 columns go four to a workgroup (PP = 4), float16 planes of 256 columns and more to the streaming kernels
+    like float32 ones (the rule is in columns, not bytes): DTCWT J = 2 forward / inverse and the ScatLayer training step against
+    the same transforms on the tile kernels (wl_set_option no_stream), which the golden tests pin to the reference."""
+    from pytorch_wavelets_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(*shape, device=DEV).to(dtype)
+    xfm, ifm, sl = (m.to(DEV).to(dtype) for m in (pw.DTCWTForward(J=2), pw.DTCWTInverse(), pw.ScatLayer()))
+    out, names = {}, {}
+    try:
+        for ns in (0, 1):
+            ops.set_option('no_stream', ns)
+            c0 = pw.launch_count()
+            yl, yh = xfm(x)
+            y = ifm((yl, yh))
+            xg = x.clone().requires_grad_(True)
+            z = sl(xg)
+            g, = torch.autograd.grad(z, xg, torch.ones_like(z))
+            out[ns] = [yl, *yh, y, z.detach(), g]
+            names[ns] = pw.kernels_since(c0)
+    finally:
+        ops.set_option('no_stream', 0)
+    assert any('Strip' in k for k in names[0]) and not any('Strip' in k for k in names[1]), names
+    tol = 6e-3 if dtype == torch.float16 else 5e-6
+    for u, v in zip(out[0], out[1]):
+        assert u.shape == v.shape
+        assert float((u.float() - v.float()).abs().max()) <= tol * float(v.float().abs().max())
