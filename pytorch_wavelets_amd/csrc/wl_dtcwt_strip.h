@@ -298,9 +298,10 @@ struct WlDtIStripArgs {
 // quad (dZ (N, 7, C, h, w), drdx / drdy (N, 6, C, h, w)) instead of the eight 8-byte loads of the plain inverse.
 // PP = 2 (planes of up to 256 columns): a workgroup owns TWO consecutive planes - compute waves 0, 1 and stager waves 0, 1 the
 // first, 2, 3 the second, the staged rows side by side - so that all eight waves work (wl_dtcwt_fused.h does the same for the
-// lean forward kernels).
+// lean forward kernels).  PP = 4: planes of up to 128 columns, one compute wave and one stager wave each.
 template <typename T, int L0, int L1, int SCAT = 0, int PP = 1>
 struct WlDtInv1Strip {
+    static_assert(PP == 1 || PP == 2 || PP == 4, "planes per workgroup");
     typedef WlDtIStripArgs<T> Args;
     static const int CW = 4;                           // compute waves: up to 256 quad columns per strip
     static const int kWaves = CW + 4;
@@ -363,8 +364,8 @@ struct WlDtInv1Strip {
         const WlDtInv1Args<T>& f = a.f;
         const int H2 = f.H / 2, W2 = f.W / 2;
         const size_t qplane = (size_t)H2 * W2;
-        const int sub = PP == 2 ? sidx0 / 2 : 0;              // PP = 2: stager waves 0, 1 the first plane, 2, 3 the second
-        const int sidx = PP == 2 ? sidx0 % 2 : sidx0;
+        const int sub = PP > 1 ? sidx0 / (4 / PP) : 0;        // PP = 2: stager waves 0, 1 the first plane, 2, 3 the second; PP = 4: a plane each
+        const int sidx = PP > 1 ? sidx0 % (4 / PP) : sidx0;
         const int64_t plane = plane0 + sub;
         const int sub_off = sub * (a.st_pitch / PP);
         const int j = 64 * sidx + lane;                       // this lane's quad of every quad row
@@ -507,8 +508,8 @@ struct WlDtInv1Strip {
 
     static WL_DEV void compute(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane0, int cw0, int lane) {
         const WlDtInv1Args<T>& f = a.f;
-        const int sub = PP == 2 ? cw0 / 2 : 0;
-        const int cw = PP == 2 ? cw0 % 2 : cw0;
+        const int sub = PP > 1 ? cw0 / (CW / PP) : 0;
+        const int cw = PP > 1 ? cw0 % (CW / PP) : cw0;
         const int64_t plane = plane0 + sub;
         const int q = s.q0 + 64 * cw + lane;
         const bool active = q < s.q1 && plane < f.NC;
@@ -581,7 +582,7 @@ struct WlDtInv1Strip {
             __builtin_amdgcn_s_setprio(2);
 #endif
             stager(a, s, ctx, plane, lane, wave - CW);
-        } else if (64 * (PP == 2 ? wave % 2 : wave) < s.q1 - s.q0) {
+        } else if (64 * (PP > 1 ? wave % (CW / PP) : wave) < s.q1 - s.q0) {
             compute(a, s, ctx, plane, wave, lane);
         } else {
             for (int hb = 0; hb < s.nhb; ++hb) ctx.sync();
