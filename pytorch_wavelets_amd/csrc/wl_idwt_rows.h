@@ -74,6 +74,10 @@ struct WlIRowsArgs {
     //                     role_level == -1: loader, role_arg = level * 16 + first_source * 4 + nsources;  -2: spare
     signed char role_level[WL_IROWS_WAVES];
     short role_arg[WL_IROWS_WAVES];
+    // narrow planes: a workgroup owns pp consecutive planes, every one with its own compute and loader waves and its own
+    // lds_plane bytes of rings (role_sub = which of them a wave serves); the schedule is the same for all of them
+    signed char role_sub[WL_IROWS_WAVES];
+    int pp, lds_plane;
     WlIRowsLevel g[WL_IROWS_MAXLEV];
     WlIRowsSeg seg[3];             // 0: whole plane, 1: top half, 2: bottom half
 };
@@ -116,7 +120,7 @@ struct WlSfbRows {
     // off a 16-byte boundary).  A step may go out once the rows it overwrites (the previous revolution's rows under the
     // same ring bytes) were consumed at least one half-batch ago; before a half-batch the wave waits until the steps
     // under the rows about to be consumed have landed.
-    static WL_DEV void loader(const Args& a, const WlIRowsSeg& sg, const WlCtx& ctx, int64_t plane, int lane, int j, int s0, int ns) {
+    static WL_DEV void loader(const Args& a, const WlIRowsSeg& sg, const WlCtx& ctx, int64_t plane, int lane, int j, int s0, int ns, int soff) {
         const WlIRowsLevel& g = a.g[j];
         const int rb = g.rbytes, R = g.dma_rows, cpr = g.cpr;
         const int plane_bytes = g.Kh * rb, ring_bytes = R * rb;
@@ -131,7 +135,7 @@ struct WlSfbRows {
             const int s = s0 + (i < ns ? i : 0);
             src[i] = s == 0 ? reinterpret_cast<const char*>(a.yl + (size_t)plane * a.ll_ps)
                             : reinterpret_cast<const char*>(a.yh[j] + ((size_t)plane * 3 + (s - 1)) * ((size_t)g.Kh * g.Kw));
-            dst[i] = g.src_off[s];
+            dst[i] = g.src_off[s] + soff;
         }
         // steps (counted from the segment's first) under rows [.., k]
         auto need = [&](int k) { return ((k >> g.dma_shift) - r0) * cpr + (((k & (R - 1)) + 1) * rb - 1) / WL_IROWS_CHUNK + 1; };
@@ -293,9 +297,9 @@ struct WlSfbRows {
     }
 
     template <int j>
-    static WL_DEV void compute(const Args& a, const WlIRowsSeg& sg, const WlCtx& ctx, int64_t plane, int c0, int lane) {
+    static WL_DEV void compute(const Args& a, const WlIRowsSeg& sg, const WlCtx& ctx, int64_t plane, int c0, int lane, int soff) {
         const WlIRowsLevel& g = a.g[j];
-        char* const smem = ctx.smem;
+        char* const smem = ctx.smem + soff;
         const int c = c0 + lane;                         // column pair: output columns 2c, 2c+1
         const bool active = 2 * c < g.OW;
         Wave R;
@@ -368,18 +372,20 @@ struct WlSfbRows {
         const int tid = ctx.tid;
         const int wave = wl_uniform(tid >> 6), lane = tid & 63;
         const int64_t bid = ctx.bid;
-        const int64_t plane = bid < a.nwhole ? bid : a.nwhole + (bid - a.nwhole) / 2;
+        const int sub = wl_uniform(a.role_sub[wave]);
+        const int64_t plane = (bid < a.nwhole ? bid : a.nwhole + (bid - a.nwhole) / 2) * a.pp + sub;
         const WlIRowsSeg& sg = a.seg[bid < a.nwhole ? 0 : 1 + (int)((bid - a.nwhole) & 1)];
-        const int lev = wl_uniform(a.role_level[wave]), arg = wl_uniform(a.role_arg[wave]);
+        const int soff = sub * a.lds_plane;
+        const int lev = plane < a.NC ? wl_uniform(a.role_level[wave]) : -2, arg = wl_uniform(a.role_arg[wave]);   // (the last workgroup may hold fewer planes)
         if (lev == -1) {
 #if defined(__HIPCC__)
             __builtin_amdgcn_s_setprio(3);   // its few instructions go first: every other wave waits for it at the barrier
 #endif
-            loader(a, sg, ctx, plane, lane, arg >> 4, (arg >> 2) & 3, (arg & 3) + 1);
+            loader(a, sg, ctx, plane, lane, arg >> 4, (arg >> 2) & 3, (arg & 3) + 1, soff);
         }
-        else if (lev == 0) compute<0>(a, sg, ctx, plane, arg, lane);
-        else if (lev == 1) compute<1>(a, sg, ctx, plane, arg, lane);
-        else if (lev == 2) compute<2>(a, sg, ctx, plane, arg, lane);
+        else if (lev == 0) compute<0>(a, sg, ctx, plane, arg, lane, soff);
+        else if (lev == 1) compute<1>(a, sg, ctx, plane, arg, lane, soff);
+        else if (lev == 2) compute<2>(a, sg, ctx, plane, arg, lane, soff);
         else
             for (int hb = 0; hb < sg.nhb; ++hb) if (!(WL_IROWS_ABLATE & 64) || !(hb & 1)) ctx.sync();   // spare wave: keeps the barrier count
     }

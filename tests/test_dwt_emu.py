@@ -329,6 +329,34 @@ def test_streaming_synthesis_fp32_goldens_on_emulator(name, strips):
     assert G.relerr(res.numpy(), g, 'rec') < 1e-5
 
 
+@pytest.mark.parametrize('seed', range(8))
+def test_streaming_synthesis_several_planes_per_workgroup(seed):
+    """Narrow planes: a workgroup of the streaming synthesis kernel owns several consecutive planes, each with its own compute
+    waves, loaders (one loader for all four sources of a single level) and rings; the last workgroup partly filled.  Random
+    sizes, 1-3 levels, float32 and float16, against the oracle."""
+    from oracle import wavelet_oracle as wo
+    from pytorch_wavelets_amd import filters
+    rng = np.random.RandomState(4100 + seed)
+    wave = ['haar', 'db2', 'db3', 'db4'][seed % 4]
+    h0, h1 = filters.dwt_analysis_taps(wave)
+    g0, g1 = filters.dwt_synthesis_taps(wave)
+    L = len(h0)
+    for mode in ('zero', 'symmetric', 'periodic'):
+        J = int(rng.randint(1, 4))
+        H = int(rng.randint(8 * L, 100))
+        W = int(rng.randint(8 * L, [120, 250, 130, 100][seed % 4]))
+        planes = int(rng.randint(9, 30))
+        x = rng.randn(1, planes, H, W)
+        oyl, oyh = wo.dwt_forward(x, J, h0, h1, h0, h1, mode)
+        want = wo.dwt_inverse(oyl, oyh, g0, g1, g0, g1, mode)
+        half = seed >= 4 and all(v.shape[-1] % 2 == 0 for v in oyh) and oyl.shape[-1] % 2 == 0
+        dt = torch.float16 if half else torch.float32
+        res = _fused_inv(torch.tensor(oyl).to(dt), [torch.tensor(v).to(dt) for v in oyh], wave, mode, 0)
+        assert res is not None, (wave, mode, H, W, J, planes)
+        assert res.shape == want.shape
+        assert np.abs(res.float().numpy() - want).max() <= (4e-3 if half else 1e-5) * np.abs(want).max(), (wave, mode, H, W, J, planes)
+
+
 @pytest.mark.parametrize('seed', range(6))
 def test_streaming_synthesis_vs_oracle_random_shapes(seed):
     """Random (odd too) heights and widths, every supported tap count, fp32 and fp16, whole planes and cut planes."""
