@@ -127,6 +127,10 @@ struct WlRowsArgs {
     // and w+4 share a SIMD, so the launcher deals the roles out for equal instruction load per SIMD.
     signed char role_level[WL_ROWS_WAVES];
     short role_col0[WL_ROWS_WAVES];
+    // narrow planes: a workgroup owns pp consecutive planes, every one with its own compute waves, loaders and lds_plane bytes
+    // of rings (role_sub = which of them a wave serves); the schedule is the same for all of them (see wl_idwt_rows.h)
+    signed char role_sub[WL_ROWS_WAVES];
+    int pp, lds_plane;
     WlRowsLevel g[WL_ROWS_MAXLEV];
     WlRowsSeg seg[3];   // 0: whole plane, 1: top half, 2: bottom half
 };
@@ -468,7 +472,8 @@ struct WlAfbRows {
         const int wave = wl_uniform(tid >> 6), lane = tid & 63;
         // workgroup -> (plane, segment)
         const int64_t bid = ctx.bid;
-        const int64_t plane = bid < a.nwhole ? bid : a.nwhole + (bid - a.nwhole) / 2;
+        const int sub = wl_uniform(a.role_sub[wave]);
+        const int64_t plane = (bid < a.nwhole ? bid : a.nwhole + (bid - a.nwhole) / 2) * a.pp + sub;
         const WlRowsSeg& sg = a.seg[bid < a.nwhole ? 0 : 1 + (int)((bid - a.nwhole) & 1)];
         // all of LDS starts as zeros: the zero row, and halo cells that stay zero in zero-padding mode
         for (int i = tid * 16; i < a.lds_bytes; i += kThreads * 16) {
@@ -476,11 +481,13 @@ struct WlAfbRows {
             *reinterpret_cast<wl_f4*>(ctx.smem + i) = z;
         }
         ctx.sync();
-        const int lev = wl_uniform(a.role_level[wave]), col0 = wl_uniform(a.role_col0[wave]);
-        if (lev == -1) loader(a, sg, ctx, plane, lane, col0);
-        else if (lev == 0) compute<0>(a, sg, ctx, plane, col0, lane);
-        else if (lev == 1) compute<1>(a, sg, ctx, plane, col0, lane);
-        else if (lev == 2) compute<2>(a, sg, ctx, plane, col0, lane);
+        WlCtx cs = ctx;                                  // this wave's plane: its own part of the LDS
+        cs.smem += sub * a.lds_plane; cs.lds_base += (unsigned)(sub * a.lds_plane);
+        const int lev = plane < a.NC ? wl_uniform(a.role_level[wave]) : -2, col0 = wl_uniform(a.role_col0[wave]);   // (the last workgroup may hold fewer planes)
+        if (lev == -1) loader(a, sg, cs, plane, lane, col0);
+        else if (lev == 0) compute<0>(a, sg, cs, plane, col0, lane);
+        else if (lev == 1) compute<1>(a, sg, cs, plane, col0, lane);
+        else if (lev == 2) compute<2>(a, sg, cs, plane, col0, lane);
         else
             for (int hb = 0; hb < sg.nhb; ++hb) ctx.sync();   // spare wave: keeps the barrier count
     }

@@ -330,6 +330,33 @@ def test_streaming_synthesis_fp32_goldens_on_emulator(name, strips):
 
 
 @pytest.mark.parametrize('seed', range(8))
+def test_streaming_analysis_several_planes_per_workgroup(seed):
+    """Narrow planes: a workgroup of the streaming analysis kernel owns several consecutive planes, each with its own compute
+    waves, loaders and rings (the last workgroup partly filled).  Random sizes (widths a multiple of 4 / 8 elements: 16-byte
+    rows), 1-3 levels, float32 and float16, against the oracle."""
+    from oracle import wavelet_oracle as wo
+    from pytorch_wavelets_amd import filters
+    rng = np.random.RandomState(4300 + seed)
+    wave = ['haar', 'db2', 'db3', 'db4'][seed % 4]
+    h0, h1 = filters.dwt_analysis_taps(wave)
+    L = len(h0)
+    half = seed >= 4
+    for mode in ('zero', 'symmetric', 'reflect'):
+        J = int(rng.randint(1, 4))
+        H = int(rng.randint(8 * L, 100))
+        W = 8 * int(rng.randint(L + 1, [15, 31, 16, 12][seed % 4]))
+        planes = int(rng.randint(9, 30))
+        x = rng.randn(1, planes, H, W)
+        oyl, oyh = wo.dwt_forward(x, J, h0, h1, h0, h1, mode)
+        res = _fused(torch.tensor(x).to(torch.float16 if half else torch.float32), wave, mode, J, 0)
+        assert res is not None, (wave, mode, H, W, J, planes)
+        tol = 4e-3 if half else 1e-5
+        for got, want in zip([res[0]] + list(res[1]), [oyl] + list(oyh)):
+            assert got.shape == want.shape
+            assert np.abs(got.float().numpy() - want).max() <= tol * np.abs(want).max(), (wave, mode, H, W, J, planes)
+
+
+@pytest.mark.parametrize('seed', range(8))
 def test_streaming_synthesis_several_planes_per_workgroup(seed):
     """Narrow planes: a workgroup of the streaming synthesis kernel owns several consecutive planes, each with its own compute
     waves, loaders (one loader for all four sources of a single level) and rings; the last workgroup partly filled.  Random
