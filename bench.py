@@ -669,6 +669,21 @@ def other_configs(pw, dev, sync):
         other['dwt_j2_db2_512x16x32x32_fp32'] = {'fwd_ms': round(tfm, 4), 'inv_ms': round(tim, 4), 'fwd_frac': frac(bm, tfm), 'inv_frac': frac(bm, tim),
                                                  'fwd_kernels': names(lambda: fm(xm)), 'inv_kernels': names(lambda: im(cm))}
         del xm, cm
+        # wavelet pooling on ImageNet-style feature maps: several narrow planes per workgroup of the streaming kernels
+        xm = torch.randn(64, 64, 112, 112, device=dev)
+        fm, im = pw.DWTForward(J=1, wave='haar', mode='zero').to(dev), pw.DWTInverse(wave='haar', mode='zero').to(dev)
+        cm = fm(xm)
+        tfm, tim = time_seq_fn(lambda: fm(xm), 30, sync), time_seq_fn(lambda: im(cm), 30, sync)
+        bm = algorithmic_bytes_fwd(64, 64, 112, 112, 1, 2, 4)
+        other['dwt_j1_haar_64x64x112x112_fp32'] = {'fwd_ms': round(tfm, 4), 'inv_ms': round(tim, 4), 'fwd_frac': frac(bm, tfm), 'inv_frac': frac(bm, tim),
+                                                   'fwd_kernels': names(lambda: fm(xm)), 'inv_kernels': names(lambda: im(cm))}
+        del xm, cm
+        xm = torch.randn(1024, 3, 128, 128, device=dev)
+        slm = pw.ScatLayer().to(dev)
+        tsm = time_seq_fn(lambda: slm(xm), 30, sync)
+        other['scatlayer_1024x3x128x128_fp32'] = {'fwd_ms': round(tsm, 4), 'frac_of_hbm_peak_at_11B_per_px': frac(11 * xm.numel(), tsm),
+                                                  'fwd_kernels': names(lambda: slm(xm))}
+        del xm
         # outside the fused streaming envelope of round 2: wider images, longer filters
         for tag, shape, wave, L in (('dwt_j3_db4_16x3x1024x1024_fp32', (16, 3, 1024, 1024), 'db4', 8),
                                     ('dwt_j3_db4_64x3x1024x1024_fp32', (64, 3, 1024, 1024), 'db4', 8),
