@@ -159,7 +159,10 @@ struct WlRowsSched {
     }
 };
 
-template <typename T, int LT, int PPR, int D = WL_ROWS_DEPTH>
+// SAME = 1: the row and the column banks are the same taps (the launcher saw the same device buffers for both axes - what a
+// transform built from ONE wavelet passes): one set of tap pairs in the scalar file instead of two.  (At 12 taps two sets are
+// 96 scalar registers: the kernel spilled them, 31-35 SGPRs and 16-28 bytes of scratch per lane.)
+template <typename T, int LT, int PPR, int D = WL_ROWS_DEPTH, int SAME = 0>
 struct WlAfbRows {
     typedef WlRowsArgs<T> Args;
     static const int kThreads = 64 * WL_ROWS_WAVES;
@@ -250,7 +253,8 @@ struct WlAfbRows {
         int ndst, hx0, hx1;     // next level's ring row: its LL sample and the halo cells it is the source of
     };
     struct Role {               // per wave (wave-uniform)
-        wl_v2 tw[LT], th[LT];   // (lo,hi) tap pairs along W / along H
+        wl_v2 tw[LT], th[SAME ? 1 : LT];   // (lo,hi) tap pairs along W / along H
+        WL_DEV wl_v2 colt(int t) const { return SAME ? tw[t] : th[SAME ? 0 : t]; }   // column-filter tap pair t
         char* hp0; char* hp1; char* hp2; char* llp;   // band planes of this (plane, level); LL plane of the last level
         unsigned rowb, llrowb, kb;
         int nring, npitch, rmask;
@@ -297,14 +301,14 @@ struct WlAfbRows {
     // (LL, W-lo/H-hi) and (W-hi/H-lo, HH), two chains each (even / odd taps)
     template <bool LAST, bool HALO>
     static WL_DEV void col_pass(Lane& L, const Role& R, char* smem, const wl_v2* w, int orow, bool keep) {
-        wl_v2 cl = wl_pk_mul_x(R.th[0], w[0]), ch = wl_pk_mul_y(R.th[0], w[0]);
-        wl_v2 cl2 = wl_pk_mul_x(R.th[1], w[1]), ch2 = wl_pk_mul_y(R.th[1], w[1]);
+        wl_v2 cl = wl_pk_mul_x(R.colt(0), w[0]), ch = wl_pk_mul_y(R.colt(0), w[0]);
+        wl_v2 cl2 = wl_pk_mul_x(R.colt(1), w[1]), ch2 = wl_pk_mul_y(R.colt(1), w[1]);
 #pragma unroll
         for (int t = 2; t < LT; t += 2) {
-            wl_pk_fma_x(cl, R.th[t], w[t]);
-            wl_pk_fma_y(ch, R.th[t], w[t]);
-            wl_pk_fma_x(cl2, R.th[t + 1], w[t + 1]);
-            wl_pk_fma_y(ch2, R.th[t + 1], w[t + 1]);
+            wl_pk_fma_x(cl, R.colt(t), w[t]);
+            wl_pk_fma_y(ch, R.colt(t), w[t]);
+            wl_pk_fma_x(cl2, R.colt(t + 1), w[t + 1]);
+            wl_pk_fma_y(ch2, R.colt(t + 1), w[t + 1]);
         }
         cl += cl2;
         ch += ch2;
@@ -369,7 +373,7 @@ struct WlAfbRows {
 #pragma unroll
         for (int t = 0; t < LT; ++t) {
             R.tw[t] = wl_uniform_v2(wl_v2{a.h_w_lo[t], a.h_w_hi[t]});
-            R.th[t] = wl_uniform_v2(wl_v2{a.h_h_lo[t], a.h_h_hi[t]});
+            if (!SAME) R.th[SAME ? 0 : t] = wl_uniform_v2(wl_v2{a.h_h_lo[t], a.h_h_hi[t]});
         }
         R.last = j == a.nlev - 1;
         const unsigned bplane = (unsigned)g.Kh * (unsigned)g.Kw;

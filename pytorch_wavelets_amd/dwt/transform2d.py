@@ -27,6 +27,11 @@ def _qmf_banks(g0_col, g1_col, g0_row, g1_row):
     return ops.is_qmf_pair(g0_col, g1_col) and ops.is_qmf_pair(g0_row, g1_row)
 
 
+def _same_banks(h0_col, h1_col, h0_row, h1_row):
+    """Are the column bank and the row bank the same taps?  (module-level: DWTForward stays picklable)"""
+    return ops.banks_equal(h0_col, h1_col, h0_row, h1_row)
+
+
 class DWTForward(nn.Module):
     """2-D multi-level DWT.  ``DWTForward(J=1, wave='db1', mode='zero')(x) -> (yl, yh)`` with
     ``yh[j]`` of shape (N, C, 3, H_j, W_j), finest scale first (reference transform2d.py:7-74)."""
@@ -44,6 +49,9 @@ class DWTForward(nn.Module):
         # kernel-variant hint, re-validated against the buffers on every call (see DWTInverse): the stored decomposition pair of
         # an orthogonal wavelet is a quadrature-mirror pair too, h1[t] = (-1)**t h0[L-1-t]
         self._qmf = ops.TapVerdict(_qmf_banks)
+        # and: are the row and the column banks the same taps (one wavelet for both axes)?  The streaming kernel then keeps
+        # one set of tap pairs in its scalar registers (ops.same_banks_hint)
+        self._same = ops.TapVerdict(_same_banks)
 
     def forward(self, x):
         mode = lowlevel.mode_to_int(self.mode)
@@ -51,7 +59,8 @@ class DWTForward(nn.Module):
             return x, []
         # NB argument order: the module's *col* pair lands in the row slots (quirk Q1, reference
         # transform2d.py:70-71).  All J levels are one autograd node / (up to) one kernel launch.
-        with ops.qmf_hint(self._qmf(self.h0_col, self.h1_col, self.h0_row, self.h1_row)):
+        with ops.qmf_hint(self._qmf(self.h0_col, self.h1_col, self.h0_row, self.h1_row)), \
+                ops.same_banks_hint(self._same(self.h0_col, self.h1_col, self.h0_row, self.h1_row)):
             outs = lowlevel.AFB2DMulti.apply(x, self.h0_col, self.h1_col, self.h0_row, self.h1_row, mode, self.J)
         return outs[0], list(outs[1:])
 

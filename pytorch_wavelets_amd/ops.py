@@ -220,6 +220,27 @@ def qmf_hint(flag):
         _HINTS.qmf = prev
 
 
+def banks_equal(lo_a, hi_a, lo_b, hi_b):
+    """Are the two filter banks the same taps, element for element (whatever their shapes)?"""
+    f = lambda t: t.detach().reshape(-1).double().cpu()   # noqa: E731
+    return (lo_a.numel() == lo_b.numel() and hi_a.numel() == hi_b.numel() and lo_a.numel() > 0
+            and bool(torch.equal(f(lo_a), f(lo_b))) and bool(torch.equal(f(hi_a), f(hi_b))))
+
+
+@contextlib.contextmanager
+def same_banks_hint(flag):
+    """Inside this context the caller vouches that the row and the column banks handed to afb2d_fused are the same taps (a
+    transform built from one wavelet): the launcher is then given ONE pair of device buffers for both axes, which is how the
+    streaming analysis kernel recognises that it needs one set of tap pairs in its scalar registers instead of two
+    (wl_rows_api.inc: 10 and 12 taps no longer spill them).  DWTForward sets it from its buffers as they are at call time."""
+    prev = getattr(_HINTS, 'same', False)
+    _HINTS.same = bool(flag)
+    try:
+        yield
+    finally:
+        _HINTS.same = prev
+
+
 STREAM_FORCE = False   # tests: send every single-level analysis the strip kernel covers to it, whatever the shape
 FUSED_STRIPS = 0   # default `strips` of the two streaming entry points below: 0 = the engine's policy (the planes must fill
                    # the chip), 1 / 2 = force the streaming kernels whatever the batch (tests pin their backward passes so)
@@ -279,6 +300,8 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None):
     if key in _FUSED_DECLINED or x.data_ptr() % 16:
         return None
     hwl, hwh, hhl, hhh = (_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi))
+    if getattr(_HINTS, 'same', False):
+        hhl, hhh = hwl, hwh              # (the caller vouches they are the same taps: same_banks_hint)
     yh = []
     h, w = H, W
     for _ in range(nlev):

@@ -329,6 +329,35 @@ def test_streaming_synthesis_fp32_goldens_on_emulator(name, strips):
     assert G.relerr(res.numpy(), g, 'rec') < 1e-5
 
 
+@pytest.mark.parametrize('wave', ['db5', 'db6', 'sym5', 'coif2'])
+def test_same_banks_variant_of_the_streaming_analysis(wave):
+    """A transform built from ONE wavelet hands the launcher one pair of tap buffers for both axes (ops.same_banks_hint, verified
+    against the buffers at every call): the 10- and 12-tap streaming analysis kernels then keep one set of tap pairs in scalar
+    registers (WlAfbRows<.., SAME = 1>).  Against the oracle; and a row bank edited in place afterwards takes the hint away."""
+    from oracle import wavelet_oracle as wo
+    from pytorch_wavelets_amd import filters
+    torch.manual_seed(0)
+    x = torch.randn(2, 3, 96, 128, dtype=torch.float32)
+    h0, h1 = filters.dwt_analysis_taps(wave)
+    with emu_backend.emulated():
+        m = pw.DWTForward(J=3, wave=wave, mode='symmetric').float()
+        c0 = pw.launch_count()
+        yl, yh = m(x)
+        ks = pw.kernels_since(c0)
+        m.h0_row.mul_(2.0)
+        c0 = pw.launch_count()
+        yl2, yh2 = m(x)
+        ks2 = pw.kernels_since(c0)
+    assert len(ks) == 1 and ks[0].endswith(', 3, 1>'), ks
+    assert len(ks2) == 1 and 'WlAfbRows' in ks2[0] and not ks2[0].endswith(', 3, 1>'), ks2
+    oyl, oyh = wo.dwt_forward(x.double().numpy(), 3, h0, h1, h0, h1, 'symmetric')
+    for got, want in zip([yl] + list(yh), [oyl] + list(oyh)):
+        assert np.abs(got.numpy() - want).max() <= 1e-5 * np.abs(want).max()
+    oyl2, oyh2 = wo.dwt_forward(x.double().numpy(), 3, h0, h1, [2.0 * v for v in h0], h1, 'symmetric')
+    for got, want in zip([yl2] + list(yh2), [oyl2] + list(oyh2)):
+        assert np.abs(got.numpy() - want).max() <= 1e-5 * np.abs(want).max()
+
+
 @pytest.mark.parametrize('seed', range(8))
 def test_streaming_analysis_several_planes_per_workgroup(seed):
     """Narrow planes: a workgroup of the streaming analysis kernel owns several consecutive planes, each with its own compute
