@@ -285,3 +285,52 @@ def check_dwt_forward_mutations(dev, wave='db8', mode='symmetric', shape=(2, 2, 
         run(copy.deepcopy(fresh()), True, 'deepcopy')
     finally:
         ops.STREAM_FORCE, _ll.FUSED_LEVELS = prev
+
+
+def check_dwt_forward_same_banks_mutations(dev, wave='db6', mode='symmetric', shape=(2, 2, 64, 288), dtype=torch.float32, tol=1e-5):
+    """DWTForward on the (forced) fused streaming analysis kernel: one wavelet for both axes -> the one-bank variant
+    (WlAfbRows<.., SAME = 1>), equal to the oracle; a row or column bank changed by any route -> the two-bank variant, equal to
+    the oracle on the mutated taps."""
+    from pytorch_wavelets_amd import ops
+    rng = np.random.RandomState(23)
+    prev = ops.FUSED_STRIPS
+    ops.FUSED_STRIPS = 1
+    try:
+        x = torch.tensor(rng.randn(*shape), dtype=dtype, device=dev)
+
+        def fresh():
+            return pw.DWTForward(J=2, wave=wave, mode=mode).to(dev).to(dtype)
+
+        def run(xfm, want_same, what):
+            yl, yh = xfm(x)
+            k = pw.last_kernel()
+            assert 'WlAfbRows' in k, (what, k)
+            assert k.endswith(', 3, 1>') == want_same, (what, k)
+            oyl, oyh = wo.dwt_forward(x.detach().cpu().double().numpy(), 2, _flat(xfm.h0_col), _flat(xfm.h1_col),
+                                      _flat(xfm.h0_row), _flat(xfm.h1_row), mode)
+            assert _rel(yl, oyl) <= tol, (what, 'yl', _rel(yl, oyl))
+            for a, b in zip(yh, oyh):
+                assert _rel(a, b) <= tol, (what, 'yh', _rel(a, b))
+
+        xfm = fresh()
+        run(xfm, True, 'pristine')
+        xfm.h1_col.mul_(0.5)
+        run(xfm, False, 'h1_col.mul_')
+        xfm.h1_row.mul_(0.5)
+        run(xfm, True, 'both banks scaled alike')
+        xfm.h0_row[0, 0, 0, 0] += 0.25
+        run(xfm, False, 'h0_row[...] +=')
+        xfm = fresh()
+        sd = {k: v.clone() for k, v in xfm.state_dict().items()}
+        sd['h0_col'] = torch.tensor(rng.randn(*sd['h0_col'].shape), dtype=dtype, device=dev)
+        xfm.load_state_dict(sd)
+        run(xfm, False, 'load_state_dict')
+        xfm = fresh()
+        xfm.h1_row = (xfm.h1_row * 2).clone()
+        run(xfm, False, 'h1_row = ...')
+        h0 = F.dwt_analysis_taps(wave)[0]
+        xfm2 = pw.DWTForward(J=2, wave=tuple(rng.randn(len(h0)) for _ in range(4)), mode=mode).to(dev).to(dtype)
+        run(xfm2, False, 'custom banks')
+        run(copy.deepcopy(fresh()), True, 'deepcopy')
+    finally:
+        ops.FUSED_STRIPS = prev

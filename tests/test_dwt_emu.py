@@ -828,6 +828,21 @@ def test_filter_buffers_changed_after_construction_dwt_inverse_dtypes():
         torch.set_default_dtype(prev)
 
 
+
+@pytest.mark.parametrize('wave,mode', [('db6', 'symmetric'), ('db5', 'zero')])
+def test_filter_buffers_changed_after_construction_same_banks_hint(wave, mode):
+    """The one-bank variant of the fused streaming analysis kernel (10 / 12 taps, both axes the same wavelet) against the
+    oracle, and the hint following the buffers as they are at call time."""
+    import _mutation_cases as M
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float32)
+    try:
+        with emu_backend.emulated():
+            M.check_dwt_forward_same_banks_mutations('cpu', wave=wave, mode=mode, shape=(1, 2, 64, 288), tol=3e-6)
+    finally:
+        torch.set_default_dtype(prev)
+
+
 @pytest.mark.parametrize('wave,mode', [('db8', 'symmetric'), ('db6', 'periodization'), ('db7', 'zero'), ('db10', 'reflect'), ('sym9', 'periodic')])
 def test_filter_buffers_changed_after_construction_dwt_forward(wave, mode):
     """The analysis strip kernel's quadrature-mirror variant (lowpass banks only, 12-20 taps) against the oracle, and the

@@ -770,3 +770,12 @@ def test_filter_buffers_changed_after_construction_dwt_forward_gpu(wave, mode, d
     buffers as they are at call time."""
     import _mutation_cases as M
     M.check_dwt_forward_mutations(DEV, wave=wave, mode=mode, shape=(2, 2, 64, 288), dtype=dtype, tol=tol)
+
+
+@pytest.mark.parametrize('wave,mode,dtype,tol', [('db6', 'symmetric', torch.float32, 1e-5), ('db5', 'reflect', torch.float32, 1e-5),
+                                                 ('coif2', 'zero', torch.float16, 4e-3)])
+def test_filter_buffers_changed_after_construction_same_banks_hint_gpu(wave, mode, dtype, tol):
+    """The one-bank variant of the fused streaming analysis kernel (WlAfbRows<.., SAME = 1>) against the ORACLE, and the hint
+    following the buffers as they are at call time."""
+    import _mutation_cases as M
+    M.check_dwt_forward_same_banks_mutations(DEV, wave=wave, mode=mode, shape=(2, 2, 64, 288), dtype=dtype, tol=tol)
