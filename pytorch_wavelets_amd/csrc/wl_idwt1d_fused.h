@@ -42,10 +42,15 @@ struct WlIdwt1dFused {
     static const int kMinWaves = 2;
     static const int HL = LT / 2;
     // n floats of src[base ..] -> dst, zeros from position `len` on (src may be null = zeros)
+    // (n is even and dst 8-byte aligned: two samples per lane and load - element-aligned 8-byte loads - while both exist)
+    typedef T Pair2 __attribute__((ext_vector_type(2), aligned(sizeof(T)), may_alias));
     static WL_DEV void load_range(float* dst, const T* src, int base, int n, int len, int tid) {
-        for (int i = tid; i < n; i += kThreads) {
+        for (int i = 2 * tid; i < n; i += 2 * kThreads) {
             const int k = base + i;
-            dst[i] = (src && k < len) ? (float)src[k] : 0.f;
+            wl_f2 v; v.x = v.y = 0.f;
+            if (src && k + 1 < len) { const Pair2 t = *reinterpret_cast<const Pair2*>(src + k); v.x = (float)t.x; v.y = (float)t.y; }
+            else if (src && k < len) v.x = (float)src[k];
+            *reinterpret_cast<wl_f2*>(dst + i) = v;
         }
     }
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
@@ -91,12 +96,12 @@ struct WlIdwt1dFused {
                 const float v0 = acc0.x + acc1.x, v1 = acc0.y + acc1.y;
                 const int p = obase + 2 * q;
                 if (nxt) {
-                    nxt[2 * q] = p < lim ? v0 : 0.f;
-                    nxt[2 * q + 1] = p + 1 < lim ? v1 : 0.f;
-                } else {
-                    if (p < lim) yp[p] = (T)v0;
-                    if (p + 1 < lim) yp[p + 1] = (T)v1;
-                }
+                    wl_f2 t; t.x = p < lim ? v0 : 0.f; t.y = p + 1 < lim ? v1 : 0.f;
+                    *reinterpret_cast<wl_f2*>(nxt + 2 * q) = t;
+                } else if (p + 1 < lim) {                        // (one element-aligned 8-byte store per lane)
+                    Pair2 t; t.x = (T)v0; t.y = (T)v1;
+                    *reinterpret_cast<Pair2*>(yp + p) = t;
+                } else if (p < lim) yp[p] = (T)v0;
             }
             ctx.sync();
         }
