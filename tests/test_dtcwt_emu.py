@@ -409,9 +409,10 @@ def test_streaming_level2_inverse_equals_tile_kernel(shape, qshift, dtype):
         assert float((u.float() - v.float()).abs().max()) <= tol * float(v.float().abs().max())
 
 
+@pytest.mark.parametrize('qshift,taps', [('qshift_a', 10), ('qshift_b', 14)])
 @pytest.mark.parametrize('shape,dtype', [((2, 1, 64, 256), torch.float32), ((1, 2, 72, 1024), torch.float32), ((2, 1, 32, 520), torch.float32),
                                          ((2, 2, 64, 512), torch.float16)])
-def test_streaming_level2_forward_equals_tile_kernel(shape, dtype):
+def test_streaming_level2_forward_equals_tile_kernel(shape, dtype, qshift, taps):
     """fwd_j2plus alone on the stagers and level-2 lanes of the fused kernel (wl_dtcwt_fused.h MODE 4: the stagers put the
     input rows and their mirrored cells straight into the ring the level-2 lanes read) against the tile kernel."""
     from pytorch_wavelets_amd import ops
@@ -420,13 +421,13 @@ def test_streaming_level2_forward_equals_tile_kernel(shape, dtype):
     h = emu_backend.handle()
     out = {}
     with emu_backend.emulated():
-        xfm = pw.DTCWTForward(J=2).to(dtype)
+        xfm = pw.DTCWTForward(J=2, qshift=qshift).to(dtype)
         try:
             for ns in (0, 1):
                 h.wl_set_option(b'no_stream', ns)
                 out[ns] = ops.dtcwt_fwd2(x, xfm.h0a, xfm.h0b, xfm.h1a, xfm.h1b)
                 if ns == 0:
-                    assert 'WlDtFwd12Strip' in pw.last_kernel() and ', 10, 4' in pw.last_kernel(), pw.last_kernel()
+                    assert 'WlDtFwd12Strip' in pw.last_kernel() and ', %d, 4' % taps in pw.last_kernel(), pw.last_kernel()
         finally:
             h.wl_set_option(b'no_stream', 0)
     tol = 5e-3 if dtype == torch.float16 else 3e-6
