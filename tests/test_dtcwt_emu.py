@@ -308,7 +308,7 @@ def test_lean_scatlayerj2_lowpass():
 
 
 @pytest.mark.parametrize('shape,dtype', [((2, 2, 64, 256), torch.float16), ((3, 2, 64, 128), torch.float16), ((3, 3, 40, 96), torch.float32), ((4, 2, 48, 64), torch.float32),
-                                         ((1, 5, 72, 112), torch.float32)])
+                                         ((1, 5, 72, 112), torch.float32), ((2, 3, 40, 160), torch.float32), ((3, 1, 64, 224), torch.float16)])
 def test_narrow_and_half_precision_planes_on_the_streaming_kernels(shape, dtype):
     """Four planes of 96-128 columns per workgroup (the last workgroup partly filled), float16 planes of 256 columns: DTCWT J = 2
     forward / inverse and the ScatLayer training step, streaming kernels against tile kernels."""

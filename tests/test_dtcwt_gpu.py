@@ -487,7 +487,7 @@ def test_scatlayerj2_in_place_equals_the_chain(shape, dtype, expect):
 
 
 @pytest.mark.parametrize('shape,dtype', [((64, 3, 256, 256), torch.float16), ((96, 3, 128, 128), torch.float16), ((96, 3, 128, 128), torch.float32),
-                                         ((40, 5, 96, 112), torch.float32), ((33, 3, 512, 256), torch.float16), ((128, 3, 72, 80), torch.float32)])
+                                         ((40, 5, 96, 112), torch.float32), ((33, 3, 512, 256), torch.float16), ((128, 3, 72, 80), torch.float32), ((64, 3, 224, 224), torch.float32), ((64, 3, 160, 200), torch.float16)])
 def test_streaming_kernels_on_narrow_and_half_precision_planes_equal_the_tile_kernels(shape, dtype):
     """Planes of 96-128 columns go four to a workgroup (PP = 4), float16 planes of 256 columns and more to the streaming kernels
     like float32 ones (the rule is in columns, not bytes): DTCWT J = 2 forward / inverse and the ScatLayer training step against

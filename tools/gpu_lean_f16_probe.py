@@ -6,7 +6,7 @@ import bench, pytorch_wavelets_amd as pw
 from pytorch_wavelets_amd import ops
 dev = 'cuda:0'; sync = torch.cuda.synchronize
 for dtype in (torch.float32, torch.float16):
-    for shape in ((256, 3, 256, 256), (64, 3, 512, 512), (256, 3, 128, 128)):
+    for shape in ((256, 3, 224, 224), (256, 3, 160, 160), (256, 3, 192, 200), (256, 3, 128, 128)):
         x = torch.randn(*shape, device=dev).to(dtype)
         mods = {'scat': pw.ScatLayer().to(dev).to(dtype), 'dtcwt1': pw.DTCWTForward(J=1).to(dev).to(dtype), 'dtcwt2': pw.DTCWTForward(J=2).to(dev).to(dtype)}
         line = []
