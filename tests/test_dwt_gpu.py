@@ -779,3 +779,44 @@ def test_filter_buffers_changed_after_construction_same_banks_hint_gpu(wave, mod
     following the buffers as they are at call time."""
     import _mutation_cases as M
     M.check_dwt_forward_same_banks_mutations(DEV, wave=wave, mode=mode, shape=(2, 2, 64, 288), dtype=dtype, tol=tol)
+
+
+@pytest.mark.parametrize('shape,wave,mode,J,dtype', [((64, 32, 96, 112), 'haar', 'zero', 1, torch.float32), ((32, 33, 80, 224), 'db2', 'symmetric', 1, torch.float32),
+                                                     ((50, 21, 64, 128), 'db4', 'reflect', 2, torch.float32), ((40, 30, 72, 96), 'db3', 'periodic', 1, torch.float32),
+                                                     ((64, 16, 128, 120), 'db2', 'symmetric', 3, torch.float32), ((64, 32, 96, 112), 'haar', 'zero', 1, torch.float16)])
+def test_streaming_kernels_several_planes_per_workgroup_gpu(shape, wave, mode, J, dtype):
+    """Narrow planes, many of them: the streaming analysis / synthesis kernels with several planes per workgroup (strips = 0: the
+    engine's choice; the plane count is no multiple of the planes per workgroup in some cases) against the same kernels with
+    every plane cut in two, one half per workgroup (strips = 2: never more than one plane per workgroup), and the oracle on a
+    slice of the batch."""
+    from pytorch_wavelets_amd import ops
+    from pytorch_wavelets_amd.dwt import lowlevel
+    torch.manual_seed(0)
+    x = torch.randn(*shape, device=DEV).to(dtype)
+    h0, h1 = F.dwt_analysis_taps(wave)
+    g0, g1 = F.dwt_synthesis_taps(wave)
+    th = [torch.tensor(v, dtype=torch.float32, device=DEV) for v in (h0, h1, h0, h1)]
+    tg = [torch.tensor(v, dtype=torch.float32, device=DEV) for v in (g0, g1, g0, g1)]
+    m = lowlevel.mode_to_int(mode)
+    a0 = ops.afb2d_fused(x, *th, m, J, strips=0)
+    a2 = ops.afb2d_fused(x, *th, m, J, strips=2)
+    assert a0 is not None and 'WlAfbRows' in pw.last_kernel()
+    tol = 2e-3 if dtype == torch.float16 else 1e-6
+    if a2 is not None:                   # (a plane that cannot be cut in two declines strips = 2: the oracle below remains)
+        for u, v in zip([a0[0]] + list(a0[1]), [a2[0]] + list(a2[1])):
+            assert u.shape == v.shape and float((u.float() - v.float()).abs().max()) <= tol * float(v.float().abs().max())
+    s0 = ops.sfb2d_fused(a0[0], a0[1], *tg, m, strips=0)
+    assert s0 is not None and 'WlSfbRows' in pw.last_kernel()
+    s2 = ops.sfb2d_fused(a0[0], a0[1], *tg, m, strips=2)
+    if s2 is not None:
+        assert s0.shape == s2.shape and float((s0.float() - s2.float()).abs().max()) <= tol * float(s2.float().abs().max())
+    # the last planes of the batch (a partly filled workgroup) against the oracle
+    xs = x[-1, -3:].double().cpu().numpy()[None]
+    oyl, oyh = wo.dwt_forward(xs, J, h0, h1, h0, h1, mode)
+    otol = 4e-3 if dtype == torch.float16 else 1e-5
+    assert float(np.abs(a0[0][-1:, -3:].double().cpu().numpy() - oyl).max()) <= otol * float(np.abs(oyl).max())
+    for j in range(J):
+        assert float(np.abs(a0[1][j][-1:, -3:].double().cpu().numpy() - oyh[j]).max()) <= otol * float(np.abs(oyh[j]).max())
+    orec = wo.dwt_inverse(oyl, oyh, g0, g1, g0, g1, mode)
+    got = s0[-1:, -3:].double().cpu().numpy()
+    assert got.shape == orec.shape and float(np.abs(got - orec).max()) <= (8e-3 if dtype == torch.float16 else 1e-5) * float(np.abs(orec).max())
