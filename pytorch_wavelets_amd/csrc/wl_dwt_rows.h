@@ -445,7 +445,11 @@ struct WlAfbRows {
             const unsigned long long c1 = WL_TICK();
             tb += c1 - c0;
             const int orow = fed - WARM;   // the output row the next feed completes (once the window is full)
-            if (n == 2 && fed - f0 >= WARM) {       // the steady state of level 1
+#ifndef WL_ROWS_FEED2_MAXL
+#define WL_ROWS_FEED2_MAXL 10    // the longest filter that takes the two-feed form: at 12 taps its four sample rows spilled 15 VGPRs
+                                 // (28 B of scratch) at the 80-register budget; one feed at a time: 62 registers, db6 0.221 -> 0.2145 ms
+#endif
+            if (LT <= WL_ROWS_FEED2_MAXL && n == 2 && fed - f0 >= WARM) {       // the steady state of level 1
                 int r0, r1, r2, r3;
                 rows_of(fed, hb, 0, r0, r1);
                 rows_of(fed + 1, hb, 1, r2, r3);
