@@ -26,3 +26,14 @@ static int wl_afb_base(int n, int L, int mode) {
     return -(p / 2);
 }
 
+// A launch of the variant HINT that relies on a relation between the filter banks, guarded on the device (wl_common.h), with
+// the plain variant PLAIN queued behind it as its armed fallback: exactly one of the two does the work.  The fallback's own
+// checks run first (dry), so that it cannot decline behind a hinted variant that is already on the stream.
+#define WL_GUARDED_PAIR(HINT, PLAIN, ...)                         \
+    do {                                                          \
+        int rc_ = PLAIN(__VA_ARGS__, 2, 1);                       \
+        if (rc_ != 0) return rc_;                                 \
+        rc_ = HINT(__VA_ARGS__, 1, 0);                            \
+        if (rc_ != 0) return rc_;                                 \
+        return PLAIN(__VA_ARGS__, 2, 2);                          \
+    } while (0)

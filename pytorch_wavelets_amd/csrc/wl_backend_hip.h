@@ -53,11 +53,11 @@ static int wl_num_cus() {
 }
 
 template <typename K>
-static int wl_launch(const typename K::Args& a, int64_t nblocks, size_t lds, void* stream) {
+static int wl_launch_named(const typename K::Args& a, int64_t nblocks, size_t lds, void* stream, const char* name, bool primary) {
     if (nblocks <= 0) return 0;
     if (nblocks > 2147483647LL || lds > 160 * 1024) return -2;
-    wl_last_kernel_ptr.store(__PRETTY_FUNCTION__, std::memory_order_relaxed);
-    wl_kernel_log(__PRETTY_FUNCTION__);
+    if (primary) wl_last_kernel_ptr.store(name, std::memory_order_relaxed);
+    wl_kernel_log(name);
     if (lds > 48 * 1024) {
         // opt in to large dynamic LDS once per kernel (idempotent, cheap)
         static thread_local unsigned granted = 0;   // bit d: done for device d (the attribute is per device)
@@ -73,4 +73,16 @@ static int wl_launch(const typename K::Args& a, int64_t nblocks, size_t lds, voi
     hipLaunchKernelGGL(wl_kernel<K>, dim3((unsigned)nblocks), dim3(K::kThreads), lds,
                        reinterpret_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
+}
+template <typename K>
+static int wl_launch(const typename K::Args& a, int64_t nblocks, size_t lds, void* stream) {
+    return wl_launch_named<K>(a, nblocks, lds, stream, __PRETTY_FUNCTION__, true);
+}
+// The armed fallback of a hinted launch (wl_common.h, tap-relation guards): the two-bank variant queued behind a variant that
+// relies on a relation between the filter banks; it returns at once unless the device finds the relation broken.  It is a
+// launch like any other in wl_kernel_history (its name carries this function's), but wl_last_kernel keeps naming the variant
+// the engine chose.
+template <typename K>
+static int wl_launch_armed(const typename K::Args& a, int64_t nblocks, size_t lds, void* stream) {
+    return wl_launch_named<K>(a, nblocks, lds, stream, __PRETTY_FUNCTION__, false);
 }

@@ -241,6 +241,32 @@ inline void wl_wait_vm_dyn(int n) { wl_emu_wait_vm(n < WL_IROWS_MAX_VM ? n : WL_
 
 
 // ---------------------------------------------------------------------------------------------
+// Tap-relation guards.  Some kernel variants hold fewer taps in their scalar registers because of a RELATION between the
+// filter banks (quadrature-mirror highpass banks, the same bank on both axes).  The host's knowledge of such a relation is a
+// hint only (a cache keyed on tensor versions cannot see writes through `.data`): the relation is verified HERE, on the
+// device, against the taps as they are when the kernel runs - every wave of the grid reads the same <= 4 x 20 taps and takes
+// the same decision.  guard 0: no check (the relation is proven by construction, e.g. identical pointers, or not used);
+// guard 1: run only if the relation holds (the hinted variant); guard 2: run only if it does NOT hold (the two-bank variant
+// launched behind a hinted one as its armed fallback: exactly one of the two does the work, the other returns at once).
+// The reference reads its filter buffers on every forward (dwt/transform2d.py:63-74, :131-148): so does this.
+// ---------------------------------------------------------------------------------------------
+WL_HD bool wl_guard_pass(int guard, bool holds) { return guard == 0 || (guard == 1) == holds; }
+// hi[t] == (-1)^t lo[L-1-t] for every t (float compare: -0 == +0 is the same filter, a NaN tap never passes)
+WL_HD bool wl_taps_qmf(const float* lo, const float* hi, int L) {
+    bool ok = true;
+    for (int t = 0; t < L; ++t) {
+        const float m = lo[L - 1 - t];
+        ok = ok && hi[t] == ((t & 1) ? -m : m);
+    }
+    return ok;
+}
+WL_HD bool wl_taps_same(const float* a, const float* b, int L) {
+    bool ok = true;
+    for (int t = 0; t < L; ++t) ok = ok && a[t] == b[t];
+    return ok;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Boundary extension: extended position i of a length-n signal -> source position, or -1 for a
 // zero sample.  Closed forms of SURVEY.md §8 (reference: dwt/lowlevel.py:28-88, utils.py:146-174).
 // ---------------------------------------------------------------------------------------------

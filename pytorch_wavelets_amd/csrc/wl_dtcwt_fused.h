@@ -18,9 +18,11 @@
 //     window: a 2 x 2 block of LL2 and, through q2c, one coefficient of each of the six level-2 orientations.
 // Rows and columns outside a segment / strip that level 2 needs (LQ - 2 = 8 either side) are computed, not exchanged:
 // the level-1 lanes run over them without storing their band-pass outputs.  Above / below the PLANE the same happens on
-// the symmetrically extended input; because the level-1 lowpass filter is symmetric (odd length, linear phase: every
-// biorthogonal table of the reference) the result IS the symmetric extension of LL1 that coldfilt applies - the caller
-// vouches for the symmetry (the Python layer checks the filter table on the host when the module is built).
+// the symmetrically extended input, with the column lowpass taps met in REVERSE order: LL1 row -1-r is then exactly LL1 row r
+// - the symmetric extension of LL1 that coldfilt applies - for ANY taps (sum_t h[t] lo[-1-r + M - t] = sum_t h[t] lo[r + t - M]
+// by the half-sample symmetry of the extended, row-filtered rows).  For the symmetric tables of the reference the reversed order
+// changes nothing; a level-1 lowpass somebody loaded or edited into an asymmetric one is filtered correctly too, so no property
+// of the taps is assumed (rounds 3-4 took the symmetry from a host-side check of the buffer, which writes through `.data` escape).
 #pragma once
 #include "wl_dtcwt_strip.h"
 
@@ -292,6 +294,15 @@ struct WlDtFwd12Strip {
         }
     }
 
+    // the (ll, hl) column filter of an LL1 row above / below the plane (MODE 2; see the header): the window read backwards
+    static WL_DEV void col_filter_rev(const Taps1& R, const wl_v2 (&w)[LW], int c, wl_v2& aL) {
+        aL = wl_v2{0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < L0; ++t) {
+            if (t & 1) fma_cc<1>(aL, w[(c + LW + M0 - t) % LW], R.c0[t / 2]); else fma_cc<0>(aL, w[(c + LW + M0 - t) % LW], R.c0[t / 2]);
+        }
+    }
+
     // ---- level-1 wave ---------------------------------------------------------------------------------------------------
     // What bounds this kernel is each wave's own instruction stream (a wave issues at most one instruction per four cycles),
     // so the epilogue is written for few instructions: the addresses of the twelve band-pass stores of a quad row are one
@@ -366,6 +377,7 @@ struct WlDtFwd12Strip {
                     }
 #endif
                 const int o0 = s.o_base + 4 * hb;              // LL1 rows o0 .. o0 + 3 are completed in this half-batch
+                const bool outp = MODE == 2 && (o0 < 0 || o0 >= f.H);   // all four above / below the plane (o0, H: multiples of 4)
                 wl_v2 pL[2], pH[2];                            // the quad's upper row: (ll, hl), (lh, hh) of its two columns
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -384,8 +396,14 @@ struct WlDtFwd12Strip {
                     wb[w] = row_filter<1>(R, sr[i]);
 #endif
                     wl_v2 aL, aH, bL, bH;
-                    col_filter(R, wa, (w + LW - M) % LW, aL, aH);
-                    col_filter(R, wb, (w + LW - M) % LW, bL, bH);
+                    if (outp) {                                // (wave-uniform; such rows own no band-pass output)
+                        col_filter_rev(R, wa, (w + LW - M) % LW, aL);
+                        col_filter_rev(R, wb, (w + LW - M) % LW, bL);
+                        aH = bH = wl_v2{0.f, 0.f};
+                    } else {
+                        col_filter(R, wa, (w + LW - M) % LW, aL, aH);
+                        col_filter(R, wb, (w + LW - M) % LW, bL, bH);
+                    }
                     if (MODE == 2) {
                         wl_f2 p; p.x = aL.x; p.y = bL.x;
                         *reinterpret_cast<wl_f2*>(l1slot + i * a.l1_pitch + l1c * 4) = p;

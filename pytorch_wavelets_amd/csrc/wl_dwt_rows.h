@@ -133,6 +133,8 @@ struct WlRowsArgs {
     int pp, lds_plane;
     WlRowsLevel g[WL_ROWS_MAXLEV];
     WlRowsSeg seg[3];   // 0: whole plane, 1: top half, 2: bottom half
+    int guard;          // tap-relation guard (wl_common.h): 1 = run only if the row and the column banks hold the same taps (the SAME
+                        // variant), 2 = only if they do not (its armed two-bank fallback), 0 = no check
 };
 
 // The schedule the LAUNCHER steps through to fill WlRowsSeg::sched: fed[j] = next feed of level j.  A feed is one pair
@@ -162,6 +164,9 @@ struct WlRowsSched {
 // SAME = 1: the row and the column banks are the same taps (the launcher saw the same device buffers for both axes - what a
 // transform built from ONE wavelet passes): one set of tap pairs in the scalar file instead of two.  (At 12 taps two sets are
 // 96 scalar registers: the kernel spilled them, 31-35 SGPRs and 16-28 bytes of scratch per lane.)
+#ifndef WL_ROWS_SAME_MIN
+#define WL_ROWS_SAME_MIN 10            // tap counts from which the one-bank variant exists (below, two banks fit the scalar file)
+#endif
 template <typename T, int LT, int PPR, int D = WL_ROWS_DEPTH, int SAME = 0>
 struct WlAfbRows {
     typedef WlRowsArgs<T> Args;
@@ -478,6 +483,10 @@ struct WlAfbRows {
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
         const int tid = ctx.tid;
         const int wave = wl_uniform(tid >> 6), lane = tid & 63;
+        if (LT >= WL_ROWS_SAME_MIN && a.guard) {   // "both axes filter with the same taps", checked against the taps as they are now
+            const bool holds = wl_taps_same(a.h_w_lo, a.h_h_lo, LT) && wl_taps_same(a.h_w_hi, a.h_h_hi, LT);
+            if (!wl_guard_pass(a.guard, holds)) return;
+        }
         // workgroup -> (plane, segment)
         const int64_t bid = ctx.bid;
         const int sub = wl_uniform(a.role_sub[wave]);

@@ -117,6 +117,8 @@ struct WlStripArgs {
     int st_off, st_pitch;          // staged ring: 2 slots x 4 rows x st_pitch bytes (float32)
     int lds_bytes;
     int pair_ok;                   // every output-column pair of every band row is one aligned 2-element store (even Kw, ll_rs)
+    int guard;                     // tap-relation guard (wl_common.h): 1 = run only if both highpass banks are the quadrature mirrors of
+                                   // their lowpass banks (the QMF variant), 2 = only if not (its armed two-bank fallback), 0 = no check
 };
 
 // QMF = 1: the caller vouches that each highpass bank is the quadrature mirror of its lowpass bank, hi[t] = (-1)^t lo[L-1-t]
@@ -628,6 +630,10 @@ struct WlAfbStrip {
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
         const int tid = ctx.tid;
         const int wave = wl_uniform(tid >> 6), lane = tid & 63;
+        if (a.guard) {   // the relation the QMF variant relies on, checked against the taps as they are now (uniform: before any barrier)
+            const bool holds = wl_taps_qmf(a.h_w_lo, a.h_w_hi, LT) && wl_taps_qmf(a.h_h_lo, a.h_h_hi, LT);
+            if (!wl_guard_pass(a.guard, holds)) return;
+        }
         // workgroup -> (plane, segment, strip): strips of one plane and segment are neighbours on the same XCD (they
         // share halo columns), segments next
         const int64_t lbid = wl_xcd_remap(ctx.bid, a.nblocks);

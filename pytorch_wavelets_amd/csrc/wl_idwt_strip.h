@@ -46,6 +46,8 @@ struct WlIStripArgs {
     int st_off, st_pitch;          // staged ring: 2 slots x 8 rows x st_pitch bytes (float32)
     int lds_bytes;
     int quad_ok;                   // every lane's 4 output columns are one aligned store (OW % 4 == 0, aligned y)
+    int guard;                     // tap-relation guard (wl_common.h): 1 = run only if both highpass banks are the quadrature mirrors of
+                                   // their lowpass banks (the QMF variant), 2 = only if not (its armed two-bank fallback), 0 = no check
 };
 
 // QMF = 1: the caller vouches that each highpass bank is the quadrature mirror of its lowpass bank, g1[t] = (-1)^t g0[L-1-t]
@@ -425,6 +427,10 @@ struct WlSfbStrip {
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
         const int tid = ctx.tid;
         const int wave = wl_uniform(tid >> 6), lane = tid & 63;
+        if (a.guard) {   // the relation the QMF variant relies on, checked against the taps as they are now (uniform: before any barrier)
+            const bool holds = wl_taps_qmf(a.g_w_lo, a.g_w_hi, LT) && wl_taps_qmf(a.g_h_lo, a.g_h_hi, LT);
+            if (!wl_guard_pass(a.guard, holds)) return;
+        }
         const int64_t lbid = wl_xcd_remap(ctx.bid, a.nblocks);
         const int per_plane = a.nstrips * a.nseg;
         const int64_t plane = lbid / per_plane;

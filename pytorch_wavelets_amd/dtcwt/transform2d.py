@@ -34,9 +34,9 @@ class DTCWTForward(nn.Module):
             h0o, h1o = biort[0], biort[1]
         self.register_buffer('h0o', prep_filt(h0o, 1))
         self.register_buffer('h1o', prep_filt(h1o, 1))
-        # a symmetric level-1 lowpass (every biorthogonal table) lets levels 1 and 2 run as one fused launch (FWD_J12): checked
-        # against the h0o buffer as it is at call time (ops.TapVerdict; the reference reads its buffers on every forward, :87-147)
-        self._h0o_symmetric = ops.TapVerdict(ops.is_symmetric_taps)
+        # (levels 1 and 2 run as one fused launch, FWD_J12, for ANY level-1 taps: the kernel meets the column lowpass taps in
+        # reverse order on the rows it computes above / below the plane, which is exact whether or not h0o is symmetric - rounds
+        # 3-4 required a symmetric h0o and checked the buffer on the host, a check that writes through `.data` escaped)
         if isinstance(qshift, str):
             h0a, h0b, _, _, h1a, h1b, _, _ = _qshift(qshift)[:8]
         else:
@@ -61,7 +61,7 @@ class DTCWTForward(nn.Module):
         # odd sizes are extended by edge replication and sizes that are not multiples of 4 by one row /
         # column on both sides (reference :116-135): both happen inside the kernels
         first = 1
-        if (self.J >= 2 and self._h0o_symmetric(self.h0o) and not self.skip_hps[0] and not self.skip_hps[1]
+        if (self.J >= 2 and not self.skip_hps[0] and not self.skip_hps[1]
                 and not self.include_scale[0]):
             low, highs[0], highs[1] = FWD_J12.apply(x, self.h0o, self.h1o, self.h0a, self.h1a, self.h0b, self.h1b,
                                                     self.o_dim, self.ri_dim, mode)
@@ -132,6 +132,7 @@ class DTCWTInverse(nn.Module):
                 # the last two levels as one operator (one launch where the engine takes it) when no crop separates them
                 low2 = self._crop_to(low, s, h_dim, w_dim)
                 if (s.dim() == 6 and highs[0].dim() == 6 and s.shape[self.o_dim] == 6 and s.shape[self.ri_dim] == 2
+                        and highs[0].shape[self.o_dim] == 6 and highs[0].shape[self.ri_dim] == 2   # (malformed level 1: the per-level path and its asserts)
                         and low2.shape[2] == 2 * s.shape[h_dim] and low2.shape[3] == 2 * s.shape[w_dim]
                         and low2.shape[2] == highs[0].shape[h_dim] and low2.shape[3] == highs[0].shape[w_dim]):
                     return INV_J21.apply(low2, s, highs[0], self.g0o, self.g1o, self.g0a, self.g1a, self.g0b, self.g1b,

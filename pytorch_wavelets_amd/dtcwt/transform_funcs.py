@@ -157,8 +157,8 @@ class FWD_J2PLUS(Function):
 class FWD_J12(Function):
     """Levels 1 and 2 of the forward as ONE operator: ``FWD_J12.apply(x, h0o, h1o, h0a, h1a, h0b, h1b, o_dim, ri_dim,
     mode_int) -> (ll2, highs1, highs2)`` = FWD_J1 followed by FWD_J2PLUS (reference dtcwt/transform2d.py:121-141) without
-    the level-1 lowpass in between.  One launch of the fused streaming kernel where the engine takes it (the caller
-    vouches for a symmetric ``h0o``), the two per-level launches otherwise; the backward is the chain of the two
+    the level-1 lowpass in between.  One launch of the fused streaming kernel where the engine takes it (any taps: nothing
+    is assumed of ``h0o``), the two per-level launches otherwise; the backward is the chain of the two
     per-level backward passes (reference transform_funcs.py:361-374, :395-413)."""
 
     @staticmethod

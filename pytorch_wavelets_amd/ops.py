@@ -169,11 +169,15 @@ _HINTS = threading.local()
 
 
 class TapVerdict(object):
-    """A host-side property of filter buffers (a kernel-variant hint) that is valid for the buffers AS THEY ARE AT CALL TIME,
-    like everything the reference derives from its buffers (it reads them on every forward: dwt/transform2d.py:131-148,
-    dtcwt/transform2d.py:87-147).  The verdict is cached under (data_ptr, _version, dtype, device, shape) of every buffer it
-    depends on - one tuple compare per call, no device sync - and recomputed on the host when that key changes: in-place
-    edits (mul_, copy_, load_state_dict), re-assigned attributes, .half() / .double() / .to(...) all change it.  Buffers without
+    """A host-side property of filter buffers, used as a kernel-variant HINT ONLY: which variant to try first.  Correctness never
+    rests on it - every variant that relies on a relation between the filter banks (quadrature-mirror highpass banks, the same
+    bank on both axes) verifies that relation ON THE DEVICE against the taps as they are when the kernel runs and leaves the work
+    to the two-bank variant queued behind it when it does not hold (csrc/wl_common.h, "tap-relation guards"), like the reference,
+    which reads its buffers on every forward (dwt/transform2d.py:63-74, :131-148).  The verdict is cached under (data_ptr,
+    _version, dtype, device, shape) of every buffer it depends on - one tuple compare per call, no device sync - and recomputed on
+    the host when that key changes: in-place edits (mul_, copy_, load_state_dict), re-assigned attributes, .half() / .double() /
+    .to(...) all change it.  What the key cannot see (writes through `.data`, whose alias has a version counter of its own; a
+    re-assigned buffer that reuses an address) leaves a stale hint, which costs one empty launch and nothing else.  Buffers without
     a version counter (inference tensors) get no hint at all.  `fn` must be a module-level function (modules stay picklable)."""
 
     def __init__(self, fn):
@@ -209,9 +213,10 @@ def is_symmetric_taps(h):
 
 @contextlib.contextmanager
 def qmf_hint(flag):
-    """Inside this context the caller vouches that the HIGHPASS banks handed to sfb2d_stream / afb2d_stream are the quadrature
+    """Inside this context the caller HINTS that the HIGHPASS banks handed to sfb2d_stream / afb2d_stream are the quadrature
     mirrors of the lowpass banks, hi[t] = (-1)**t * lo[L-1-t] (policy bit 1 of wl_dwt2d_synthesis_stream /
-    wl_dwt2d_analysis_stream): DWTInverse / DWTForward set it from their buffers as they are at call time (TapVerdict)."""
+    wl_dwt2d_analysis_stream): DWTInverse / DWTForward set it from their buffers (TapVerdict).  The QMF kernel variant checks the
+    relation on the device and the two-bank variant stands by behind it: a wrong hint is slow, not wrong."""
     prev = getattr(_HINTS, 'qmf', False)
     _HINTS.qmf = bool(flag)
     try:
@@ -229,10 +234,11 @@ def banks_equal(lo_a, hi_a, lo_b, hi_b):
 
 @contextlib.contextmanager
 def same_banks_hint(flag):
-    """Inside this context the caller vouches that the row and the column banks handed to afb2d_fused are the same taps (a
-    transform built from one wavelet): the launcher is then given ONE pair of device buffers for both axes, which is how the
-    streaming analysis kernel recognises that it needs one set of tap pairs in its scalar registers instead of two
-    (wl_rows_api.inc: 10 and 12 taps no longer spill them).  DWTForward sets it from its buffers as they are at call time."""
+    """Inside this context the caller HINTS that the row and the column banks handed to afb2d_fused are the same taps (a
+    transform built from one wavelet): bit 2 of the launcher's `strips` argument.  The streaming analysis kernel then runs its
+    one-bank variant - one set of tap pairs in its scalar registers instead of two (wl_rows_api.inc: 10 and 12 taps no longer
+    spill them) - which compares the two banks on the device first; the two-bank variant stands by behind it.  DWTForward sets it
+    from its buffers (TapVerdict)."""
     prev = getattr(_HINTS, 'same', False)
     _HINTS.same = bool(flag)
     try:
@@ -245,8 +251,10 @@ STREAM_FORCE = False   # tests: send every single-level analysis the strip kerne
 FUSED_STRIPS = 0   # default `strips` of the two streaming entry points below: 0 = the engine's policy (the planes must fill
                    # the chip), 1 / 2 = force the streaming kernels whatever the batch (tests pin their backward passes so)
 # configurations the streaming launchers declined (WL_ERR_UNSUPPORTED for reasons only they can see: rows wider than the
-# compute waves, LDS budget, schedule table, ...).  A decline depends on nothing but the key, so the outputs of a doomed
-# call are allocated once per configuration, not on every forward of the n = 3, 2, 1 ladder of the callers.
+# compute waves, LDS budget, schedule table, ...).  A decline depends on nothing but the key - every argument the launcher's
+# decision can depend on is part of it: device (CU count), dtype, plane count, sizes, strides, tap counts, mode / extension,
+# output placement - so the outputs of a doomed call are allocated once per configuration, not on every forward of the
+# n = 3, 2, 1 ladder of the callers.
 _FUSED_DECLINED = set()
 _FUSED_DECLINED_MAX = 4096
 
@@ -300,8 +308,9 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None):
     if key in _FUSED_DECLINED or x.data_ptr() % 16:
         return None
     hwl, hwh, hhl, hhh = (_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi))
-    if getattr(_HINTS, 'same', False):
-        hhl, hhh = hwl, hwh              # (the caller vouches they are the same taps: same_banks_hint)
+    # same_banks_hint: bit 2 of `strips` - a HINT; the one-bank kernel variant compares the two banks on the device and the
+    # two-bank variant stands by behind it, so a stale hint costs an empty launch, never a wrong coefficient
+    same = 4 if getattr(_HINTS, 'same', False) else 0
     yh = []
     h, w = H, W
     for _ in range(nlev):
@@ -310,7 +319,7 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None):
     yl = torch.empty((N, C, h, w), dtype=x.dtype, device=x.device)
     ptrs = (ctypes.c_void_p * nlev)(*[t.data_ptr() for t in yh])
     rc = _call('wl_dwt2d_analysis_fused', x, x.data_ptr(), yl.data_ptr(), ptrs, _DTYPES[x.dtype], N * C, H, W, nlev,
-               hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(), hhh.data_ptr(), L, mode, strips, _stream(x))
+               hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(), hhh.data_ptr(), L, mode, strips | same, _stream(x))
     if rc == -3:
         _remember_decline(key)
         return None
@@ -721,13 +730,13 @@ def swt2d_level(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, dilation, ext):
     Lw, Lh = h_w_lo.numel(), h_h_lo.numel()
     if h_w_hi.numel() != Lw or h_h_hi.numel() != Lh or x.numel() == 0:
         return None
-    key = ('swt2d', x.device, x.dtype, H, W, Lw, Lh, dilation)
-    if key in _FUSED_DECLINED:
-        return None
     st = _plane_strides(x)
     if st is None or st[1] != W:
         x = x.contiguous()
         st = (H * W, W)
+    key = ('swt2d', x.device, x.dtype, N * C, H, W, st[0], Lw, Lh, dilation, ext)
+    if key in _FUSED_DECLINED:
+        return None
     taps = [_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi)]
     y = torch.empty((N, 4 * C, H, W), dtype=x.dtype, device=x.device)
     rc = _call('wl_swt2d_level', x, x.data_ptr(), st[0], y.data_ptr(), _DTYPES[x.dtype], N * C, H, W,
@@ -844,7 +853,7 @@ def dtcwt_fwd1_rot(x, h0, h1, h2, symmetric, scat=False, magbias=0.0):
     if x.dim() != 4 or x.numel() == 0:
         return None
     N, C, H, W = x.shape
-    key = ('dtrot', x.device, x.dtype, H, W, h0.numel(), h1.numel(), h2.numel())
+    key = ('dtrot', x.device, x.dtype, N, C, H, W, h0.numel(), h1.numel(), h2.numel(), bool(symmetric), bool(scat))
     if key in _FUSED_DECLINED:
         return None
     x = x.contiguous()
@@ -870,13 +879,14 @@ def dtcwt_fwd1_rot(x, h0, h1, h2, symmetric, scat=False, magbias=0.0):
 def dtcwt_fwd12(x, h0o, h1o, h0a, h0b, h1a, h1b, mode, force=False):
     """Levels 1 and 2 of the forward in one launch (wl_dtcwt_fwd_level12: the level-1 lowpass stays on chip):
     x (N,C,H,W) -> (highs1 (N,C,6,H/2,W/2,2), ll2 (N,C,H/2,W/2), highs2 (N,C,6,H/4,W/4,2)), or None when the engine
-    declines (callers chain dtcwt_fwd1 / dtcwt_fwd2).  The caller vouches for a symmetric h0o."""
+    declines (callers chain dtcwt_fwd1 / dtcwt_fwd2).  Exact for any taps (csrc/wl_dtcwt_fused.h: the rows above / below the
+    plane meet the column lowpass taps in reverse order, so no symmetry of h0o is assumed)."""
     _check_tensor(x, 'x')
     N, C, H, W = x.shape
     if mode != 1 or H % 4 or W % 4 or x.dtype not in (torch.float32, torch.float16):
         return None
     force = force or STREAM_FORCE
-    key = ('dt12', x.dtype, N * C, H, W, h0o.numel(), h1o.numel(), h0a.numel(), x.device.index)
+    key = ('dt12', x.device, x.dtype, N * C, H, W, h0o.numel(), h1o.numel(), h0a.numel(), mode)
     if not force and key in _FUSED_DECLINED:
         return None
     x = x.contiguous()
@@ -978,11 +988,11 @@ def dtcwt_inv21(ll2, highs2, highs1, g0o, g1o, g0a, g0b, g1a, g1b, mode, force=F
             or tuple(highs1.shape) != (N, C, 6, h, w, 2) or ll2.numel() == 0):
         return None
     force = force or STREAM_FORCE
-    key = ('dti21', ll2.dtype, N * C, h, w, g0o.numel(), g1o.numel(), g0a.numel(), ll2.device.index)
-    if not force and key in _FUSED_DECLINED:
-        return None
     _same_device(ll2, highs2, highs1)
     ll2, ps, rs = _planes(ll2)
+    key = ('dti21', ll2.device, ll2.dtype, N * C, h, w, ps, rs, g0o.numel(), g1o.numel(), g0a.numel(), mode)
+    if not force and key in _FUSED_DECLINED:
+        return None
     highs2, highs1 = highs2.contiguous(), highs1.contiguous()
     t0, t1 = _taps(g0o, ll2), _taps(g1o, ll2)
     ta, tb, tc, td = (_taps(g, ll2) for g in (g0a, g0b, g1a, g1b))
@@ -1051,7 +1061,7 @@ def scat_fwd2_into(x, z, z_bs, z_ll_off, z_mag_off, h0a, h0b, h1a, h1b, magbias)
     assert z.is_contiguous() and z.dtype == x.dtype and z.device == x.device
     last = (N - 1) * z_bs + max(z_ll_off + C * q, z_mag_off + 6 * C * q)
     assert N == 0 or (min(z_bs, z_ll_off, z_mag_off) >= 0 and last <= z.numel()), 'entries outside z'
-    key = ('scat2', x.dtype, N * C, H, W, int(h0a.numel()))
+    key = ('scat2', x.device, x.dtype, N, C, H, W, int(h0a.numel()), z_bs, z_ll_off, z_mag_off)
     if H % 4 or W % 4 or key in _FUSED_DECLINED:
         return False
     ta, tb, tc, td = (_taps(h, x) for h in (h0a, h0b, h1a, h1b))

@@ -28,6 +28,18 @@ def _inv_oracle(ifm, yl, yh, mode):
                           _flat(ifm.g0_col), _flat(ifm.g1_col), _flat(ifm.g0_row), _flat(ifm.g1_row), mode)
 
 
+def primary(ks):
+    """kernels_since without the armed fallbacks (the two-bank variants queued behind a variant that relies on a relation
+    between the filter banks; they return at once unless the device finds the relation broken)"""
+    return [k for k in ks if not k.endswith('(armed fallback)')]
+
+
+def _stale_hint_launches(ks, hinted_test, plain_test, what):
+    """A write the host's cache key cannot see (through `.data`): the hinted variant is launched, finds the relation broken
+    on the device and returns; the armed two-bank variant behind it does the work."""
+    assert len(ks) == 2 and hinted_test(ks[0]) and ks[1].endswith('(armed fallback)') and plain_test(ks[1]), (what, ks)
+
+
 def _is_qmf_kernel(name):
     if 'WlSfbStrip<' not in name:
         return False
@@ -110,6 +122,21 @@ def check_dwt_inverse_mutations(dev, wave='db8', mode='symmetric', shape=(2, 2, 
         taps = [rng.randn(len(h0)) for _ in range(4)]
         ifm2 = pw.DWTInverse(wave=tuple(taps), mode=mode).to(dev).to(dtype)
         run(ifm2, False, 'custom banks')
+        # 5b. writes through `.data` (its alias has a version counter of its own: the host's cache key does not move and the
+        # hint goes stale - the round-4 advisor's repro).  The QMF variant checks the relation on the device and returns; the
+        # armed two-bank variant behind it does the work: equal to the oracle on the mutated taps.
+        if has_q:
+            for edit, what in ((lambda m: m.g1_col.data.mul_(2), 'g1_col.data.mul_'),
+                               (lambda m: m.g1_row.data.copy_(torch.tensor(rng.randn(*m.g1_row.shape), dtype=dtype, device=dev)), 'g1_row.data.copy_'),
+                               (lambda m: m.g0_col.data.add_(0.125), 'g0_col.data.add_')):
+                ifm = fresh()
+                run(ifm, True, 'pristine before ' + what)
+                edit(ifm)
+                c0 = pw.launch_count()
+                r = ifm((yl, yh))
+                ks = pw.kernels_since(c0)
+                _stale_hint_launches(ks, _is_qmf_kernel, lambda k: 'WlSfbStrip<' in k and not _is_qmf_kernel(k.replace(' (armed fallback)', '')), what)
+                assert _rel(r, _inv_oracle(ifm, yl, yh, mode)) <= tol, (what, _rel(r, _inv_oracle(ifm, yl, yh, mode)))
         # 6. copies of a module carry a valid hint of their own
         ifm = fresh()
         run(ifm, True, 'pristine 6')
@@ -163,9 +190,10 @@ def _fwd_oracle(xfm, x, J):
 
 
 def check_dtcwt_forward_mutations(dev, shape=(2, 1, 32, 256), tol=1e-5):
-    """DTCWTForward J=2 on the (forced) fused level-1+2 kernel, which relies on a symmetric h0o for the rows it computes
-    above / below the plane: un-mutated -> fused, equal to the oracle; a non-symmetric h0o by any route -> per-level path,
-    equal to the oracle on the mutated taps."""
+    """DTCWTForward J=2 on the (forced) fused level-1+2 kernel.  Rounds 3-4: the kernel relied on a symmetric h0o for the rows
+    it computes above / below the plane and the module checked the buffer on the host (a check writes through `.data` escaped).
+    Round 5: those rows meet the column lowpass taps in reverse order, exact for ANY taps - so every mutated, non-symmetric h0o
+    below STAYS on the fused launch and must equal the oracle on the mutated taps (`want_fused` is True throughout)."""
     from pytorch_wavelets_amd import ops
     rng = np.random.RandomState(3)
     prev = ops.STREAM_FORCE
@@ -195,33 +223,40 @@ def check_dtcwt_forward_mutations(dev, shape=(2, 1, 32, 256), tol=1e-5):
         sd = {k: v.clone() for k, v in xfm.state_dict().items()}
         sd['h0o'] = asym.clone()
         xfm.load_state_dict(sd)
-        run(xfm, False, 'load_state_dict')
+        run(xfm, True, 'load_state_dict')
         xfm.load_state_dict(fresh().state_dict())
         run(xfm, True, 'load_state_dict back')
         # 2. in-place edit
         xfm = fresh()
         run(xfm, True, 'pristine 2')
         xfm.h0o[0, 0, 0, 0] += 0.125
-        run(xfm, False, 'h0o[...] +=')
+        run(xfm, True, 'h0o[...] +=')
         # 3. re-assignment / .data
         xfm = fresh()
         run(xfm, True, 'pristine 3')
         xfm.h0o = asym.clone()
-        run(xfm, False, 'h0o = ...')
+        run(xfm, True, 'h0o = ...')
         xfm = fresh()
         run(xfm, True, 'pristine 4')
         xfm.h0o.data = asym.clone()
-        run(xfm, False, 'h0o.data = ...')
+        run(xfm, True, 'h0o.data = ...')
         # 4. tuples of arrays as constructor input (documented upstream), non-symmetric
         hb = F.dtcwt_forward_taps('near_sym_a', 'qshift_a')
         bi = (np.array([0.1, 0.3, 0.5, 0.2, -0.1]), _unprep(hb[1]))
         qs = tuple(_unprep(t) for t in (hb[2], hb[3], hb[4], hb[5]))
         xfm = pw.DTCWTForward(J=2, biort=bi, qshift=qs).to(dev)
-        run(xfm, False, 'tuple biort')
-        # 5. a symmetric edit keeps the fused launch
+        run(xfm, True, 'tuple biort')
+        # 5. a symmetric edit
         xfm = fresh()
         xfm.h0o.mul_(0.5)
         run(xfm, True, 'symmetric edit')
+        # 6. writes through `.data` (invisible to any host-side cache): non-symmetric 5 taps, and a 7-tap non-symmetric h1o
+        xfm = fresh()
+        run(xfm, True, 'pristine 6')
+        xfm.h0o.data.copy_(asym)
+        run(xfm, True, 'h0o.data.copy_')
+        xfm.h1o.data[0, 0, 1, 0] += 0.375
+        run(xfm, True, 'h1o.data[...] +=')
     finally:
         ops.STREAM_FORCE = prev
 
@@ -279,6 +314,21 @@ def check_dwt_forward_mutations(dev, wave='db8', mode='symmetric', shape=(2, 2, 
         xfm = fresh()
         xfm.h1_col = (xfm.h1_col * 2).clone()
         run(xfm, False, 'h1_col = ...')
+        # writes through `.data`: invisible to the host's cache key (the round-4 advisor's repro: h1_col.data.mul_(2)) - the QMF
+        # variant finds the relation broken on the device, the armed two-bank variant behind it does the work
+        for edit, what in ((lambda m: m.h1_col.data.mul_(2), 'h1_col.data.mul_'),
+                           (lambda m: m.h0_row.data.copy_(torch.tensor(rng.randn(*m.h0_row.shape), dtype=dtype, device=dev)), 'h0_row.data.copy_')):
+            xfm = fresh()
+            run(xfm, True, 'pristine before ' + what)
+            edit(xfm)
+            c0 = pw.launch_count()
+            yl, yh = xfm(x)
+            ks = pw.kernels_since(c0)
+            _stale_hint_launches(ks, _is_qmf_analysis_kernel,
+                                 lambda k: 'WlAfbStrip<' in k and not _is_qmf_analysis_kernel(k.replace(' (armed fallback)', '')), what)
+            oyl, oyh = wo.dwt_forward(x.detach().cpu().double().numpy(), 1, _flat(xfm.h0_col), _flat(xfm.h1_col),
+                                      _flat(xfm.h0_row), _flat(xfm.h1_row), mode)
+            assert _rel(yl, oyl) <= tol and _rel(yh[0], oyh[0]) <= tol, (what, _rel(yl, oyl), _rel(yh[0], oyh[0]))
         h0 = F.dwt_analysis_taps(wave)[0]
         xfm2 = pw.DWTForward(J=1, wave=tuple(rng.randn(len(h0)) for _ in range(4)), mode=mode).to(dev).to(dtype)
         run(xfm2, False, 'custom banks')
@@ -328,6 +378,23 @@ def check_dwt_forward_same_banks_mutations(dev, wave='db6', mode='symmetric', sh
         xfm = fresh()
         xfm.h1_row = (xfm.h1_row * 2).clone()
         run(xfm, False, 'h1_row = ...')
+        # writes through `.data` (invisible to the host's cache key; the round-4 advisor's repro: h1_row.data.mul_(2)): the
+        # one-bank variant compares the banks on the device and returns, the armed two-bank variant behind it does the work
+        for edit, what in ((lambda m: m.h1_row.data.mul_(2), 'h1_row.data.mul_'),
+                           (lambda m: m.h0_col.data.copy_(torch.tensor(rng.randn(*m.h0_col.shape), dtype=dtype, device=dev)), 'h0_col.data.copy_')):
+            xfm = fresh()
+            run(xfm, True, 'pristine before ' + what)
+            edit(xfm)
+            c0 = pw.launch_count()
+            yl, yh = xfm(x)
+            ks = pw.kernels_since(c0)
+            _stale_hint_launches(ks, lambda k: 'WlAfbRows<' in k and k.endswith(', 3, 1>'),
+                                 lambda k: 'WlAfbRows<' in k and not k.replace(' (armed fallback)', '').endswith(', 3, 1>'), what)
+            oyl, oyh = wo.dwt_forward(x.detach().cpu().double().numpy(), 2, _flat(xfm.h0_col), _flat(xfm.h1_col),
+                                      _flat(xfm.h0_row), _flat(xfm.h1_row), mode)
+            assert _rel(yl, oyl) <= tol, (what, 'yl', _rel(yl, oyl))
+            for a, b in zip(yh, oyh):
+                assert _rel(a, b) <= tol, (what, 'yh', _rel(a, b))
         h0 = F.dwt_analysis_taps(wave)[0]
         xfm2 = pw.DWTForward(J=2, wave=tuple(rng.randn(len(h0)) for _ in range(4)), mode=mode).to(dev).to(dtype)
         run(xfm2, False, 'custom banks')

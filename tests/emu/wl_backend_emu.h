@@ -113,11 +113,11 @@ inline void wl_emu_entry(unsigned lo, unsigned hi) {
 }
 
 template <typename K>
-static int wl_launch(const typename K::Args& a, int64_t nblocks, size_t lds, void* /*stream*/) {
+static int wl_launch_named(const typename K::Args& a, int64_t nblocks, size_t lds, void* /*stream*/, const char* name, bool primary) {
     if (nblocks <= 0) return 0;
     if (lds > 160 * 1024) return -2;
-    wl_last_kernel_ptr = __PRETTY_FUNCTION__;
-    wl_kernel_log_buf[wl_kernel_log_n++ & 7] = __PRETTY_FUNCTION__;
+    if (primary) wl_last_kernel_ptr = name;
+    wl_kernel_log_buf[wl_kernel_log_n++ & 7] = name;
     const int nt = K::kThreads;
     const size_t kStack = 256 * 1024;
 #pragma omp parallel
@@ -198,4 +198,13 @@ static int wl_launch(const typename K::Args& a, int64_t nblocks, size_t lds, voi
         free(smem);
     }
     return 0;
+}
+template <typename K>
+static int wl_launch(const typename K::Args& a, int64_t nblocks, size_t lds, void* stream) {
+    return wl_launch_named<K>(a, nblocks, lds, stream, __PRETTY_FUNCTION__, true);
+}
+// (see wl_backend_hip.h: the armed fallback of a hinted launch)
+template <typename K>
+static int wl_launch_armed(const typename K::Args& a, int64_t nblocks, size_t lds, void* stream) {
+    return wl_launch_named<K>(a, nblocks, lds, stream, __PRETTY_FUNCTION__, false);
 }
