@@ -97,7 +97,10 @@ int wl_dwt2d_synthesis(const void* ll, int64_t ll_plane_stride, int ll_row_strid
  * zero / symmetric / reflect for nlev > 1, any mode for nlev == 1.  `strips`: 0 = let the engine decide (it declines
  * below about 3/8 as many planes as compute units, where the tile kernels win; with fewer planes than compute units it
  * cuts planes in two so that every workgroup has a compute unit of its own), 1 = force this kernel, whole planes,
- * 2 = force, every plane cut in two.  Returns WL_ERR_UNSUPPORTED outside the
+ * 2 = force, every plane cut in two; + 4 (bit 2) = a HINT that (h_h_lo, h_h_hi) hold the same taps as (h_w_lo, h_w_hi): the
+ * 10- and 12-tap kernels then run their one-bank variant (one set of tap pairs in scalar registers), which compares the two
+ * banks on the device first, with the two-bank variant queued behind it for the case that they differ (identical POINTERS for
+ * both axes need no hint and no check).  Returns WL_ERR_UNSUPPORTED outside the
  * kernel's envelope: the caller then uses wl_dwt2d_analysis level by level. */
 int wl_dwt2d_analysis_fused(const void* x, void* yl, void* const* yh, int dtype, int64_t planes, int H,
                             int W, int nlev, const void* h_w_lo, const void* h_w_hi, const void* h_h_lo,
@@ -227,20 +230,31 @@ int wl_scat_bwd_level1(const void* dz, const void* drdx, const void* drdy, void*
 /* ONE analysis level by the streaming strip kernel (csrc/wl_dwt_strip.h): the same operator as wl_dwt2d_analysis_strided
  * (AFB2D.forward, dwt/lowlevel.py:336-347) for one square filter length L (even, <= 20), float32 / float16, every mode, rows
  * of any width that are a whole number of 16-byte pieces: every input sample is read once per column strip and row
- * segment, by LDS-DMA.  policy bit 0: 0 = the engine decides whether the launch pays (enough workgroups for the chip), 1 = force; bit 1 (value 2) = the caller vouches that each highpass bank is the quadrature mirror of its lowpass bank, h_hi[t] == (-1)^t h_lo[L-1-t] (the pair of every orthogonal wavelet as stored): from 12 taps on the kernel then holds the lowpass banks only.
+ * segment.  policy bit 0: 0 = the engine decides whether the launch pays (enough workgroups for the chip), 1 = force;
+ * bit 1 (value 2) = a HINT that each highpass bank is the quadrature mirror of its lowpass bank, h_hi[t] == (-1)^t h_lo[L-1-t]
+ * (the pair of every orthogonal wavelet as stored): from 12 taps on the engine then launches a kernel variant that relies on
+ * the relation - it holds the lowpass banks only - and VERIFIES it on the device against the taps as they are when it runs;
+ * the two-bank variant is queued behind it and does the work when the relation does not hold (a wrong hint costs an empty
+ * launch, never a wrong coefficient).  tap_scratch: NULL, or WL_TAP_SCRATCH_BYTES of device memory that stay valid until the
+ * launches of this call have run (stream order): with the hint the hinted variant is then the LATTICE kernel
+ * (csrc/wl_lattice.h: the column pass as K = L/2 plane rotations, half the multiplications), whose coefficients a one-thread
+ * kernel derives from the column bank on the device and accepts only if they reproduce the bank to 2^-22 (float32 data) /
+ * 2^-12 (float16 data) of its largest tap - else the two-bank variant runs as above.
  * Returns WL_ERR_UNSUPPORTED outside its envelope (callers then use wl_dwt2d_analysis_strided). */
+#define WL_TAP_SCRATCH_BYTES 64
 int wl_dwt2d_analysis_stream(const void* x, int64_t x_plane_stride, int x_row_stride, void* ll, int64_t ll_plane_stride,
                              int ll_row_stride, void* highs, int dtype, int64_t planes, int H, int W, const void* h_w_lo,
                              const void* h_w_hi, const void* h_h_lo, const void* h_h_hi, int L, int mode, int policy,
-                             void* stream);
+                             void* tap_scratch, void* stream);
 
 /* ONE synthesis level by the streaming strip kernel (csrc/wl_idwt_strip.h): the same operator as wl_dwt2d_synthesis
  * (SFB2D.forward, dwt/lowlevel.py:671-680; the (OH, OW) crop is AFB2D.backward's, :356-364) for one square filter length L
  * (even, <= 20), float32 / float16, every mode, coefficient rows that are whole 16-byte pieces; highs must be present.
- * policy bit 0 as for wl_dwt2d_analysis_stream (1 = force); bit 1 (value 2) = the caller vouches that each highpass bank is
+ * policy bit 0 as for wl_dwt2d_analysis_stream (1 = force); bit 1 (value 2) = a HINT that each highpass bank is
  * the quadrature mirror of its lowpass bank, g_hi[t] = (-1)^t g_lo[L-1-t] (the reconstruction pair of every orthogonal
- * wavelet): from 12 taps on the kernel then derives the highpass tap pairs from the lowpass ones by operand modifiers instead
- * of holding both banks in scalar registers (same arithmetic, same results).  Returns WL_ERR_UNSUPPORTED outside its envelope. */
+ * wavelet): from 12 taps on the hinted kernel variant derives the highpass tap pairs from the lowpass ones by operand modifiers
+ * instead of holding both banks in scalar registers (same arithmetic, same results) after verifying the relation on the device;
+ * the two-bank variant stands by behind it as for the analysis.  Returns WL_ERR_UNSUPPORTED outside its envelope. */
 int wl_dwt2d_synthesis_stream(const void* ll, int64_t ll_plane_stride, int ll_row_stride, const void* highs, void* y,
                               int dtype, int64_t planes, int Kh, int Kw, int OH, int OW, const void* g_w_lo,
                               const void* g_w_hi, const void* g_h_lo, const void* g_h_hi, int L, int mode, int policy,

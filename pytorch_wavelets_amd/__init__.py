@@ -40,7 +40,8 @@ def kernels_since(count):
         name = raw.split('K = ')[-1].rstrip(']') if 'K = ' in raw else raw
         # the two-bank variant queued behind a variant that relies on a relation between the filter banks: it returns at once
         # unless the device finds the relation broken (csrc/wl_common.h, tap-relation guards)
-        out.append(name + ' (armed fallback)' if 'wl_launch_armed' in raw else name)
+        # ' (aux)': a helper launch in front of the chosen kernel (WlTapPrep: one thread that examines the filter banks on the device)
+        out.append(name + ' (armed fallback)' if 'wl_launch_armed' in raw else name + ' (aux)' if 'wl_launch_aux' in raw else name)
     return out
 
 

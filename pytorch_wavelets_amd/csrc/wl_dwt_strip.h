@@ -27,6 +27,7 @@
 #pragma once
 #include "wl_common.h"
 #include "wl_dwt_rows.h"   // wl_pk_fma_x / _y, wl_pk_mul_x / _y, wl_uniform_v2
+#include "wl_lattice.h"
 
 #ifndef WL_STRIP_CWAVES
 #define WL_STRIP_CWAVES 4
@@ -119,6 +120,8 @@ struct WlStripArgs {
     int pair_ok;                   // every output-column pair of every band row is one aligned 2-element store (even Kw, ll_rs)
     int guard;                     // tap-relation guard (wl_common.h): 1 = run only if both highpass banks are the quadrature mirrors of
                                    // their lowpass banks (the QMF variant), 2 = only if not (its armed two-bank fallback), 0 = no check
+    const float* lat;              // LAT variant and its fallback: the verdict + lattice of the column bank that WlTapPrep left in
+                                   // device scratch (wl_lattice.h); the guard then reads the verdict word instead of the taps
 };
 
 // QMF = 1: the caller vouches that each highpass bank is the quadrature mirror of its lowpass bank, hi[t] = (-1)^t lo[L-1-t]
@@ -127,9 +130,16 @@ struct WlStripArgs {
 // or P[u] with its halves swapped, the high half negated for odd t - operand modifiers of the packed FMA (op_sel, neg_hi).
 // Half the scalar registers: at 16 taps the two banks of rows and columns were 64 of them and the scalar file overflowed
 // (25-34 spilled scalars, read back through v_readlane in the half-batch loop).
-template <typename T, int LT, int QMF = 0>
+// LAT = 1 (with QMF = 1): the COLUMN pass runs the orthogonal bank as a lattice of rotations (wl_lattice.h): per pair of new
+// rows and output column 2 K packed FMAs and K - 1 delayed values instead of the 2 L FMAs and the L-row window of the direct
+// form - this kernel is bound by the vector instructions it issues (16 taps: 285 per half-batch, 272 of them FMAs; with the
+// lattice 72 of the 136 column FMAs go).  The recurrence's coefficients and the verdict that they reproduce the bank in the
+// buffers come from device scratch (a.lat, written by WlTapPrep in front of this launch).
+template <typename T, int LT, int QMF = 0, int LAT = 0>
 struct WlAfbStrip {
     typedef WlStripArgs<T> Args;
+    static_assert(!LAT || QMF, "the lattice variant runs its row pass in the QMF form");
+    static const int KL = LT / 2;                      // rotations of the lattice
     static const int NB = QMF ? LT / 2 : LT;           // tap pairs held per bank
     static const int kWaves = WL_STRIP_CWAVES + WL_STRIP_SWAVES;
     static const int kThreads = 64 * kWaves;
@@ -138,7 +148,8 @@ struct WlAfbStrip {
     static const int A = 16 / SZ;          // elements per 16-byte piece
     static const int WARM = (LT - 2) / 2;  // feeds that only fill the window
     static const int LW = (LT + 3) / 4 * 4;            // window slots: a multiple of the 4 rows of a half-batch
-    static const int PERIOD = LW / 4;      // half-batches after which the circular window is back where it started
+    // half-batches after which the circular window is back where it started (lattice: the K delay slots, two feeds per half-batch)
+    static const int PERIOD = LAT ? (KL % 2 ? KL : KL / 2) : LW / 4;
     static const int NV4 = (LT + 2 + 3) / 4;           // 16-byte words a lane reads per row: its L+2 samples
     static const int D = WL_STRIP_D;
     static const bool kPipe = LT >= 14;    // see compute(): when the rows of a half-batch's second feed are requested
@@ -477,8 +488,23 @@ struct WlAfbStrip {
 #endif
         return r;
     }
+    // d = w * (c, c) + z, c = the low (HI = 0) / high (HI = 1) half of a scalar-register pair; NZ: - z instead of + z
+    template <int HI, int NZ> static WL_DEV wl_v2 fma_s(wl_v2 w, wl_v2 pair, wl_v2 z) {
+        wl_v2 d;
+#if defined(__HIPCC__)
+        if (!HI && !NZ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(w), "s"(pair), "v"(z));
+        else if (HI && !NZ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(w), "s"(pair), "v"(z));
+        else if (!HI && NZ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(w), "s"(pair), "v"(z));
+        else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(w), "s"(pair), "v"(z));
+#else
+        const float c = HI ? pair.y : pair.x;
+        d.x = __builtin_fmaf(w.x, c, NZ ? -z.x : z.x); d.y = __builtin_fmaf(w.y, c, NZ ? -z.y : z.y);
+#endif
+        return d;
+    }
     struct Wave {
-        wl_v2 tw[NB], th[NB];      // (lo,hi) tap pairs along W / along H (wave-uniform: scalar registers); QMF: P[u] = (lo[u], lo[L-1-u])
+        wl_v2 tw[NB], th[NB];             // (lo,hi) tap pairs along W / along H (wave-uniform: scalar registers); QMF: P[u] = (lo[u], lo[L-1-u])
+        wl_v2 lt[LAT ? KL : 1];           // LAT: (T_k, -T_k) of the column lattice (the row taps carry its gain g)
         char* llp; char* hp0; char* hp1; char* hp2;
         unsigned rowb, llrowb;
         bool two, pair_ok;
@@ -511,6 +537,30 @@ struct WlAfbStrip {
         cl = l0 + l1;
         ch = h0 + h1;
     }
+    // One feed of the column lattice for both columns of the lane (wl_lattice.h): (a, b) = the row-filtered pair of new rows;
+    // delay slot of stage k at feed f: (k - f) mod K - stage k - 1 leaves its v in the slot it has just read, stage 0 in the
+    // one free slot, so nothing is ever moved (`rot` = f mod K is compile-time after unrolling).  The two columns are
+    // interleaved stage by stage: a packed FMA that depends on the one right before it costs a wait state.
+    static WL_DEV void lat_feed(const Wave& R, wl_v2 (&SA)[KL], wl_v2 (&SB)[KL], int rot, wl_v2 aA, wl_v2 bA, wl_v2 aB, wl_v2 bB,
+                                wl_v2& loA, wl_v2& hiA, wl_v2& loB, wl_v2& hiB) {
+        wl_v2 uA = fma_s<0, 0>(bA, R.lt[0], aA), uB = fma_s<0, 0>(bB, R.lt[0], aB);         // a + T0 b
+        wl_v2 vA = fma_s<1, 0>(aA, R.lt[0], bA), vB = fma_s<1, 0>(aB, R.lt[0], bB);         // b - T0 a
+        if (KL == 1) { loA = uA; loB = uB; hiA = -vA; hiB = -vB; return; }
+        SA[(KL - rot) % KL] = vA; SB[(KL - rot) % KL] = vB;
+#pragma unroll
+        for (int k = 1; k < KL; ++k) {
+            const int slot = (k + KL - rot) % KL;
+            const wl_v2 dA = SA[slot], dB = SB[slot];
+            const wl_v2 nA = fma_s<0, 0>(dA, R.lt[k], uA), nB = fma_s<0, 0>(dB, R.lt[k], uB);   // u + Tk v'
+            if (k < KL - 1) {
+                SA[slot] = fma_s<1, 0>(uA, R.lt[k], dA); SB[slot] = fma_s<1, 0>(uB, R.lt[k], dB);   // v' - Tk u
+            } else {
+                hiA = fma_s<0, 1>(uA, R.lt[k], dA); hiB = fma_s<0, 1>(uB, R.lt[k], dB);             // -(v' - Tk u)
+            }
+            uA = nA; uB = nB;
+        }
+        loA = uA; loB = uB;
+    }
     static WL_DEV void load_row(const char* p, wl_v2 (&s)[2 * NV4]) {
 #pragma unroll
         for (int u = 0; u < NV4; ++u) {
@@ -531,10 +581,16 @@ struct WlAfbStrip {
         const int kA = s.k0 + 2 * jp;
         const bool active = kA < s.k1;
         Wave R;
+        const float gsc = LAT ? a.lat[1] : 1.f;               // the lattice's gain rides on the row taps
 #pragma unroll
         for (int t = 0; t < NB; ++t) {
-            R.tw[t] = wl_uniform_v2(QMF ? wl_v2{a.h_w_lo[t], a.h_w_lo[LT - 1 - t]} : wl_v2{a.h_w_lo[t], a.h_w_hi[t]});
-            R.th[t] = wl_uniform_v2(QMF ? wl_v2{a.h_h_lo[t], a.h_h_lo[LT - 1 - t]} : wl_v2{a.h_h_lo[t], a.h_h_hi[t]});
+            R.tw[t] = wl_uniform_v2(LAT ? wl_v2{a.h_w_lo[t] * gsc, a.h_w_lo[LT - 1 - t] * gsc}
+                                        : QMF ? wl_v2{a.h_w_lo[t], a.h_w_lo[LT - 1 - t]} : wl_v2{a.h_w_lo[t], a.h_w_hi[t]});
+            if (!LAT) R.th[t] = wl_uniform_v2(QMF ? wl_v2{a.h_h_lo[t], a.h_h_lo[LT - 1 - t]} : wl_v2{a.h_h_lo[t], a.h_h_hi[t]});
+        }
+        if (LAT) {
+#pragma unroll
+            for (int k = 0; k < KL; ++k) R.lt[LAT ? k : 0] = wl_uniform_v2(wl_v2{a.lat[2 + k], -a.lat[2 + k]});
         }
         const unsigned bplane = (unsigned)a.Kh * (unsigned)a.Kw;
         R.hp0 = reinterpret_cast<char*>(a.highs + (size_t)plane * 3 * bplane);
@@ -552,9 +608,12 @@ struct WlAfbStrip {
         char* ph0 = R.hp0 + (size_t)((unsigned)s.o_lo * R.rowb);
         char* ph1 = R.hp1 + (size_t)((unsigned)s.o_lo * R.rowb);
         char* ph2 = R.hp2 + (size_t)((unsigned)s.o_lo * R.rowb);
-        wl_v2 wa[LW], wb[LW];                                                 // circular windows of the two columns
+        wl_v2 wa[LAT ? 2 : LW], wb[LAT ? 2 : LW];                             // circular windows of the two columns (LAT: the two new rows)
+        wl_v2 SA[KL], SB[KL];                                                 // LAT: delay slots of the two columns' lattices
 #pragma unroll
-        for (int t = 0; t < LW; ++t) wa[t] = wb[t] = wl_v2{0.f, 0.f};
+        for (int t = 0; t < (LAT ? 2 : LW); ++t) wa[t] = wb[t] = wl_v2{0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < KL; ++t) SA[t] = SB[t] = wl_v2{0.f, 0.f};
         char* const smem = ctx.smem;
         int fed = 0;                                                          // feeds done (wave-uniform)
         unsigned long long tbar = 0, tmath = 0;
@@ -582,16 +641,26 @@ struct WlAfbStrip {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         if (i < n) {
-                            const int w0 = (4 * ph + 2 * i) % LW;             // slots of the two new rows
+                            const int w0 = LAT ? 0 : (4 * ph + 2 * i) % LW;   // slots of the two new rows
                             row_pass(R, sr[2 * i], wa[w0], wb[w0]);
                             row_pass(R, sr[2 * i + 1], wa[(w0 + 1) % LW], wb[(w0 + 1) % LW]);
                             if (kPipe && i == 0) { load_row(slot + 2 * a.st_pitch, sr[2]); load_row(slot + 3 * a.st_pitch, sr[3]); }
+                            wl_v2 cla, cha, clb, chb;
+                            if constexpr (LAT != 0) {   // (every feed: the lattice's state; its first K - 1 outputs of a segment are the warm-up)
+                                // the lattice filters the packed (row-lo, row-hi) pair: lo = (ll, hl), hi = (lh, hh); the direct
+                                // form packs the other way round, cl = (ll, lh), ch = (hl, hh): a renaming of registers
+                                wl_v2 loA, hiA, loB, hiB;
+                                lat_feed(R, SA, SB, (2 * ph + i) % KL, wa[0], wa[1], wb[0], wb[1], loA, hiA, loB, hiB);
+                                cla = wl_v2{loA.x, hiA.x}; cha = wl_v2{loA.y, hiA.y};
+                                clb = wl_v2{loB.x, hiB.x}; chb = wl_v2{loB.y, hiB.y};
+                            }
                             if (fed + i >= WARM) {
                                 // the L rows of this output end with the two new ones: the oldest sits LT-1 slots back
                                 const int first = (w0 + 1 + LW - (LT - 1)) % LW;
-                                wl_v2 cla, cha, clb, chb;
-                                col_pass(R, wa, first, cla, cha);
-                                col_pass(R, wb, first, clb, chb);
+                                if constexpr (!LAT) {
+                                    col_pass(R, wa, first, cla, cha);
+                                    col_pass(R, wb, first, clb, chb);
+                                }
                                 if (!(WL_STRIP_ABLATE & 4) || cla.x + clb.y + cha.x + chb.y == 1.2345e30f) {
                                     // (the second feed's row is one further down when the first feed emitted one too)
                                     const unsigned k = (i == 1 && fed >= WARM) ? 1u : 0u;
@@ -630,8 +699,9 @@ struct WlAfbStrip {
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
         const int tid = ctx.tid;
         const int wave = wl_uniform(tid >> 6), lane = tid & 63;
-        if (a.guard) {   // the relation the QMF variant relies on, checked against the taps as they are now (uniform: before any barrier)
-            const bool holds = wl_taps_qmf(a.h_w_lo, a.h_w_hi, LT) && wl_taps_qmf(a.h_h_lo, a.h_h_hi, LT);
+        if (a.guard) {   // the relation the QMF / LAT variant relies on, checked against the taps as they are now (uniform: before any barrier)
+            const bool holds = a.lat ? *reinterpret_cast<const unsigned*>(a.lat) == WL_LAT_OK   // (WlTapPrep's verdict, read by both launches)
+                                     : wl_taps_qmf(a.h_w_lo, a.h_w_hi, LT) && wl_taps_qmf(a.h_h_lo, a.h_h_hi, LT);
             if (!wl_guard_pass(a.guard, holds)) return;
         }
         // workgroup -> (plane, segment, strip): strips of one plane and segment are neighbours on the same XCD (they

@@ -457,6 +457,8 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
 # 2 KiB analysis / 1 KiB synthesis).  Mirrors WL_STRIP_MINW / WL_ISTRIP_MINW of csrc/wl_strip_api.inc.
 STRIP_MINW_F16 = 256
 ISTRIP_MINW_F16 = 0
+TAP_SCRATCH_FLOATS = 16   # WL_TAP_SCRATCH_FLOATS of csrc/wl_lattice.h
+STRIP_LATTICE = True      # hinted strip launches of 12 taps and more run the lattice variant (False: the QMF variant; A/B measurements)
 
 
 def afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=False):
@@ -481,9 +483,13 @@ def afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=False):
     Kh, Kw = coeff_len(H, L, mode), coeff_len(W, L, mode)
     ll = torch.empty((N, C, Kh, Kw), dtype=x.dtype, device=x.device)
     highs = torch.empty((N, C, 3, Kh, Kw), dtype=x.dtype, device=x.device)
+    # device scratch for the lattice variant (csrc/wl_lattice.h): a one-thread kernel leaves its verdict on the banks and the
+    # column lattice there, the lattice kernel and its armed two-bank fallback read it.  (Freed when this call returns: the
+    # allocator hands it out again on this stream only, behind the launches that read it.)
+    scratch = torch.empty(TAP_SCRATCH_FLOATS, dtype=torch.float32, device=x.device) if qmf and L >= 12 and STRIP_LATTICE else None
     rc = _call('wl_dwt2d_analysis_stream', x, x.data_ptr(), x_ps, x_rs, ll.data_ptr(), Kh * Kw, Kw, highs.data_ptr(),
                _DTYPES[x.dtype], N * C, H, W, hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(), hhh.data_ptr(), L, mode,
-               (1 if force else 0) | (2 if qmf else 0), _stream(x))
+               (1 if force else 0) | (2 if qmf else 0), None if scratch is None else scratch.data_ptr(), _stream(x))
     if rc == -3:
         _remember_decline(key)
         return None

@@ -1,0 +1,128 @@
+"""The lattice variant of the analysis strip kernel (csrc/wl_lattice.h, WlAfbStrip<.., QMF = 1, LAT = 1>): the column pass as
+K = L/2 plane rotations whose coefficients a one-thread kernel derives on the device from the column bank as it is at call
+time, accepted only if they reproduce that bank.  Every case against the ORACLE on the taps the module holds.
+Shared by the emulator tests (device 'cpu' under emu_backend.emulated()) and the -m gpu tests."""
+import numpy as np
+import torch
+
+import pytorch_wavelets_amd as pw
+from oracle import wavelet_oracle as wo
+from pytorch_wavelets_amd import filters as F
+
+
+def _flat(b):
+    return b.detach().cpu().double().numpy().ravel()
+
+
+def _rel(a, b):
+    a = a.detach().cpu().double().numpy()
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _is_lattice(name):
+    if 'WlAfbStrip<' not in name:
+        return False
+    args = [a.strip() for a in name[name.index('<') + 1:name.rindex('>')].split(',')]   # <T, L, QMF = 0, LAT = 0>
+    return len(args) >= 4 and args[3] == '1'
+
+
+def _run(xfm, x, mode, tol, what, want_lattice=True):
+    c0 = pw.launch_count()
+    yl, yh = xfm(x)
+    ks = pw.kernels_since(c0)
+    if want_lattice:   # the examination of the banks, the lattice kernel, its armed two-bank fallback
+        assert len(ks) == 3 and ks[0].startswith('WlTapPrep') and _is_lattice(ks[1]) and ks[2].endswith('(armed fallback)'), (what, ks)
+    oyl, oyh = wo.dwt_forward(x.detach().cpu().double().numpy(), 1, _flat(xfm.h0_col), _flat(xfm.h1_col),
+                              _flat(xfm.h0_row), _flat(xfm.h1_row), mode)
+    e = max(_rel(yl, oyl), _rel(yh[0], oyh[0]))
+    assert e <= tol, (what, e)
+    return e
+
+
+LATTICE_WAVES = [('db6', 'symmetric'), ('db7', 'zero'), ('db8', 'periodization'), ('sym8', 'reflect'), ('db10', 'periodic'),
+                 ('coif3', 'symmetric'), ('coif2', 'periodization'), ('sym6', 'zero'), ('db9', 'symmetric')]
+
+
+def check_lattice_vs_oracle(dev, wave, mode, shape=(2, 2, 72, 288), dtype=torch.float32):
+    """One analysis level of a long orthogonal filter on the (forced) strip kernel: the lattice variant, float32: 1e-5 of the
+    largest coefficient (measured 2-3e-7: as accurate as the direct sum)."""
+    from pytorch_wavelets_amd import ops
+    from pytorch_wavelets_amd.dwt import lowlevel as _ll
+    rng = np.random.RandomState(29)
+    prev = ops.STREAM_FORCE, _ll.FUSED_LEVELS
+    ops.STREAM_FORCE, _ll.FUSED_LEVELS = True, False
+    try:
+        x = torch.tensor(rng.randn(*shape), dtype=dtype, device=dev)
+        xfm = pw.DWTForward(J=1, wave=wave, mode=mode).to(dev).to(dtype)
+        return _run(xfm, x, mode, 1e-5 if dtype == torch.float32 else 3e-3, (wave, mode))
+    finally:
+        ops.STREAM_FORCE, _ll.FUSED_LEVELS = prev
+
+
+def check_lattice_rejections(dev, dtype=torch.float32, shape=(1, 2, 64, 288), tol=1e-5):
+    """Banks the host's quadrature-mirror hint passes but that are no orthogonal pair (or not the pair the device finds when the
+    kernel runs): the one-thread examination rejects them and the armed two-bank variant does the work - equal to the oracle
+    on the taps in the buffers."""
+    from pytorch_wavelets_amd import ops
+    from pytorch_wavelets_amd.dwt import lowlevel as _ll
+    rng = np.random.RandomState(31)
+    prev = ops.STREAM_FORCE, _ll.FUSED_LEVELS
+    ops.STREAM_FORCE, _ll.FUSED_LEVELS = True, False
+    try:
+        x = torch.tensor(rng.randn(*shape), dtype=dtype, device=dev)
+        L = 16
+        sign = np.array([1.0, -1.0] * (L // 2))
+        # 1. a random lowpass with its exact mirror as highpass: QMF holds (the hint is given), the pair is not orthogonal
+        lo = rng.randn(L)
+        hi = sign * lo[::-1]
+        # (the constructor reverses what it is given: hand it the reversed pair so that the STORED pair is (lo, hi))
+        xfm = pw.DWTForward(J=1, wave=(lo[::-1].copy(), hi[::-1].copy()), mode='symmetric').to(dev).to(dtype)
+        assert ops.is_qmf_pair(xfm.h0_col, xfm.h1_col), 'the test wants a mirror pair in the buffers'
+        _run(xfm, x, 'symmetric', tol, 'random mirror pair')
+        # 2. db8 with its lowpass (and, mirrored, its highpass) perturbed by 1e-3: still a mirror pair, orthogonal to 1e-3 only
+        h0, h1 = (np.asarray(v, dtype=np.float64) for v in F.dwt_analysis_taps('db8'))
+        dec_lo = h0[::-1].copy()
+        dec_lo[3] += 1e-3
+        stored_lo = dec_lo[::-1]
+        stored_hi = sign * stored_lo[::-1]
+        xfm = pw.DWTForward(J=1, wave=(dec_lo, stored_hi[::-1].copy()), mode='periodization').to(dev).to(dtype)
+        assert ops.is_qmf_pair(xfm.h0_col, xfm.h1_col)
+        _run(xfm, x, 'periodization', tol, 'db8 perturbed by 1e-3')
+        # 3. the column bank edited through `.data` AFTER a lattice launch (invisible to the host's cache key)
+        xfm = pw.DWTForward(J=1, wave='db8', mode='symmetric').to(dev).to(dtype)
+        _run(xfm, x, 'symmetric', tol, 'pristine db8')
+        xfm.h0_col.data[0, 0, 5, 0] += 0.25
+        _run(xfm, x, 'symmetric', tol, 'h0_col.data[...] +=')
+        xfm = pw.DWTForward(J=1, wave='db8', mode='symmetric').to(dev).to(dtype)
+        _run(xfm, x, 'symmetric', tol, 'pristine db8 (2)')
+        xfm.h1_row.data.mul_(-1.0)
+        _run(xfm, x, 'symmetric', tol, 'h1_row.data.mul_(-1)')
+        # 4. NaN taps: rejected, and the two-bank variant propagates them like the reference would
+        xfm = pw.DWTForward(J=1, wave='db8', mode='symmetric').to(dev).to(dtype)
+        xfm.h0_col.data[0, 0, 2, 0] = float('nan')
+        yl, yh = xfm(x)
+        assert bool(torch.isnan(yl).any())
+    finally:
+        ops.STREAM_FORCE, _ll.FUSED_LEVELS = prev
+
+
+def check_lattice_float16_module(dev, shape=(1, 2, 64, 2048)):
+    """BASELINE configs[4]'s geometry at one level: a `.half()` module holds float16-ROUNDED taps, no exact orthogonal pair any
+    more.  The lattice is accepted to a quarter unit in the last place of the storage type and computes the orthogonal bank
+    nearest to the rounded taps: against the oracle on the rounded taps AND against the oracle on the float32 table (the
+    reference's expected value, oracle/pin_fp16_config5.py) within the float16 tolerance of the suite."""
+    from pytorch_wavelets_amd import ops
+    from pytorch_wavelets_amd.dwt import lowlevel as _ll
+    rng = np.random.RandomState(37)
+    prev = ops.STREAM_FORCE, _ll.FUSED_LEVELS
+    ops.STREAM_FORCE, _ll.FUSED_LEVELS = True, False
+    try:
+        x = torch.tensor(rng.randn(*shape), device=dev).half()
+        xfm = pw.DWTForward(J=1, wave='db8', mode='periodization').to(dev).half()
+        _run(xfm, x, 'periodization', 2e-3, 'float16 module, rounded taps')
+        yl, yh = xfm(x)
+        h0, h1 = F.dwt_analysis_taps('db8')
+        oyl, oyh = wo.dwt_forward(x.detach().cpu().double().numpy(), 1, h0, h1, h0, h1, 'periodization')
+        assert _rel(yl, oyl) <= 2e-3 and _rel(yh[0], oyh[0]) <= 2e-3, (_rel(yl, oyl), _rel(yh[0], oyh[0]))
+    finally:
+        ops.STREAM_FORCE, _ll.FUSED_LEVELS = prev

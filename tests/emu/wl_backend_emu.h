@@ -208,3 +208,9 @@ template <typename K>
 static int wl_launch_armed(const typename K::Args& a, int64_t nblocks, size_t lds, void* stream) {
     return wl_launch_named<K>(a, nblocks, lds, stream, __PRETTY_FUNCTION__, false);
 }
+// A helper launch in front of the kernel the engine chose (WlTapPrep: one thread that examines the filter banks): in
+// wl_kernel_history under this function's name, not in wl_last_kernel.
+template <typename K>
+static int wl_launch_aux(const typename K::Args& a, int64_t nblocks, size_t lds, void* stream) {
+    return wl_launch_named<K>(a, nblocks, lds, stream, __PRETTY_FUNCTION__, false);
+}

@@ -856,3 +856,24 @@ def test_filter_buffers_changed_after_construction_dwt_forward(wave, mode):
             M.check_dwt_forward_mutations('cpu', wave=wave, mode=mode, shape=(1, 2, 64, 288), tol=3e-6)
     finally:
         torch.set_default_dtype(prev)
+
+
+@pytest.mark.parametrize('wave,mode', __import__('_lattice_cases').LATTICE_WAVES)
+def test_lattice_variant_of_the_analysis_strip_kernel(wave, mode):
+    """csrc/wl_lattice.h: the column pass of the long-filter strip kernel as K = L/2 plane rotations, factored on the device
+    from the taps as they are at call time - against the oracle, 12-20 taps, every extension mode."""
+    import _lattice_cases as LC
+    with emu_backend.emulated():
+        LC.check_lattice_vs_oracle('cpu', wave, mode)
+
+
+def test_lattice_variant_rejects_banks_it_cannot_reproduce():
+    import _lattice_cases as LC
+    with emu_backend.emulated():
+        LC.check_lattice_rejections('cpu')
+
+
+def test_lattice_variant_float16_module():
+    import _lattice_cases as LC
+    with emu_backend.emulated():
+        LC.check_lattice_float16_module('cpu', shape=(1, 1, 48, 2048))

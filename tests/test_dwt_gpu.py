@@ -820,3 +820,27 @@ def test_streaming_kernels_several_planes_per_workgroup_gpu(shape, wave, mode, J
     orec = wo.dwt_inverse(oyl, oyh, g0, g1, g0, g1, mode)
     got = s0[-1:, -3:].double().cpu().numpy()
     assert got.shape == orec.shape and float(np.abs(got - orec).max()) <= (8e-3 if dtype == torch.float16 else 1e-5) * float(np.abs(orec).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('wave,mode', __import__('_lattice_cases').LATTICE_WAVES)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_lattice_variant_of_the_analysis_strip_kernel(wave, mode, dtype):
+    """csrc/wl_lattice.h on the GPU: the lattice column pass (coefficients factored on the device from the taps at call time)
+    against the oracle on the module's taps, 12-20 taps, every extension mode, float32 and float16 storage."""
+    import _lattice_cases as LC
+    # (float16-rounded db10 taps are further from an orthogonal pair than the device's acceptance test allows: there the armed
+    # two-bank variant does the work - the result must be right either way)
+    LC.check_lattice_vs_oracle(DEV, wave, mode, shape=(3, 2, 136, 1032), dtype=dtype)
+
+
+@pytest.mark.gpu
+def test_lattice_variant_rejects_banks_it_cannot_reproduce():
+    import _lattice_cases as LC
+    LC.check_lattice_rejections(DEV, shape=(2, 2, 96, 1040))
+
+
+@pytest.mark.gpu
+def test_lattice_variant_float16_module():
+    import _lattice_cases as LC
+    LC.check_lattice_float16_module(DEV, shape=(2, 3, 256, 2048))
