@@ -254,11 +254,13 @@ int wl_dwt2d_analysis_stream(const void* x, int64_t x_plane_stride, int x_row_st
  * the quadrature mirror of its lowpass bank, g_hi[t] = (-1)^t g_lo[L-1-t] (the reconstruction pair of every orthogonal
  * wavelet): from 12 taps on the hinted kernel variant derives the highpass tap pairs from the lowpass ones by operand modifiers
  * instead of holding both banks in scalar registers (same arithmetic, same results) after verifying the relation on the device;
- * the two-bank variant stands by behind it as for the analysis.  Returns WL_ERR_UNSUPPORTED outside its envelope. */
+ * the two-bank variant stands by behind it as for the analysis.  tap_scratch as for wl_dwt2d_analysis_stream (NULL, or
+ * WL_TAP_SCRATCH_BYTES of device memory: the hinted variant is then the lattice kernel, from 12 taps on, 14 included).
+ * Returns WL_ERR_UNSUPPORTED outside its envelope. */
 int wl_dwt2d_synthesis_stream(const void* ll, int64_t ll_plane_stride, int ll_row_stride, const void* highs, void* y,
                               int dtype, int64_t planes, int Kh, int Kw, int OH, int OW, const void* g_w_lo,
                               const void* g_w_hi, const void* g_h_lo, const void* g_h_hi, int L, int mode, int policy,
-                              void* stream);
+                              void* tap_scratch, void* stream);
 
 /* Gradients of the two non-separable banks, as autograd gives them upstream (where afb2d_nonsep / sfb2d_nonsep are
  * plain differentiable ATen chains, dwt/lowlevel.py:524-597, :746-798):

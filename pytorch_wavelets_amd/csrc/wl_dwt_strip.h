@@ -488,20 +488,7 @@ struct WlAfbStrip {
 #endif
         return r;
     }
-    // d = w * (c, c) + z, c = the low (HI = 0) / high (HI = 1) half of a scalar-register pair; NZ: - z instead of + z
-    template <int HI, int NZ> static WL_DEV wl_v2 fma_s(wl_v2 w, wl_v2 pair, wl_v2 z) {
-        wl_v2 d;
-#if defined(__HIPCC__)
-        if (!HI && !NZ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(w), "s"(pair), "v"(z));
-        else if (HI && !NZ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(w), "s"(pair), "v"(z));
-        else if (!HI && NZ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(w), "s"(pair), "v"(z));
-        else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(w), "s"(pair), "v"(z));
-#else
-        const float c = HI ? pair.y : pair.x;
-        d.x = __builtin_fmaf(w.x, c, NZ ? -z.x : z.x); d.y = __builtin_fmaf(w.y, c, NZ ? -z.y : z.y);
-#endif
-        return d;
-    }
+    template <int HI, int NZ> static WL_DEV wl_v2 fma_s(wl_v2 w, wl_v2 pair, wl_v2 z) { return wl_fma_s<HI, NZ>(w, pair, z); }
     struct Wave {
         wl_v2 tw[NB], th[NB];             // (lo,hi) tap pairs along W / along H (wave-uniform: scalar registers); QMF: P[u] = (lo[u], lo[L-1-u])
         wl_v2 lt[LAT ? KL : 1];           // LAT: (T_k, -T_k) of the column lattice (the row taps carry its gain g)

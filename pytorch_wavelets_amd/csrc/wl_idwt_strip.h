@@ -25,6 +25,7 @@
 #include "wl_common.h"
 #include "wl_dwt_rows.h"   // wl_pk_fma_x / _y, wl_pk_mul_x / _y, wl_uniform_v2
 #include "wl_dwt_strip.h"  // WlStage, WL_STRIP_* geometry constants
+#include "wl_lattice.h"
 
 template <typename T>
 struct WlIStripArgs {
@@ -48,15 +49,21 @@ struct WlIStripArgs {
     int quad_ok;                   // every lane's 4 output columns are one aligned store (OW % 4 == 0, aligned y)
     int guard;                     // tap-relation guard (wl_common.h): 1 = run only if both highpass banks are the quadrature mirrors of
                                    // their lowpass banks (the QMF variant), 2 = only if not (its armed two-bank fallback), 0 = no check
+    const float* lat;              // LAT variant and its fallback: WlTapPrep's verdict + the column lattice in device scratch (wl_lattice.h);
+                                   // the guard then reads the verdict word instead of the taps
 };
 
 // QMF = 1: the caller vouches that each highpass bank is the quadrature mirror of its lowpass bank, g1[t] = (-1)^t g0[L-1-t]
 // (every orthogonal wavelet as pywt / the reference tabulates its RECONSTRUCTION pair): the highpass tap pairs are then the
 // lowpass pairs read backwards with the halves swapped and one half negated - operand modifiers of the packed FMA - and never
 // occupy scalar registers (68 of them at 16 taps: the scalar file overflowed, 32 v_readlane per half-batch).
-template <typename T, int LT, int SODD, int QMF = 0>
+// LAT = 1 (with QMF = 1): the COLUMN synthesis runs the orthogonal bank as a lattice of rotations (wl_lattice.h, the transposed
+// recurrence): per coefficient row and column pair 2 K packed FMAs and K - 1 delayed values instead of 2 L FMAs and two L/2-row
+// windows (16 taps: 64 of the 128 FMAs of a feed are column FMAs, 32 of them go).
+template <typename T, int LT, int SODD, int QMF = 0, int LAT = 0>
 struct WlSfbStrip {
     typedef WlIStripArgs<T> Args;
+    static_assert(!LAT || QMF, "the lattice variant runs its row synthesis in the QMF form");
     static const int kWaves = WL_STRIP_CWAVES + 4;
     static const int kThreads = 64 * kWaves;
     static const int kMinWaves = LT >= 18 ? 3 : 4;
@@ -66,7 +73,7 @@ struct WlSfbStrip {
     static const int NT = HL + SODD;       // tap pairs of the row synthesis
     static const int NC2 = (NT + 1 + 1) / 2;   // 8-byte words a lane reads per source row: its NT + 1 coefficients
     static const int LW = (HL + 1) / 2 * 2;    // window slots: a multiple of the 2 rows of a half-batch
-    static const int PERIOD = LW / 2;
+    static const int PERIOD = LAT ? (HL % 2 ? HL : HL / 2) : LW / 2;   // (lattice: HL delay slots, two feeds per half-batch)
     static const int D = WL_STRIP_D;
 
     struct Strip {
@@ -259,7 +266,29 @@ struct WlSfbStrip {
     struct Wave {
         wl_v2 twl[NT], twh[QMF ? 1 : NT];    // row-synthesis tap pairs of the W-low / W-high bank (shifted by one for SODD)
         wl_v2 ghl[HL], ghh[QMF ? 1 : HL];    // (g[2t], g[2t+1]) of the H-low / H-high bank
+        wl_v2 lt[LAT ? HL : 1];              // LAT: (T_k, -T_k) of the column lattice (the row taps carry its gain g)
     };
+    // One feed of the column lattice for both column pairs of the lane (wl_lattice.h, the synthesis recurrence): (a, b) = the
+    // row-synthesised lowpass / highpass coefficient row -> (P, Q) = output rows (2m, 2m+1), each packed over the pair's two
+    // columns.  Stage k leaves its q in delay slot (k + f) mod K at feed f - the slot stage k - 1 reads one feed later and
+    // overwrites in place: nothing is ever moved (`rot` = f mod K is compile-time after unrolling).
+    static WL_DEV void lat_feed(const Wave& R, wl_v2 (&SA)[HL], wl_v2 (&SB)[HL], int rot, wl_v2 aA, wl_v2 bA, wl_v2 aB, wl_v2 bB,
+                                wl_v2& PA, wl_v2& QA, wl_v2& PB, wl_v2& QB) {
+        wl_v2 qA = wl_fma_s<0, 1>(aA, R.lt[HL - 1], bA), qB = wl_fma_s<0, 1>(aB, R.lt[HL - 1], bB);   // T a - b
+        wl_v2 pA = wl_fma_s<0, 0>(bA, R.lt[HL - 1], aA), pB = wl_fma_s<0, 0>(bB, R.lt[HL - 1], aB);   // a + T b
+        if (HL == 1) { PA = pA; PB = pB; QA = qA; QB = qB; return; }
+        SA[(HL - 1 + rot) % HL] = qA; SB[(HL - 1 + rot) % HL] = qB;
+#pragma unroll
+        for (int k = HL - 1; k >= 1; --k) {
+            const int slot = (k - 1 + rot) % HL;
+            const wl_v2 dA = SA[slot], dB = SB[slot];
+            const wl_v2 nA = wl_fma_s<1, 0>(dA, R.lt[k - 1], pA), nB = wl_fma_s<1, 0>(dB, R.lt[k - 1], pB);   // p - T q'
+            qA = wl_fma_s<0, 0>(pA, R.lt[k - 1], dA); qB = wl_fma_s<0, 0>(pB, R.lt[k - 1], dB);             // q' + T p
+            if (k > 1) { SA[slot] = qA; SB[slot] = qB; }
+            pA = nA; pB = nB;
+        }
+        PA = pA; PB = pB; QA = qA; QB = qB;
+    }
     // acc += q(pair) * s.x / s.y, q(pair) = (pair.y, pair.x) with one half negated: NEGLO -> (-pair.y, pair.x), else (pair.y, -pair.x)
     template <int Y, int NEGLO> static WL_DEV void fma_q(wl_v2& acc, wl_v2 pair, wl_v2 sv) {
 #if defined(__HIPCC__)
@@ -343,6 +372,7 @@ struct WlSfbStrip {
         const int u = s.u0 + 64 * cw + lane;                  // lane unit: output columns 4u .. 4u+3
         const bool active = u < s.u1;
         Wave R;
+        const float gsc = LAT ? a.lat[1] : 1.f;               // the lattice's gain rides on the row-synthesis taps
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             // SODD: pairs (g[2j-1], g[2j]) with g[-1] = g[L] = 0
@@ -351,12 +381,16 @@ struct WlSfbStrip {
             const float l1 = i1 >= 0 && i1 < LT ? a.g_w_lo[i1 >= 0 && i1 < LT ? i1 : 0] : 0.f;
             const float h0 = i0 >= 0 && i0 < LT ? a.g_w_hi[i0 >= 0 && i0 < LT ? i0 : 0] : 0.f;
             const float h1 = i1 >= 0 && i1 < LT ? a.g_w_hi[i1 >= 0 && i1 < LT ? i1 : 0] : 0.f;
-            R.twl[j] = wl_uniform_v2(wl_v2{l0, l1});
+            R.twl[j] = wl_uniform_v2(wl_v2{l0 * gsc, l1 * gsc});
             if (!QMF) R.twh[QMF ? 0 : j] = wl_uniform_v2(wl_v2{h0, h1});
+        }
+        if (LAT) {
+#pragma unroll
+            for (int k = 0; k < HL; ++k) R.lt[LAT ? k : 0] = wl_uniform_v2(wl_v2{a.lat[2 + k], -a.lat[2 + k]});
         }
 #pragma unroll
         for (int t = 0; t < HL; ++t) {
-            R.ghl[t] = wl_uniform_v2(wl_v2{a.g_h_lo[2 * t], a.g_h_lo[2 * t + 1]});
+            if (!LAT) R.ghl[t] = wl_uniform_v2(wl_v2{a.g_h_lo[2 * t], a.g_h_lo[2 * t + 1]});
             if (!QMF) R.ghh[QMF ? 0 : t] = wl_uniform_v2(wl_v2{a.g_h_hi[2 * t], a.g_h_hi[2 * t + 1]});
         }
         char* const yp = reinterpret_cast<char*>(a.y + (size_t)plane * a.OH * a.OW);
@@ -365,9 +399,13 @@ struct WlSfbStrip {
         const int ncols = active ? (a.OW - 4 * u < 4 ? a.OW - 4 * u : 4) : 0;   // columns of this lane inside the output
         const int soff = s.lane_off + 8 * (active ? u - s.u0 : 0);
         const int N2 = 2 * a.Kh;
-        wl_v2 waA[LW], wbA[LW], waB[LW], wbB[LW];              // circular windows: (a, b) of the two pairs
+        static const int NW = LAT ? 1 : LW;
+        wl_v2 waA[NW], wbA[NW], waB[NW], wbB[NW];              // circular windows: (a, b) of the two pairs (LAT: the new row only)
+        wl_v2 SA[HL], SB[HL];                                  // LAT: delay slots of the two pairs' lattices
 #pragma unroll
-        for (int t = 0; t < LW; ++t) waA[t] = wbA[t] = waB[t] = wbB[t] = wl_v2{0.f, 0.f};
+        for (int t = 0; t < NW; ++t) waA[t] = wbA[t] = waB[t] = wbB[t] = wl_v2{0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < HL; ++t) SA[t] = SB[t] = wl_v2{0.f, 0.f};
         char* const smem = ctx.smem;
         int fed = 0;
         for (int hb0 = 0; hb0 < s.nhb; hb0 += PERIOD) {
@@ -388,13 +426,23 @@ struct WlSfbStrip {
                             load_row(slot + (2 + i) * a.st_pitch, clh);
                             load_row(slot + (4 + i) * a.st_pitch, chl);
                             load_row(slot + (6 + i) * a.st_pitch, chh);
-                            const int w = (2 * ph + i) % LW;
+                            const int w = LAT ? 0 : (2 * ph + i) % LW;
                             waA[w] = row_syn<0>(R, cll, chl); wbA[w] = row_syn<0>(R, clh, chh);
                             waB[w] = row_syn<1>(R, cll, chl); wbB[w] = row_syn<1>(R, clh, chh);
+                            wl_v2 y0A, y1A, y0B, y1B;
+                            if constexpr (LAT != 0) {   // (every feed: the lattice's state; the first K - 1 outputs of a segment are the warm-up)
+                                // the lattice delivers (row 2m, row 2m+1), each packed over the pair's two columns; the direct form
+                                // packs the other way round, y0 = (row 2m, row 2m+1) of the even column: a renaming of registers
+                                wl_v2 PA, QA, PB, QB;
+                                lat_feed(R, SA, SB, (2 * ph + i) % HL, waA[0], wbA[0], waB[0], wbB[0], PA, QA, PB, QB);
+                                y0A = wl_v2{PA.x, QA.x}; y1A = wl_v2{PA.y, QA.y};
+                                y0B = wl_v2{PB.x, QB.x}; y1B = wl_v2{PB.y, QB.y};
+                            }
                             if (fed + i >= HL - 1) {
-                                wl_v2 y0A, y1A, y0B, y1B;
-                                col_syn(R, waA, wbA, w, y0A, y1A);
-                                col_syn(R, waB, wbB, w, y0B, y1B);
+                                if constexpr (!LAT) {
+                                    col_syn(R, waA, wbA, w, y0A, y1A);
+                                    col_syn(R, waB, wbB, w, y0B, y1B);
+                                }
                                 // z-rows 2m, 2m+1 of feed m -> output rows 2m - sh (+1), rolled under periodization
                                 const int m = s.e_first + fed + i;
                                 int p0 = 2 * m - a.sh, p1 = p0 + 1;
@@ -427,8 +475,9 @@ struct WlSfbStrip {
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
         const int tid = ctx.tid;
         const int wave = wl_uniform(tid >> 6), lane = tid & 63;
-        if (a.guard) {   // the relation the QMF variant relies on, checked against the taps as they are now (uniform: before any barrier)
-            const bool holds = wl_taps_qmf(a.g_w_lo, a.g_w_hi, LT) && wl_taps_qmf(a.g_h_lo, a.g_h_hi, LT);
+        if (a.guard) {   // the relation the QMF / LAT variant relies on, checked against the taps as they are now (uniform: before any barrier)
+            const bool holds = a.lat ? *reinterpret_cast<const unsigned*>(a.lat) == WL_LAT_OK   // (WlTapPrep's verdict, read by both launches)
+                                     : wl_taps_qmf(a.g_w_lo, a.g_w_hi, LT) && wl_taps_qmf(a.g_h_lo, a.g_h_hi, LT);
             if (!wl_guard_pass(a.guard, holds)) return;
         }
         const int64_t lbid = wl_xcd_remap(ctx.bid, a.nblocks);

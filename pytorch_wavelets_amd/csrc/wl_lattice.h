@@ -32,15 +32,23 @@
 #define WL_TAP_SCRATCH_FLOATS 16       // device scratch of a lattice launch: [0] verdict, [1] g, [2 .. 2 + K) T_k
 #define WL_LAT_OK 0x4c415431u          // verdict word of an accepted factorisation
 
-// lo / hi: the L stored taps of one axis.  true: *g and T[0 .. L/2) hold the recurrence above.
-WL_HD bool wl_lattice_factor(const float* lo, const float* hi, int L, double tol, float* g, float* T) {
+// The SYNTHESIS bank of the same wavelet, as the synthesis kernels evaluate it (reference dwt/lowlevel.py:226-271): the output row
+// pair of feed m is  (z[2m], z[2m+1]) = sum_{t < K} (g0[2t], g0[2t+1]) a[m-t] + (g1[2t], g1[2t+1]) b[m-t]  (a / b = the lowpass /
+// highpass coefficient rows), the polynomial matrix R(z) whose TRANSPOSE F(z) = sum_t [[g0[2t], g0[2t+1]], [g1[2t], g1[2t+1]]] z^-t
+// factors exactly like E(z) above (`syn` = true builds F's coefficients).  Transposing the product reverses it:
+//     (p, q) = (a, -b);   for k = K-1 .. 1:  (p, q) <- (p - T_k q, q + T_k p),  q <- q one feed ago;
+//     (z[2m], z[2m+1]) = g (p - T_0 q, q + T_0 p)                                  (g again folded into the row synthesis' taps)
+//
+// lo / hi: the L stored taps of one axis.  true: *g and T[0 .. L/2) hold the recurrence.
+WL_HD bool wl_lattice_factor(const float* lo, const float* hi, int L, double tol, float* g, float* T, bool syn = false) {
     const int K = L / 2;
     if (L < 4 || (L & 1) || K > WL_LAT_MAXK) return false;
     double E[WL_LAT_MAXK][2][2], n0[WL_LAT_MAXK][2], n1[WL_LAT_MAXK][2], Td[WL_LAT_MAXK];
     double scale = 0.0;
     for (int i = 0; i < K; ++i) {
-        E[i][0][0] = lo[L - 2 - 2 * i]; E[i][0][1] = lo[L - 1 - 2 * i];
-        E[i][1][0] = hi[L - 2 - 2 * i]; E[i][1][1] = hi[L - 1 - 2 * i];
+        const int e = syn ? 2 * i : L - 2 - 2 * i;
+        E[i][0][0] = lo[e]; E[i][0][1] = lo[e + 1];
+        E[i][1][0] = hi[e]; E[i][1][1] = hi[e + 1];
     }
     for (int t = 0; t < L; ++t) {
         const double a = lo[t] < 0 ? -(double)lo[t] : (double)lo[t], b = hi[t] < 0 ? -(double)hi[t] : (double)hi[t];
@@ -89,6 +97,21 @@ WL_HD bool wl_lattice_factor(const float* lo, const float* hi, int L, double tol
     return ab(gain) > 1e-30;
 }
 
+// d = w * (c, c) + z, c = the low (HI = 0) / high (HI = 1) half of a scalar-register pair; NZ: - z instead of + z
+template <int HI, int NZ> WL_DEV wl_v2 wl_fma_s(wl_v2 w, wl_v2 pair, wl_v2 z) {
+    wl_v2 d;
+#if defined(__HIPCC__)
+    if (!HI && !NZ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(w), "s"(pair), "v"(z));
+    else if (HI && !NZ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(w), "s"(pair), "v"(z));
+    else if (!HI && NZ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(w), "s"(pair), "v"(z));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(w), "s"(pair), "v"(z));
+#else
+    const float c = HI ? pair.y : pair.x;
+    d.x = __builtin_fmaf(w.x, c, NZ ? -z.x : z.x); d.y = __builtin_fmaf(w.y, c, NZ ? -z.y : z.y);
+#endif
+    return d;
+}
+
 // ---- the one-thread kernel in front of a lattice launch ---------------------------------------------------------------
 // Verdict + factorisation of the COLUMN bank (h_h_*) into `out` (WL_TAP_SCRATCH_FLOATS floats of device memory the caller
 // owns for the duration of the launches that read it): accepted iff both highpass banks are the quadrature mirrors of their
@@ -98,6 +121,7 @@ struct WlTapPrepArgs {
     float* out;
     int L;
     float tol;
+    int syn;               // the banks are a synthesis pair (WlSfbStrip) / an analysis pair (WlAfbStrip)
 };
 struct WlTapPrep {
     typedef WlTapPrepArgs Args;
@@ -108,7 +132,7 @@ struct WlTapPrep {
         float g = 0.f, T[WL_LAT_MAXK];
         for (int k = 0; k < WL_LAT_MAXK; ++k) T[k] = 0.f;
         bool ok = wl_taps_qmf(a.h_w_lo, a.h_w_hi, a.L) && wl_taps_qmf(a.h_h_lo, a.h_h_hi, a.L);
-        ok = ok && wl_lattice_factor(a.h_h_lo, a.h_h_hi, a.L, (double)a.tol, &g, T);
+        ok = ok && wl_lattice_factor(a.h_h_lo, a.h_h_hi, a.L, (double)a.tol, &g, T, a.syn != 0);
         unsigned* flag = reinterpret_cast<unsigned*>(a.out);
         a.out[1] = g;
         for (int k = 0; k < WL_LAT_MAXK; ++k) a.out[2 + k] = T[k];

@@ -526,9 +526,11 @@ def sfb2d_stream(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None, f
         return None
     gwl, gwh, ghl, ghh = (_taps(g, ll) for g in (g_w_lo, g_w_hi, g_h_lo, g_h_hi))
     y = torch.empty((N, C, OH, OW), dtype=ll.dtype, device=ll.device)
+    # (device scratch for the lattice variant: see afb2d_stream)
+    scratch = torch.empty(TAP_SCRATCH_FLOATS, dtype=torch.float32, device=ll.device) if qmf and L >= 12 and STRIP_LATTICE else None
     rc = _call('wl_dwt2d_synthesis_stream', ll, ll.data_ptr(), ll_ps, ll_rs, highs.data_ptr(), y.data_ptr(), _DTYPES[ll.dtype],
                N * C, Kh, Kw, OH, OW, gwl.data_ptr(), gwh.data_ptr(), ghl.data_ptr(), ghh.data_ptr(), L, mode,
-               (1 if force else 0) | (2 if qmf else 0), _stream(ll))
+               (1 if force else 0) | (2 if qmf else 0), None if scratch is None else scratch.data_ptr(), _stream(ll))
     if rc == -3:
         _remember_decline(key)
         return None

@@ -126,3 +126,72 @@ def check_lattice_float16_module(dev, shape=(1, 2, 64, 2048)):
         assert _rel(yl, oyl) <= 2e-3 and _rel(yh[0], oyh[0]) <= 2e-3, (_rel(yl, oyl), _rel(yh[0], oyh[0]))
     finally:
         ops.STREAM_FORCE, _ll.FUSED_LEVELS = prev
+
+
+def _is_lattice_syn(name):
+    if 'WlSfbStrip<' not in name:
+        return False
+    args = [a.strip() for a in name[name.index('<') + 1:name.rindex('>')].split(',')]   # <T, L, SODD, QMF = 0, LAT = 0>
+    return len(args) >= 5 and args[4] == '1'
+
+
+def _run_inv(ifm, yl, yh, mode, tol, what):
+    c0 = pw.launch_count()
+    r = ifm((yl, yh))
+    ks = pw.kernels_since(c0)
+    assert len(ks) == 3 and ks[0].startswith('WlTapPrep') and _is_lattice_syn(ks[1]) and ks[2].endswith('(armed fallback)'), (what, ks)
+    want = wo.dwt_inverse(yl.detach().cpu().double().numpy(), [h.detach().cpu().double().numpy() for h in yh],
+                          _flat(ifm.g0_col), _flat(ifm.g1_col), _flat(ifm.g0_row), _flat(ifm.g1_row), mode)
+    e = _rel(r, want)
+    assert e <= tol, (what, e)
+    return e
+
+
+def check_lattice_inverse_vs_oracle(dev, wave, mode, shape=(2, 2, 72, 288), dtype=torch.float32):
+    """One synthesis level of a long orthogonal filter on the (forced) strip kernel: the lattice variant (the transposed
+    recurrence), against the oracle on the module's taps."""
+    from pytorch_wavelets_amd import ops
+    from pytorch_wavelets_amd.dwt import lowlevel as _ll
+    rng = np.random.RandomState(41)
+    prev = ops.STREAM_FORCE, _ll.FUSED_LEVELS
+    ops.STREAM_FORCE, _ll.FUSED_LEVELS = True, False
+    try:
+        h0, h1 = F.dwt_analysis_taps(wave)
+        oyl, oyh = wo.dwt_forward(rng.randn(*shape), 1, h0, h1, h0, h1, mode)
+        yl = torch.tensor(oyl, dtype=dtype, device=dev)
+        yh = [torch.tensor(v, dtype=dtype, device=dev) for v in oyh]
+        ifm = pw.DWTInverse(wave=wave, mode=mode).to(dev).to(dtype)
+        return _run_inv(ifm, yl, yh, mode, 1e-5 if dtype == torch.float32 else 3e-3, (wave, mode))
+    finally:
+        ops.STREAM_FORCE, _ll.FUSED_LEVELS = prev
+
+
+def check_lattice_inverse_rejections(dev, dtype=torch.float32, shape=(1, 2, 64, 288), tol=1e-5):
+    """Synthesis banks that pass the host's mirror-pair hint but are no orthogonal pair, or were edited through `.data`: the
+    device rejects the lattice, the armed two-bank variant does the work - equal to the oracle on the taps in the buffers."""
+    from pytorch_wavelets_amd import ops
+    from pytorch_wavelets_amd.dwt import lowlevel as _ll
+    rng = np.random.RandomState(43)
+    prev = ops.STREAM_FORCE, _ll.FUSED_LEVELS
+    ops.STREAM_FORCE, _ll.FUSED_LEVELS = True, False
+    try:
+        h0, h1 = F.dwt_analysis_taps('db8')
+        oyl, oyh = wo.dwt_forward(rng.randn(*shape), 1, h0, h1, h0, h1, 'symmetric')
+        yl = torch.tensor(oyl, dtype=dtype, device=dev)
+        yh = [torch.tensor(v, dtype=dtype, device=dev) for v in oyh]
+        L = 16
+        sign = np.array([1.0, -1.0] * (L // 2))
+        lo = rng.randn(L)
+        ifm = pw.DWTInverse(wave=(lo, sign * lo[::-1]), mode='symmetric').to(dev).to(dtype)
+        assert ops.is_qmf_pair(ifm.g0_col, ifm.g1_col), 'the test wants a mirror pair in the buffers'
+        _run_inv(ifm, yl, yh, 'symmetric', tol, 'random mirror pair')
+        ifm = pw.DWTInverse(wave='db8', mode='symmetric').to(dev).to(dtype)
+        _run_inv(ifm, yl, yh, 'symmetric', tol, 'pristine db8')
+        ifm.g0_col.data[0, 0, 4, 0] -= 0.125
+        _run_inv(ifm, yl, yh, 'symmetric', tol, 'g0_col.data[...] -=')
+        ifm = pw.DWTInverse(wave='db8', mode='symmetric').to(dev).to(dtype)
+        _run_inv(ifm, yl, yh, 'symmetric', tol, 'pristine db8 (2)')
+        ifm.g1_row.data.mul_(0.5)
+        _run_inv(ifm, yl, yh, 'symmetric', tol, 'g1_row.data.mul_')
+    finally:
+        ops.STREAM_FORCE, _ll.FUSED_LEVELS = prev

@@ -49,8 +49,9 @@ def _is_qmf_kernel(name):
 
 
 def synthesis_has_qmf_variant(L):
-    """tap counts at which wl_dwt2d_synthesis_stream has a quadrature-mirror instantiation (not 14: it spills, measured slower)"""
-    return L in (12, 16, 18, 20)
+    """tap counts at which wl_dwt2d_synthesis_stream has a hinted (quadrature-mirror / lattice) instantiation (14: the lattice
+    variant only - the QMF variant alone spilled there and measured slower, round 4)"""
+    return L in (12, 14, 16, 18, 20)
 
 
 def check_dwt_inverse_mutations(dev, wave='db8', mode='symmetric', shape=(2, 2, 64, 288), dtype=torch.float32, tol=1e-5):

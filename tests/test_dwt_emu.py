@@ -877,3 +877,19 @@ def test_lattice_variant_float16_module():
     import _lattice_cases as LC
     with emu_backend.emulated():
         LC.check_lattice_float16_module('cpu', shape=(1, 1, 48, 2048))
+
+
+@pytest.mark.parametrize('wave,mode', __import__('_lattice_cases').LATTICE_WAVES)
+def test_lattice_variant_of_the_synthesis_strip_kernel(wave, mode):
+    """csrc/wl_lattice.h, the transposed recurrence: the column synthesis of the long-filter strip kernel as K = L/2 plane
+    rotations, factored on the device from the taps at call time - against the oracle, 12-20 taps, every mode (both tap-pair
+    shifts of periodization)."""
+    import _lattice_cases as LC
+    with emu_backend.emulated():
+        LC.check_lattice_inverse_vs_oracle('cpu', wave, mode)
+
+
+def test_lattice_variant_of_the_synthesis_rejects_banks_it_cannot_reproduce():
+    import _lattice_cases as LC
+    with emu_backend.emulated():
+        LC.check_lattice_inverse_rejections('cpu')

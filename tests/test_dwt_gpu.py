@@ -215,8 +215,8 @@ def test_fp16_config5_full_plane_size(W):
     pw.DWTForward(J=1, wave='db8', mode='periodization').to(DEV).half()(x)
     # W = 2048: the streaming strip kernel; W = 2046 (periodization needs whole wrapped groups): the tile kernel (pair
     # staging; V4 = 0 is the template default)
-    # (the module's banks are a quadrature-mirror pair: the strip kernel's QMF instantiation)
-    assert _last_kernel() == ('WlAfbStrip<_Float16, 16, 1>' if W % 4 == 0 else 'WlAfbTile<_Float16, 16, 16, 64, 1>'), _last_kernel()
+    # (the module's banks are a quadrature-mirror pair: the strip kernel's lattice instantiation, csrc/wl_lattice.h)
+    assert _last_kernel() == ('WlAfbStrip<_Float16, 16, 1, 1>' if W % 4 == 0 else 'WlAfbTile<_Float16, 16, 16, 64, 1>'), _last_kernel()
     yl, yh = xfm(x)
     assert yl.shape == (2, 16, 128, (W + 15) // 16) and yh[0].shape == (2, 16, 3, 1024, W // 2)
     h0, h1 = F.dwt_analysis_taps('db8')
@@ -844,3 +844,17 @@ def test_lattice_variant_rejects_banks_it_cannot_reproduce():
 def test_lattice_variant_float16_module():
     import _lattice_cases as LC
     LC.check_lattice_float16_module(DEV, shape=(2, 3, 256, 2048))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('wave,mode', __import__('_lattice_cases').LATTICE_WAVES)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_lattice_variant_of_the_synthesis_strip_kernel(wave, mode, dtype):
+    import _lattice_cases as LC
+    LC.check_lattice_inverse_vs_oracle(DEV, wave, mode, shape=(3, 2, 136, 1032), dtype=dtype)
+
+
+@pytest.mark.gpu
+def test_lattice_variant_of_the_synthesis_rejects_banks_it_cannot_reproduce():
+    import _lattice_cases as LC
+    LC.check_lattice_inverse_rejections(DEV, shape=(2, 2, 96, 1040))

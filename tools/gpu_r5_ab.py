@@ -1,11 +1,17 @@
-"""Round-5 same-box A/B: the library of the previous round (WL_LIB=ab/libwl_old.so) against this one on the launches the
+"""Round-5 same-box A/B: the package of the previous round (WL_PKG_ROOT=ab/old_pkg: python + library) against this one on the launches the
 tap-relation guards touch - 12-tap fused forward (one-bank variant + armed fallback), 16-tap strip kernels (QMF variant + armed
 fallback: config 5 reduced to 8 planes... full size), the fused DTCWT forward (reversed column taps above / below the plane).
 usage: python tools/gpu_r5_ab.py [tag]   (prints one JSON line per case)"""
 import json, os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if os.environ.get('WL_PKG_ROOT'):      # the package (python + library) of another commit, e.g. ab/old_pkg (git archive <commit> pytorch_wavelets_amd)
+    sys.path.insert(0, os.path.join(ROOT, os.environ['WL_PKG_ROOT']))
 import bench, pytorch_wavelets_amd as pw
-tag = sys.argv[1] if len(sys.argv) > 1 else os.environ.get('WL_LIB', 'new')
+from pytorch_wavelets_amd import ops
+tag = sys.argv[1] if len(sys.argv) > 1 else os.environ.get('WL_PKG_ROOT', 'new')
+if os.environ.get('WL_NO_LATTICE'):
+    ops.STRIP_LATTICE = False
 dev = 'cuda:0'; sync = torch.cuda.synchronize
 out = {}
 def t(name, fn, n=30):
