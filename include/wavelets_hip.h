@@ -239,7 +239,9 @@ int wl_scat_bwd_level1(const void* dz, const void* drdx, const void* drdy, void*
  * launches of this call have run (stream order): with the hint the hinted variant is then the LATTICE kernel
  * (csrc/wl_lattice.h: the column pass as K = L/2 plane rotations, half the multiplications), whose coefficients a one-thread
  * kernel derives from the column bank on the device and accepts only if they reproduce the bank to 2^-22 (float32 data) /
- * 2^-12 (float16 data) of its largest tap - else the two-bank variant runs as above.
+ * 2^-12 (float16 data) of its largest tap - else the two-bank variant runs as above.  policy bit 2 (value 4): tap_scratch
+ * already holds that examination of exactly these four banks for this dtype, written by an earlier call of this function on
+ * this stream (the levels of one transform share it): the one-thread kernel is not launched again.
  * Returns WL_ERR_UNSUPPORTED outside its envelope (callers then use wl_dwt2d_analysis_strided). */
 #define WL_TAP_SCRATCH_BYTES 64
 int wl_dwt2d_analysis_stream(const void* x, int64_t x_plane_stride, int x_row_stride, void* ll, int64_t ll_plane_stride,

@@ -256,13 +256,13 @@ WL_HD bool wl_taps_qmf(const float* lo, const float* hi, int L) {
     bool ok = true;
     for (int t = 0; t < L; ++t) {
         const float m = lo[L - 1 - t];
-        ok = ok && hi[t] == ((t & 1) ? -m : m);
+        ok = ok & (hi[t] == ((t & 1) ? -m : m));       // (no short circuit: straight-line compares after unrolling)
     }
     return ok;
 }
 WL_HD bool wl_taps_same(const float* a, const float* b, int L) {
     bool ok = true;
-    for (int t = 0; t < L; ++t) ok = ok && a[t] == b[t];
+    for (int t = 0; t < L; ++t) ok = ok & (a[t] == b[t]);
     return ok;
 }
 

@@ -143,7 +143,11 @@ struct WlAfbStrip {
     static const int NB = QMF ? LT / 2 : LT;           // tap pairs held per bank
     static const int kWaves = WL_STRIP_CWAVES + WL_STRIP_SWAVES;
     static const int kThreads = 64 * kWaves;
-    static const int kMinWaves = LT >= 18 ? 3 : 4;   // two 8-wave workgroups per CU need four waves per SIMD: at most 128 registers (18, 20 taps: 168)
+#ifndef WL_STRIP_LAT_MINW
+#define WL_STRIP_LAT_MINW 4     // waves per SIMD the lattice variants are compiled for (6: three workgroups per CU, at most 80 registers)
+#endif
+    // two 8-wave workgroups per CU need four waves per SIMD: at most 128 registers (18, 20 taps: 168)
+    static const int kMinWaves = (LAT && LT <= 16) ? WL_STRIP_LAT_MINW : LT >= 18 ? 3 : 4;
     static const int SZ = (int)sizeof(T);
     static const int A = 16 / SZ;          // elements per 16-byte piece
     static const int WARM = (LT - 2) / 2;  // feeds that only fill the window

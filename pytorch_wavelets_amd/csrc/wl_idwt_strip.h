@@ -66,7 +66,11 @@ struct WlSfbStrip {
     static_assert(!LAT || QMF, "the lattice variant runs its row synthesis in the QMF form");
     static const int kWaves = WL_STRIP_CWAVES + 4;
     static const int kThreads = 64 * kWaves;
-    static const int kMinWaves = LT >= 18 ? 3 : 4;
+#ifndef WL_STRIP_LAT_MINW
+#define WL_STRIP_LAT_MINW 4     // waves per SIMD the lattice variants are compiled for (6: three workgroups per CU, at most 80 registers)
+#endif
+    // two 8-wave workgroups per CU need four waves per SIMD: at most 128 registers (18, 20 taps: 168)
+    static const int kMinWaves = (LAT && LT <= 16) ? WL_STRIP_LAT_MINW : LT >= 18 ? 3 : 4;
     static const int SZ = (int)sizeof(T);
     static const int A = 16 / SZ;
     static const int HL = LT / 2;

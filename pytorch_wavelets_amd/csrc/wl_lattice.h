@@ -40,16 +40,21 @@
 //     (z[2m], z[2m+1]) = g (p - T_0 q, q + T_0 p)                                  (g again folded into the row synthesis' taps)
 //
 // lo / hi: the L stored taps of one axis.  true: *g and T[0 .. L/2) hold the recurrence.
-WL_HD bool wl_lattice_factor(const float* lo, const float* hi, int L, double tol, float* g, float* T, bool syn = false) {
+// (L is a template parameter: every loop unrolls and the matrices live in registers - with run-time bounds they sat in scratch
+// memory and the one-thread kernel took 25 us, as long as a small analysis launch)
+template <int L>
+WL_HD bool wl_lattice_factor(const float* lo, const float* hi, double tol, float* g, float* T, bool syn = false) {
+    static_assert(L >= 4 && L % 2 == 0 && L / 2 <= WL_LAT_MAXK, "even tap counts from 4 to 20");
     const int K = L / 2;
-    if (L < 4 || (L & 1) || K > WL_LAT_MAXK) return false;
-    double E[WL_LAT_MAXK][2][2], n0[WL_LAT_MAXK][2], n1[WL_LAT_MAXK][2], Td[WL_LAT_MAXK];
+    double E[K][2][2], n0[K][2], n1[K][2], Td[K];
     double scale = 0.0;
+#pragma unroll
     for (int i = 0; i < K; ++i) {
         const int e = syn ? 2 * i : L - 2 - 2 * i;
         E[i][0][0] = lo[e]; E[i][0][1] = lo[e + 1];
         E[i][1][0] = hi[e]; E[i][1][1] = hi[e + 1];
     }
+#pragma unroll
     for (int t = 0; t < L; ++t) {
         const double a = lo[t] < 0 ? -(double)lo[t] : (double)lo[t], b = hi[t] < 0 ? -(double)hi[t] : (double)hi[t];
         if (!(a <= 1e30) || !(b <= 1e30)) return false;            // NaN / Inf taps
@@ -58,6 +63,7 @@ WL_HD bool wl_lattice_factor(const float* lo, const float* hi, int L, double tol
     if (!(scale > 0.0)) return false;
     auto ab = [](double v) { return v < 0 ? -v : v; };
     double res = 0.0, gain = 1.0;
+#pragma unroll
     for (int k = K - 1; k >= 1; --k) {
         // E(z) = R_k D(z) E'(z): the rotation that annihilates the z^-k coefficient of row 0 (and with it, for a paraunitary
         // E, the z^0 coefficient of row 1)
@@ -67,17 +73,26 @@ WL_HD bool wl_lattice_factor(const float* lo, const float* hi, int L, double tol
         if (!(r > 1e-12 * scale)) return false;
         const double s = x / r, c = y / r;
         if (!(ab(c) > 1e-7)) return false;                         // a rotation by 90 degrees has no finite tangent
-        for (int i = 0; i <= k; ++i)
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+#pragma unroll
             for (int q = 0; q < 2; ++q) {
+                if (i > k) continue;
                 n0[i][q] = c * E[i][0][q] - s * E[i][1][q];
                 n1[i][q] = s * E[i][0][q] + c * E[i][1][q];
             }
+#pragma unroll
         for (int q = 0; q < 2; ++q) {
             res = ab(n0[k][q]) > res ? ab(n0[k][q]) : res;
             res = ab(n1[0][q]) > res ? ab(n1[0][q]) : res;
         }
-        for (int i = 0; i < k; ++i)
-            for (int q = 0; q < 2; ++q) { E[i][0][q] = n0[i][q]; E[i][1][q] = n1[i + 1][q]; }
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (i >= k) continue;
+                E[i][0][q] = n0[i][q]; E[i][1][q] = n1[i + 1][q];
+            }
         Td[k] = -(s / c);
         gain *= c;
     }
@@ -89,6 +104,7 @@ WL_HD bool wl_lattice_factor(const float* lo, const float* hi, int L, double tol
     Td[0] = -(s0 / c0);
     gain *= c0;
     if (!(res <= tol * scale)) return false;
+#pragma unroll
     for (int k = 0; k < K; ++k) {
         if (!(ab(Td[k]) < 1e6)) return false;
         T[k] = (float)Td[k];
@@ -123,19 +139,24 @@ struct WlTapPrepArgs {
     float tol;
     int syn;               // the banks are a synthesis pair (WlSfbStrip) / an analysis pair (WlAfbStrip)
 };
+template <int LT>
 struct WlTapPrep {
     typedef WlTapPrepArgs Args;
     static const int kThreads = 64;
     static const int kMinWaves = 1;
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
-        if (ctx.tid != 0 || ctx.bid != 0) return;
-        float g = 0.f, T[WL_LAT_MAXK];
-        for (int k = 0; k < WL_LAT_MAXK; ++k) T[k] = 0.f;
-        bool ok = wl_taps_qmf(a.h_w_lo, a.h_w_hi, a.L) && wl_taps_qmf(a.h_h_lo, a.h_h_hi, a.L);
-        ok = ok && wl_lattice_factor(a.h_h_lo, a.h_h_hi, a.L, (double)a.tol, &g, T, a.syn != 0);
+        if (ctx.bid != 0) return;
+        // (every lane of the one wave computes the same: the taps arrive by scalar loads, nothing diverges)
+        float g = 0.f, T[LT / 2];
+#pragma unroll
+        for (int k = 0; k < LT / 2; ++k) T[k] = 0.f;
+        bool ok = wl_taps_qmf(a.h_w_lo, a.h_w_hi, LT) && wl_taps_qmf(a.h_h_lo, a.h_h_hi, LT);
+        ok = wl_lattice_factor<LT>(a.h_h_lo, a.h_h_hi, (double)a.tol, &g, T, a.syn != 0) && ok;
+        if (ctx.tid != 0) return;
         unsigned* flag = reinterpret_cast<unsigned*>(a.out);
         a.out[1] = g;
-        for (int k = 0; k < WL_LAT_MAXK; ++k) a.out[2 + k] = T[k];
+#pragma unroll
+        for (int k = 0; k < LT / 2; ++k) a.out[2 + k] = T[k];
         flag[0] = ok ? WL_LAT_OK : 0u;
     }
 };

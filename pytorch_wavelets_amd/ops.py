@@ -217,12 +217,40 @@ def qmf_hint(flag):
     mirrors of the lowpass banks, hi[t] = (-1)**t * lo[L-1-t] (policy bit 1 of wl_dwt2d_synthesis_stream /
     wl_dwt2d_analysis_stream): DWTInverse / DWTForward set it from their buffers (TapVerdict).  The QMF kernel variant checks the
     relation on the device and the two-bank variant stands by behind it: a wrong hint is slow, not wrong."""
-    prev = getattr(_HINTS, 'qmf', False)
+    prev = getattr(_HINTS, 'qmf', False), getattr(_HINTS, 'tapcache', None)
     _HINTS.qmf = bool(flag)
+    _HINTS.tapcache = {} if flag else None      # the levels of one transform share their float32 taps and the lattice scratch (_hinted_taps)
     try:
         yield
     finally:
-        _HINTS.qmf = prev
+        _HINTS.qmf, _HINTS.tapcache = prev
+
+
+def _hinted_taps(bufs, ref, L, syn):
+    """The four banks of a hinted strip launch as float32 device taps + the lattice variant's device scratch (csrc/wl_lattice.h:
+    a one-thread kernel leaves its verdict on the banks and the column lattice there; the lattice kernel and its armed two-bank
+    fallback read it) + policy bit 2 when the scratch was already filled for exactly these buffers by an earlier level of the
+    SAME module call.  The cache lives in the qmf_hint context of that call (no user code runs between its levels) and is keyed
+    on the buffers' addresses, dtypes and the data type: the levels of a transform then share one examination and - for a
+    `.half()` module - one conversion of the taps.  The scratch stays referenced until the context ends: the allocator hands
+    it out again on this stream only, behind the launches that read it."""
+    cache = getattr(_HINTS, 'tapcache', None)
+    key = (tuple((b.data_ptr(), b.dtype, b._version) for b in bufs), ref.device, ref.dtype, L, bool(syn))
+    ent = cache.get(key) if cache is not None else None
+    if ent is None:
+        taps = tuple(_taps(b, ref) for b in bufs)
+        scratch = torch.empty(TAP_SCRATCH_FLOATS, dtype=torch.float32, device=ref.device) if L >= 12 and STRIP_LATTICE else None
+        ent = [taps, scratch, 0]
+        if cache is not None:
+            cache[key] = ent
+    return ent
+
+
+def _mark_prepared(ent):
+    """A hinted strip launch went through (rc == 0): its scratch now holds the examination of these banks (only then - a launcher
+    that declines returns before its one-thread kernel, and a recycled block may hold the verdict of another module's taps)."""
+    if ent[1] is not None:
+        ent[2] = 4
 
 
 def banks_equal(lo_a, hi_a, lo_b, hi_b):
@@ -479,21 +507,19 @@ def afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=False):
     key = ('afbs', x.device, x.dtype, N * C, H, W, x_ps, x_rs, L, mode, bool(force), qmf)
     if key in _FUSED_DECLINED:
         return None
-    hwl, hwh, hhl, hhh = (_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi))
+    ent = _hinted_taps((h_w_lo, h_w_hi, h_h_lo, h_h_hi), x, L, False) if qmf else [tuple(_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi)), None, 0]
+    (hwl, hwh, hhl, hhh), scratch, prepared = ent
     Kh, Kw = coeff_len(H, L, mode), coeff_len(W, L, mode)
     ll = torch.empty((N, C, Kh, Kw), dtype=x.dtype, device=x.device)
     highs = torch.empty((N, C, 3, Kh, Kw), dtype=x.dtype, device=x.device)
-    # device scratch for the lattice variant (csrc/wl_lattice.h): a one-thread kernel leaves its verdict on the banks and the
-    # column lattice there, the lattice kernel and its armed two-bank fallback read it.  (Freed when this call returns: the
-    # allocator hands it out again on this stream only, behind the launches that read it.)
-    scratch = torch.empty(TAP_SCRATCH_FLOATS, dtype=torch.float32, device=x.device) if qmf and L >= 12 and STRIP_LATTICE else None
     rc = _call('wl_dwt2d_analysis_stream', x, x.data_ptr(), x_ps, x_rs, ll.data_ptr(), Kh * Kw, Kw, highs.data_ptr(),
                _DTYPES[x.dtype], N * C, H, W, hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(), hhh.data_ptr(), L, mode,
-               (1 if force else 0) | (2 if qmf else 0), None if scratch is None else scratch.data_ptr(), _stream(x))
+               (1 if force else 0) | (2 if qmf else 0) | prepared, None if scratch is None else scratch.data_ptr(), _stream(x))
     if rc == -3:
         _remember_decline(key)
         return None
     _lib.check(rc, 'wl_dwt2d_analysis_stream')
+    _mark_prepared(ent)
     return ll, highs
 
 
@@ -524,17 +550,17 @@ def sfb2d_stream(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None, f
     key = ('sfbs', ll.device, ll.dtype, N * C, Kh, Kw, ll_ps, ll_rs, OH, OW, L, mode, bool(force), qmf)
     if key in _FUSED_DECLINED:
         return None
-    gwl, gwh, ghl, ghh = (_taps(g, ll) for g in (g_w_lo, g_w_hi, g_h_lo, g_h_hi))
+    ent = _hinted_taps((g_w_lo, g_w_hi, g_h_lo, g_h_hi), ll, L, True) if qmf else [tuple(_taps(g, ll) for g in (g_w_lo, g_w_hi, g_h_lo, g_h_hi)), None, 0]
+    (gwl, gwh, ghl, ghh), scratch, prepared = ent
     y = torch.empty((N, C, OH, OW), dtype=ll.dtype, device=ll.device)
-    # (device scratch for the lattice variant: see afb2d_stream)
-    scratch = torch.empty(TAP_SCRATCH_FLOATS, dtype=torch.float32, device=ll.device) if qmf and L >= 12 and STRIP_LATTICE else None
     rc = _call('wl_dwt2d_synthesis_stream', ll, ll.data_ptr(), ll_ps, ll_rs, highs.data_ptr(), y.data_ptr(), _DTYPES[ll.dtype],
                N * C, Kh, Kw, OH, OW, gwl.data_ptr(), gwh.data_ptr(), ghl.data_ptr(), ghh.data_ptr(), L, mode,
-               (1 if force else 0) | (2 if qmf else 0), None if scratch is None else scratch.data_ptr(), _stream(ll))
+               (1 if force else 0) | (2 if qmf else 0) | prepared, None if scratch is None else scratch.data_ptr(), _stream(ll))
     if rc == -3:
         _remember_decline(key)
         return None
     _lib.check(rc, 'wl_dwt2d_synthesis_stream')
+    _mark_prepared(ent)
     return y
 
 

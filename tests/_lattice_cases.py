@@ -195,3 +195,34 @@ def check_lattice_inverse_rejections(dev, dtype=torch.float32, shape=(1, 2, 64, 
         _run_inv(ifm, yl, yh, 'symmetric', tol, 'g1_row.data.mul_')
     finally:
         ops.STREAM_FORCE, _ll.FUSED_LEVELS = prev
+
+
+def check_lattice_levels_share_one_examination(dev, shape=(1, 2, 128, 1024)):
+    """The levels of ONE module call share their float32 taps and the one-thread examination of the banks (policy bit 2 of the
+    strip entry points): J = 2 forward and inverse of a `.half()` module = one WlTapPrep launch each, two lattice launches, two
+    armed fallbacks - and the result against the oracle on the module's taps."""
+    from pytorch_wavelets_amd import ops
+    from pytorch_wavelets_amd.dwt import lowlevel as _ll
+    rng = np.random.RandomState(47)
+    prev = ops.STREAM_FORCE, _ll.FUSED_LEVELS
+    ops.STREAM_FORCE, _ll.FUSED_LEVELS = True, False
+    try:
+        x = torch.tensor(rng.randn(*shape), device=dev).half()
+        xfm = pw.DWTForward(J=2, wave='db8', mode='periodization').to(dev).half()
+        ifm = pw.DWTInverse(wave='db8', mode='periodization').to(dev).half()
+        c0 = pw.launch_count()
+        yl, yh = xfm(x)
+        ks = pw.kernels_since(c0)
+        assert [k.startswith('WlTapPrep') for k in ks] == [True, False, False, False, False] and _is_lattice(ks[1]) and _is_lattice(ks[3]), ks
+        oyl, oyh = wo.dwt_forward(x.detach().cpu().double().numpy(), 2, _flat(xfm.h0_col), _flat(xfm.h1_col),
+                                  _flat(xfm.h0_row), _flat(xfm.h1_row), 'periodization')
+        assert _rel(yl, oyl) <= 3e-3 and all(_rel(a, b) <= 3e-3 for a, b in zip(yh, oyh))
+        c0 = pw.launch_count()
+        r = ifm((yl, yh))
+        ks = pw.kernels_since(c0)
+        assert [k.startswith('WlTapPrep') for k in ks] == [True, False, False, False, False] and _is_lattice_syn(ks[1]) and _is_lattice_syn(ks[3]), ks
+        want = wo.dwt_inverse(yl.detach().cpu().double().numpy(), [h.detach().cpu().double().numpy() for h in yh],
+                              _flat(ifm.g0_col), _flat(ifm.g1_col), _flat(ifm.g0_row), _flat(ifm.g1_row), 'periodization')
+        assert _rel(r, want) <= 3e-3
+    finally:
+        ops.STREAM_FORCE, _ll.FUSED_LEVELS = prev

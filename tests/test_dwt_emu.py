@@ -893,3 +893,9 @@ def test_lattice_variant_of_the_synthesis_rejects_banks_it_cannot_reproduce():
     import _lattice_cases as LC
     with emu_backend.emulated():
         LC.check_lattice_inverse_rejections('cpu')
+
+
+def test_lattice_levels_share_one_examination():
+    import _lattice_cases as LC
+    with emu_backend.emulated():
+        LC.check_lattice_levels_share_one_examination('cpu', shape=(1, 1, 96, 1024))

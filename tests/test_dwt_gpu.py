@@ -858,3 +858,9 @@ def test_lattice_variant_of_the_synthesis_strip_kernel(wave, mode, dtype):
 def test_lattice_variant_of_the_synthesis_rejects_banks_it_cannot_reproduce():
     import _lattice_cases as LC
     LC.check_lattice_inverse_rejections(DEV, shape=(2, 2, 96, 1040))
+
+
+@pytest.mark.gpu
+def test_lattice_levels_share_one_examination():
+    import _lattice_cases as LC
+    LC.check_lattice_levels_share_one_examination(DEV, shape=(2, 4, 512, 2048))

@@ -7,8 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 if os.environ.get('WL_PKG_ROOT'):      # the package (python + library) of another commit, e.g. ab/old_pkg (git archive <commit> pytorch_wavelets_amd)
     sys.path.insert(0, os.path.join(ROOT, os.environ['WL_PKG_ROOT']))
-import bench, pytorch_wavelets_amd as pw
+import pytorch_wavelets_amd as pw        # (before bench: importing bench puts the repo root in front of sys.path)
 from pytorch_wavelets_amd import ops
+import bench
 tag = sys.argv[1] if len(sys.argv) > 1 else os.environ.get('WL_PKG_ROOT', 'new')
 if os.environ.get('WL_NO_LATTICE'):
     ops.STRIP_LATTICE = False
