@@ -54,7 +54,8 @@ def check_lattice_vs_oracle(dev, wave, mode, shape=(2, 2, 72, 288), dtype=torch.
     try:
         x = torch.tensor(rng.randn(*shape), dtype=dtype, device=dev)
         xfm = pw.DWTForward(J=1, wave=wave, mode=mode).to(dev).to(dtype)
-        return _run(xfm, x, mode, 1e-5 if dtype == torch.float32 else 3e-3, (wave, mode))
+        # (18 taps: no lattice instantiation - nine delay slots would need nine unrolled half-batches - the QMF variant runs)
+        return _run(xfm, x, mode, 1e-5 if dtype == torch.float32 else 3e-3, (wave, mode), want_lattice=len(F.dwt_analysis_taps(wave)[0]) != 18)
     finally:
         ops.STREAM_FORCE, _ll.FUSED_LEVELS = prev
 
@@ -135,11 +136,12 @@ def _is_lattice_syn(name):
     return len(args) >= 5 and args[4] == '1'
 
 
-def _run_inv(ifm, yl, yh, mode, tol, what):
+def _run_inv(ifm, yl, yh, mode, tol, what, want_lattice=True):
     c0 = pw.launch_count()
     r = ifm((yl, yh))
     ks = pw.kernels_since(c0)
-    assert len(ks) == 3 and ks[0].startswith('WlTapPrep') and _is_lattice_syn(ks[1]) and ks[2].endswith('(armed fallback)'), (what, ks)
+    if want_lattice:
+        assert len(ks) == 3 and ks[0].startswith('WlTapPrep') and _is_lattice_syn(ks[1]) and ks[2].endswith('(armed fallback)'), (what, ks)
     want = wo.dwt_inverse(yl.detach().cpu().double().numpy(), [h.detach().cpu().double().numpy() for h in yh],
                           _flat(ifm.g0_col), _flat(ifm.g1_col), _flat(ifm.g0_row), _flat(ifm.g1_row), mode)
     e = _rel(r, want)
@@ -161,7 +163,7 @@ def check_lattice_inverse_vs_oracle(dev, wave, mode, shape=(2, 2, 72, 288), dtyp
         yl = torch.tensor(oyl, dtype=dtype, device=dev)
         yh = [torch.tensor(v, dtype=dtype, device=dev) for v in oyh]
         ifm = pw.DWTInverse(wave=wave, mode=mode).to(dev).to(dtype)
-        return _run_inv(ifm, yl, yh, mode, 1e-5 if dtype == torch.float32 else 3e-3, (wave, mode))
+        return _run_inv(ifm, yl, yh, mode, 1e-5 if dtype == torch.float32 else 3e-3, (wave, mode), want_lattice=len(h0) != 18)
     finally:
         ops.STREAM_FORCE, _ll.FUSED_LEVELS = prev
 
@@ -226,3 +228,29 @@ def check_lattice_levels_share_one_examination(dev, shape=(1, 2, 128, 1024)):
         assert _rel(r, want) <= 3e-3
     finally:
         ops.STREAM_FORCE, _ll.FUSED_LEVELS = prev
+
+
+def check_tile_kernels_14_18_taps(dev, wave, shape=(2, 2, 100, 104)):
+    """db7 / sym7 (14 taps) and db9 / sym9 (18 taps) on the compile-time-tap tile kernels (round 5: before, every narrow level
+    of theirs ran on the run-time-tap kernel): J = 2 forward and inverse, every mode, float32 + float16, against the oracle."""
+    rng = np.random.RandomState(53)
+    h0, h1 = F.dwt_analysis_taps(wave)
+    g0, g1 = F.dwt_synthesis_taps(wave)
+    L = len(h0)
+    for mode in ('zero', 'symmetric', 'periodization', 'reflect', 'periodic'):
+        for dt, tol in ((torch.float32, 1e-5), (torch.float16, 4e-3)):
+            x = torch.tensor(rng.randn(*shape)).to(dt).to(dev)
+            oyl, oyh = wo.dwt_forward(x.detach().cpu().double().numpy(), 2, h0, h1, h0, h1, mode)
+            xfm = pw.DWTForward(J=2, wave=wave, mode=mode).to(dev)
+            ifm = pw.DWTInverse(wave=wave, mode=mode).to(dev)
+            c0 = pw.launch_count()
+            yl, yh = xfm(x)
+            ks = pw.kernels_since(c0)
+            assert any(k.startswith('WlAfbTile<') and ', %d' % L in k for k in ks), (wave, mode, ks)
+            c0 = pw.launch_count()
+            r = ifm((yl, yh))
+            ks = pw.kernels_since(c0)
+            assert any(k.startswith('WlSfbTile<') and ', %d,' % L in k for k in ks), (wave, mode, ks)
+            orec = wo.dwt_inverse(yl.detach().cpu().double().numpy(), [h.detach().cpu().double().numpy() for h in yh], g0, g1, g0, g1, mode)
+            errs = [_rel(yl, oyl)] + [_rel(a, b) for a, b in zip(yh, oyh)] + [_rel(r, orec)]
+            assert max(errs) <= tol, (wave, mode, dt, errs)

@@ -899,3 +899,10 @@ def test_lattice_levels_share_one_examination():
     import _lattice_cases as LC
     with emu_backend.emulated():
         LC.check_lattice_levels_share_one_examination('cpu', shape=(1, 1, 96, 1024))
+
+
+@pytest.mark.parametrize('wave', ['db7', 'db9', 'sym7'])
+def test_tile_kernels_for_14_and_18_taps(wave):
+    import _lattice_cases as LC
+    with emu_backend.emulated():
+        LC.check_tile_kernels_14_18_taps('cpu', wave)

@@ -864,3 +864,10 @@ def test_lattice_variant_of_the_synthesis_rejects_banks_it_cannot_reproduce():
 def test_lattice_levels_share_one_examination():
     import _lattice_cases as LC
     LC.check_lattice_levels_share_one_examination(DEV, shape=(2, 4, 512, 2048))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('wave', ['db7', 'db9', 'sym7', 'sym9'])
+def test_tile_kernels_for_14_and_18_taps(wave):
+    import _lattice_cases as LC
+    LC.check_tile_kernels_14_18_taps(DEV, wave, shape=(4, 3, 200, 232))
