@@ -345,7 +345,10 @@ def main():
         c0 = pw.launch_count()
         wl.run(p)
         launches[p] = pw.kernels_since(c0)
-        order = launches[p] if p == 'f' else launches[p][::-1]      # (an inverse runs coarsest level first)
+        # (the label: a kernel that does the transform's work - not the one-thread examination of the filter banks in front of a
+        # lattice launch, "(aux)", nor the two-bank variant queued behind a hinted one, "(armed fallback)", which returns at once)
+        prim = [k for k in launches[p] if not k.endswith(')')]
+        order = prim if p == 'f' else prim[::-1]                    # (an inverse runs coarsest level first)
         kernel[p] = order[0] if order else pw.last_kernel()
     parts = [p for p in 'fi' if p == 'f' or wl.ifm is not None]
 
@@ -453,15 +456,20 @@ def main():
             # kernels execute: 17 packed FMAs (v_pk_fma_f32) per output sample at 16 taps (L row taps + L column taps + 1, on
             # (lo, hi) pairs), one output sample per input pixel and level (critically sampled: sum over 4 levels = 1.328 P);
             # a wave64 VALU instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md).
+            # Round 5: with the lattice column pass (csrc/wl_lattice.h: K = L/2 rotations instead of L taps) it is L + L/2 + 0.5 = 12.5
+            # per output sample - the VALU floor then lies under the HBM floor and the line says bound: "hbm".
             samples = wl.x.numel() * sum(0.25 ** j for j in range(wl.J))
-            valu_min_ms = samples * 17 * 4 / 64 / (1024 * 2.4e9) * 1e3
+            lattice = any(k.startswith('WlAfbStrip<') and k.rstrip('>').endswith(', 1, 1') for k in launches['f'])
+            fma_per_sample = 12.5 if lattice else 17
+            valu_min_ms = samples * fma_per_sample * 4 / 64 / (1024 * 2.4e9) * 1e3
             hbm_min_ms = wl.bytes['f'] / (HBM_PEAK_GBS * 1e9) * 1e3
             roof['bound'] = 'valu' if valu_min_ms > hbm_min_ms else 'hbm'
             roof['valu'] = {'bound': 'valu', 'unit': 'ms', 'min_ms_at_valu_peak': round(valu_min_ms, 4),
                             'min_ms_at_hbm_peak': round(hbm_min_ms, 4),
                             'frac': round(valu_min_ms / part_ms['f'], 4),
-                            'what': '17 v_pk_fma_f32 per output sample x 1.328 samples per pixel, 4 cycles per wave64 '
-                                    'instruction and SIMD, 1024 SIMDs at 2.4 GHz'}
+                            'what': '%g v_pk_fma_f32 per output sample (%s) x 1.328 samples per pixel, 4 cycles per wave64 '
+                                    'instruction and SIMD, 1024 SIMDs at 2.4 GHz'
+                                    % (fma_per_sample, 'lattice column pass' if lattice else 'direct form')}
             if 'i' in part_ms:
                 roof['valu']['inverse_frac'] = round(valu_min_ms / part_ms['i'], 4)
         if wl.key == 'dwt':

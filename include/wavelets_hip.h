@@ -51,8 +51,11 @@ int wl_set_option(const char* name, int value);
 int wl_get_option(const char* name);   /* current value, or WL_ERR_UNSUPPORTED for an unknown name */
 const char* wl_last_kernel(void);
 /* wl_launch_count(): kernels launched by the process so far; wl_kernel_history(back): the functor launched `back` launches
- * ago (0 = the last one, up to 7; "" beyond) - a multi-launch transform (DTCWT: one kernel per level or pair of levels)
- * can then be labelled launch by launch. */
+ * ago (0 = the last one, up to 31; "" beyond) - a multi-launch transform (DTCWT: one kernel per level or pair of levels)
+ * can then be labelled launch by launch.  A name that contains "wl_launch_armed" is the two-bank variant queued behind a kernel
+ * variant that relies on a relation between the filter banks (it returns at once unless the device finds the relation broken),
+ * "wl_launch_aux" a helper launch (the one-thread examination of the banks in front of a lattice launch); wl_last_kernel names
+ * neither. */
 long long wl_launch_count(void);
 const char* wl_kernel_history(int back);
 

@@ -30,10 +30,10 @@ def launch_count():
 
 def kernels_since(count):
     """The kernel functors launched since ``count = launch_count()`` was read, oldest first (the engine remembers the last
-    eight): every launch of a multi-launch transform by name."""
+    32): every launch of a multi-launch transform by name."""
     from . import ops
     be = ops._backend()
-    n = min(int(be.wl_launch_count()) - count, 8)
+    n = min(int(be.wl_launch_count()) - count, 32)
     out = []
     for back in range(n - 1, -1, -1):
         raw = be.wl_kernel_history(back).decode()

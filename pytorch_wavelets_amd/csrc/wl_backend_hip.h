@@ -24,18 +24,18 @@ __global__ void __launch_bounds__(K::kThreads, K::kMinWaves) wl_kernel(const typ
 #include <atomic>
 inline std::atomic<const char*> wl_last_kernel_ptr{""};
 static const char* wl_last_kernel_name() { return wl_last_kernel_ptr.load(std::memory_order_relaxed); }
-// ... and the last eight, with a running count of launches: a benchmark names EVERY kernel of a multi-launch transform
-inline std::atomic<const char*> wl_kernel_log_buf[8] = {};
+// ... and the last 32, with a running count of launches: a benchmark names EVERY kernel of a multi-launch transform
+inline std::atomic<const char*> wl_kernel_log_buf[32] = {};
 inline std::atomic<long long> wl_kernel_log_n{0};
 static void wl_kernel_log(const char* name) {
     const long long i = wl_kernel_log_n.fetch_add(1, std::memory_order_relaxed);
-    wl_kernel_log_buf[i & 7].store(name, std::memory_order_relaxed);
+    wl_kernel_log_buf[i & 31].store(name, std::memory_order_relaxed);
 }
 static long long wl_launch_count_value() { return wl_kernel_log_n.load(std::memory_order_relaxed); }
 static const char* wl_kernel_history_name(int back) {
     const long long n = wl_kernel_log_n.load(std::memory_order_relaxed);
-    if (back < 0 || back >= 8 || back >= n) return "";
-    const char* p = wl_kernel_log_buf[(n - 1 - back) & 7].load(std::memory_order_relaxed);
+    if (back < 0 || back >= 32 || back >= n) return "";
+    const char* p = wl_kernel_log_buf[(n - 1 - back) & 31].load(std::memory_order_relaxed);
     return p ? p : "";
 }
 

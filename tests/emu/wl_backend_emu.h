@@ -20,12 +20,12 @@
 inline int wl_num_cus() { return 2; }
 inline const char* wl_last_kernel_ptr = "";
 inline const char* wl_last_kernel_name() { return wl_last_kernel_ptr; }
-inline const char* wl_kernel_log_buf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+inline const char* wl_kernel_log_buf[32] = {};
 inline long long wl_kernel_log_n = 0;
 inline long long wl_launch_count_value() { return wl_kernel_log_n; }
 inline const char* wl_kernel_history_name(int back) {
-    if (back < 0 || back >= 8 || back >= wl_kernel_log_n) return "";
-    return wl_kernel_log_buf[(wl_kernel_log_n - 1 - back) & 7];
+    if (back < 0 || back >= 32 || back >= wl_kernel_log_n) return "";
+    return wl_kernel_log_buf[(wl_kernel_log_n - 1 - back) & 31];
 }
 
 struct WlEmuBlock {
@@ -117,7 +117,7 @@ static int wl_launch_named(const typename K::Args& a, int64_t nblocks, size_t ld
     if (nblocks <= 0) return 0;
     if (lds > 160 * 1024) return -2;
     if (primary) wl_last_kernel_ptr = name;
-    wl_kernel_log_buf[wl_kernel_log_n++ & 7] = name;
+    wl_kernel_log_buf[wl_kernel_log_n++ & 31] = name;
     const int nt = K::kThreads;
     const size_t kStack = 256 * 1024;
 #pragma omp parallel

@@ -1,4 +1,4 @@
-"""Turn the outputs of tools/gpu_round4.sh / gpu_round3.sh (one gpurun call) into the tracked summaries under profiles/
+"""Turn the outputs of tools/gpu_round5.sh / gpu_round4.sh / gpu_round3.sh (one gpurun call) into the tracked summaries under profiles/
 (RND = the round prefix, 'r04' unless given; the counter files are written only when the call made the PMC passes):
    <tag>_bench_line.json, <tag>_bench_{dtcwt,scat,cfg5}.json   the JSON lines of the four bench commands
    <tag>_kernel_durations.csv, <tag>_{dtcwt,scat,cfg5}_kernel_durations.csv   per (kernel, grid) launch count / mean / min / max (us)
@@ -140,8 +140,9 @@ if os.path.exists(os.path.join(G, 'pmc_%s_bench' % tag, 'pmc_summary.json')):
              'wait_inst_any_fraction_of_wave_cycles': round(m['SQ_WAIT_INST_ANY'] / m['SQ_WAVE_CYCLES'], 4),   # (both in units of 4 cycles)
              'hbm_bytes_corrected': t.get(name, {}).get('hbm_bytes_corrected')}
         out['kernels'][name] = d
-    out['reading'] = ('Both kernels are bound by vector-ALU issue, not by HBM: a wave64 VALU instruction occupies its SIMD for 4 cycles, so '
-                      '4 x SQ_INSTS_VALU / (SIMDs x kernel cycles) is the VALU-pipe utilisation.  See DESIGN.md 4.6 / 5 for the derivation '
-                      'of the VALU roofline of config 5 (1.24 ms for the four levels against 1.07 ms at the HBM peak).')
+    out['reading'] = ('A wave64 VALU instruction occupies its SIMD for 4 cycles, so 4 x SQ_INSTS_VALU / (SIMDs x kernel cycles) is the VALU-pipe '
+                      'utilisation.  Rounds 3-4 (direct form, 17 packed FMAs per output sample): both kernels bound by vector-ALU issue (utilisation '
+                      '0.63-0.67, VALU roofline of the four levels 1.24 ms against 1.07 ms at the HBM peak).  Round 5 (lattice column pass, '
+                      'csrc/wl_lattice.h: 12.5 per output sample, VALU floor 0.91 ms): see DESIGN.md 4.18 / 5.')
     json.dump(out, open(os.path.join(P, RND + '_cfg5_pmc_summary.json'), 'w'), indent=1)
     print('wrote', RND + '_cfg5_pmc_summary.json')
