@@ -347,6 +347,40 @@ struct WlSfbStrip {
         RowSyn<P, 1>::run(R, lo, hi, acc);
         return acc;
     }
+    // The four row syntheses of a feed - pairs A (P = 0) and B (P = 1), a from (ll, hl), b from (lh, hh) - with their accumulator
+    // chains interleaved tap by tap: a packed FMA that reads the result of the one two instructions before it waits a cycle (the
+    // compiler put an s_nop behind every other FMA of the two-chain form: 270 in the four half-batches of the 16-tap loop).
+    template <int J, int U = 0> struct RowSyn4 {
+        static WL_DEV void run(const Wave& R, const wl_v2 (&cll)[NC2], const wl_v2 (&clh)[NC2], const wl_v2 (&chl)[NC2], const wl_v2 (&chh)[NC2],
+                               wl_v2& aA, wl_v2& bA, wl_v2& aB, wl_v2& bB) {
+            fma_cell<NT - 1 - J>(aA, R.twl[J], cll); fma_cell<NT - 1 - J>(bA, R.twl[J], clh);
+            fma_cell<NT - J>(aB, R.twl[J], cll); fma_cell<NT - J>(bB, R.twl[J], clh);
+            if (QMF) {
+                fma_cell_q<NT - 1 - J, J>(aA, R, chl); fma_cell_q<NT - 1 - J, J>(bA, R, chh);
+                fma_cell_q<NT - J, J>(aB, R, chl); fma_cell_q<NT - J, J>(bB, R, chh);
+            } else {
+                fma_cell<NT - 1 - J>(aA, R.twh[QMF ? 0 : J], chl); fma_cell<NT - 1 - J>(bA, R.twh[QMF ? 0 : J], chh);
+                fma_cell<NT - J>(aB, R.twh[QMF ? 0 : J], chl); fma_cell<NT - J>(bB, R.twh[QMF ? 0 : J], chh);
+            }
+            RowSyn4<J + 1, U>::run(R, cll, clh, chl, chh, aA, bA, aB, bB);
+        }
+    };
+    template <int U> struct RowSyn4<NT, U> {
+        static WL_DEV void run(const Wave&, const wl_v2 (&)[NC2], const wl_v2 (&)[NC2], const wl_v2 (&)[NC2], const wl_v2 (&)[NC2], wl_v2&, wl_v2&, wl_v2&, wl_v2&) {}
+    };
+    static WL_DEV void row_syn4(const Wave& R, const wl_v2 (&cll)[NC2], const wl_v2 (&clh)[NC2], const wl_v2 (&chl)[NC2], const wl_v2 (&chh)[NC2],
+                                wl_v2& aA, wl_v2& bA, wl_v2& aB, wl_v2& bB) {
+        aA = mul_cell<NT - 1>(R.twl[0], cll); bA = mul_cell<NT - 1>(R.twl[0], clh);
+        aB = mul_cell<NT>(R.twl[0], cll); bB = mul_cell<NT>(R.twl[0], clh);
+        if (QMF) {
+            fma_cell_q<NT - 1, 0>(aA, R, chl); fma_cell_q<NT - 1, 0>(bA, R, chh);
+            fma_cell_q<NT, 0>(aB, R, chl); fma_cell_q<NT, 0>(bB, R, chh);
+        } else {
+            fma_cell<NT - 1>(aA, R.twh[0], chl); fma_cell<NT - 1>(bA, R.twh[0], chh);
+            fma_cell<NT>(aB, R.twh[0], chl); fma_cell<NT>(bB, R.twh[0], chh);
+        }
+        RowSyn4<1>::run(R, cll, clh, chl, chh, aA, bA, aB, bB);
+    }
     // polyphase column synthesis from the circular window whose NEWEST row sits in slot `newest`:
     // y0 = (z-row 2m, 2m+1) of the pair's even column, y1 of its odd column
     static WL_DEV void col_syn(const Wave& R, const wl_v2 (&wa)[LW], const wl_v2 (&wb)[LW], int newest, wl_v2& y0, wl_v2& y1) {
@@ -431,8 +465,7 @@ struct WlSfbStrip {
                             load_row(slot + (4 + i) * a.st_pitch, chl);
                             load_row(slot + (6 + i) * a.st_pitch, chh);
                             const int w = LAT ? 0 : (2 * ph + i) % LW;
-                            waA[w] = row_syn<0>(R, cll, chl); wbA[w] = row_syn<0>(R, clh, chh);
-                            waB[w] = row_syn<1>(R, cll, chl); wbB[w] = row_syn<1>(R, clh, chh);
+                            row_syn4(R, cll, clh, chl, chh, waA[w], wbA[w], waB[w], wbB[w]);
                             wl_v2 y0A, y1A, y0B, y1B;
                             if constexpr (LAT != 0) {   // (every feed: the lattice's state; the first K - 1 outputs of a segment are the warm-up)
                                 // the lattice delivers (row 2m, row 2m+1), each packed over the pair's two columns; the direct form
