@@ -96,18 +96,23 @@ int wl_dwt2d_synthesis(const void* ll, int64_t ll_plane_stride, int ll_row_strid
  * (dwt/transform2d.py:63-74): x (planes,H,W) dense -> yh[j] (planes,3,H_j,W_j) for j < nlev and the last
  * level's low-pass yl; one workgroup streams one plane top to bottom, the intermediate LL_j stay in LDS rings and
  * HBM traffic is the algorithmic minimum.  `yh` is a HOST array of nlev device pointers.  Same taps (even length
- * L <= 12) on both axes of every level, F32/F16 data, float taps; rows of 16-byte multiples up to ~630 outputs wide;
+ * L <= 12; 14, 16, 20 in the lattice form, see `strips`) on both axes of every level, F32/F16 data, float taps; rows of 16-byte multiples up to ~630 outputs wide;
  * zero / symmetric / reflect for nlev > 1, any mode for nlev == 1.  `strips`: 0 = let the engine decide (it declines
  * below about 3/8 as many planes as compute units, where the tile kernels win; with fewer planes than compute units it
  * cuts planes in two so that every workgroup has a compute unit of its own), 1 = force this kernel, whole planes,
  * 2 = force, every plane cut in two; + 4 (bit 2) = a HINT that (h_h_lo, h_h_hi) hold the same taps as (h_w_lo, h_w_hi): the
  * 10- and 12-tap kernels then run their one-bank variant (one set of tap pairs in scalar registers), which compares the two
  * banks on the device first, with the two-bank variant queued behind it for the case that they differ (identical POINTERS for
- * both axes need no hint and no check).  Returns WL_ERR_UNSUPPORTED outside the
+ * both axes need no hint and no check); + 8 (bit 3) = a HINT that each highpass bank is the quadrature mirror of its lowpass bank.
+ * With BOTH hints and tap_scratch (NULL, or WL_TAP_SCRATCH_BYTES of device memory as for wl_dwt2d_analysis_stream) the 10- to
+ * 20-tap kernels (10, 12, 14, 16, 20) run their LATTICE variant (csrc/wl_lattice.h) behind the one-thread examination of the banks,
+ * the two-bank variant armed behind it: the only fused multi-level form of 14, 16 and 20 taps (without the hints and the scratch
+ * those lengths return WL_ERR_UNSUPPORTED); + 16 (bit 4) = tap_scratch already holds the examination of exactly these banks (an
+ * earlier launch of the same transform on this stream).  Returns WL_ERR_UNSUPPORTED outside the
  * kernel's envelope: the caller then uses wl_dwt2d_analysis level by level. */
 int wl_dwt2d_analysis_fused(const void* x, void* yl, void* const* yh, int dtype, int64_t planes, int H,
                             int W, int nlev, const void* h_w_lo, const void* h_w_hi, const void* h_h_lo,
-                            const void* h_h_hi, int L, int mode, int strips, void* stream);
+                            const void* h_h_hi, int L, int mode, int strips, void* tap_scratch, void* stream);
 
 /* All `nlev` (1..3) synthesis levels in ONE launch = the body of DWTInverse.forward's level loop
  * (dwt/transform2d.py:131-148) = nlev x SFB2D.forward (dwt/lowlevel.py:671-680): yl (planes, Kh[nlev-1],

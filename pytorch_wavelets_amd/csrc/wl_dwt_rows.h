@@ -80,6 +80,8 @@ inline wl_v2 wl_pk_mul_y(wl_v2 tap, wl_v2 s) { return wl_v2{tap.x * s.y, tap.y *
 inline wl_v2 wl_uniform_v2(wl_v2 v) { return v; }
 #endif
 
+#include "wl_lattice.h"   // the lattice form of the column pass (LAT variants), the QMF form of a tap pair
+
 struct WlRowsLevel {
     int Hs, Ws;         // source rows / cols of this level
     int Kh, Kw;         // output rows / cols
@@ -135,6 +137,8 @@ struct WlRowsArgs {
     WlRowsSeg seg[3];   // 0: whole plane, 1: top half, 2: bottom half
     int guard;          // tap-relation guard (wl_common.h): 1 = run only if the row and the column banks hold the same taps (the SAME
                         // variant), 2 = only if they do not (its armed two-bank fallback), 0 = no check
+    const float* lat;   // LAT variant and its fallback: WlTapPrep's verdict (+ the column lattice) in device scratch (wl_lattice.h): the
+                        // guard reads the verdict word instead of comparing taps
 };
 
 // The schedule the LAUNCHER steps through to fill WlRowsSeg::sched: fed[j] = next feed of level j.  A feed is one pair
@@ -167,9 +171,16 @@ struct WlRowsSched {
 #ifndef WL_ROWS_SAME_MIN
 #define WL_ROWS_SAME_MIN 10            // tap counts from which the one-bank variant exists (below, two banks fit the scalar file)
 #endif
-template <typename T, int LT, int PPR, int D = WL_ROWS_DEPTH, int SAME = 0>
+// LAT = 1 (round 5, with SAME = 1): one ORTHOGONAL bank for both axes - the row pass in the QMF form (the lowpass bank only, L/2 tap
+// pairs in scalar registers), the column pass as the lattice of wl_lattice.h: L packed FMAs and L/2 - 1 delayed values per output
+// row where the direct form needs 2L FMAs and an L-row window that is moved along every feed.  The kernel is bound by the
+// instructions its waves issue: 12 taps shed a third of them, and 14-20 taps - which the direct form cannot hold in 80
+// registers - get a fused multi-level kernel at all.
+template <typename T, int LT, int PPR, int D = WL_ROWS_DEPTH, int SAME = 0, int LAT = 0>
 struct WlAfbRows {
     typedef WlRowsArgs<T> Args;
+    static_assert(!LAT || SAME, "the lattice variant holds one bank");
+    static const int KL = LT / 2;          // rotations of the lattice
     static const int kThreads = 64 * WL_ROWS_WAVES;
     static const int kMinWaves = 6;        // two workgroups per CU: 24 waves on 4 SIMDs
     static const int LROWS = 4 / WL_ROWS_LOADERS;   // rows of a half-batch one loader wave is responsible for
@@ -252,14 +263,15 @@ struct WlAfbRows {
 
     // ---- compute waves of level j -----------------------------------------------------------------------------
     struct Lane {               // per lane
-        wl_v2 win[LT];          // row-filtered (lo,hi) of the last L extended rows of column k, oldest first
+        wl_v2 win[LAT ? (KL > 1 ? KL - 1 : 1) : LT];   // row-filtered (lo,hi) of the last L extended rows of column k, oldest first (LAT: the K - 1 delayed values)
         unsigned ob;            // byte offset of this lane's next output sample inside a band plane
         int off;                // byte offset of its first row-filter sample inside a ring row
         int ndst, hx0, hx1;     // next level's ring row: its LL sample and the halo cells it is the source of
     };
     struct Role {               // per wave (wave-uniform)
-        wl_v2 tw[LT], th[SAME ? 1 : LT];   // (lo,hi) tap pairs along W / along H
-        WL_DEV wl_v2 colt(int t) const { return SAME ? tw[t] : th[SAME ? 0 : t]; }   // column-filter tap pair t
+        wl_v2 tw[LAT ? KL : LT], th[SAME ? 1 : LT];   // (lo,hi) tap pairs along W / along H (LAT: the QMF form, (lo[u], lo[L-1-u]) g)
+        wl_v2 lt[LAT ? KL : 1];            // LAT: (T_k, -T_k) of the column lattice
+        WL_DEV wl_v2 colt(int t) const { return SAME ? tw[LAT ? 0 : t] : th[SAME ? 0 : t]; }   // column-filter tap pair t (direct form)
         char* hp0; char* hp1; char* hp2; char* llp;   // band planes of this (plane, level); LL plane of the last level
         unsigned rowb, llrowb, kb;
         int nring, npitch, rmask;
@@ -290,6 +302,20 @@ struct WlAfbRows {
     // row filter of two rows: four independent chains (even / odd taps of either row; dependent v_pk_fma_f32 need a
     // wait state in between)
     static WL_DEV void row_pass(const Role& R, const wl_v2 (&s0)[LT / 2], const wl_v2 (&s1)[LT / 2], wl_v2& a0, wl_v2& a1) {
+        if constexpr (LAT != 0) {
+            a0 = wl_qmf_mul<LT>(R.tw, 0, 0, s0[0]); a1 = wl_qmf_mul<LT>(R.tw, 0, 0, s1[0]);
+            wl_v2 b0 = wl_qmf_mul<LT>(R.tw, 1, 1, s0[0]), b1 = wl_qmf_mul<LT>(R.tw, 1, 1, s1[0]);
+#pragma unroll
+            for (int u = 1; u < LT / 2; ++u) {
+                wl_qmf_fma<LT>(a0, R.tw, 2 * u, 0, s0[u]);
+                wl_qmf_fma<LT>(a1, R.tw, 2 * u, 0, s1[u]);
+                wl_qmf_fma<LT>(b0, R.tw, 2 * u + 1, 1, s0[u]);
+                wl_qmf_fma<LT>(b1, R.tw, 2 * u + 1, 1, s1[u]);
+            }
+            a0 += b0;
+            a1 += b1;
+            return;
+        }
         a0 = wl_pk_mul_x(R.tw[0], s0[0]); a1 = wl_pk_mul_x(R.tw[0], s1[0]);
         wl_v2 b0 = wl_pk_mul_y(R.tw[1], s0[0]), b1 = wl_pk_mul_y(R.tw[1], s1[0]);
 #pragma unroll
@@ -317,6 +343,27 @@ struct WlAfbRows {
         }
         cl += cl2;
         ch += ch2;
+        emit_row<LAST, HALO>(L, R, smem, cl, ch, orow, keep);
+    }
+    // one feed of the column lattice (wl_lattice.h): (a, b) = the row-filtered pair of new rows -> cl = (ll, lh), ch = (hl, hh); the
+    // K - 1 delayed values move along by one stage (the direct form moves its L - 2 window rows)
+    static WL_DEV void lat_feed(Lane& L, const Role& R, wl_v2 a, wl_v2 b, wl_v2& cl, wl_v2& ch) {
+        wl_v2 u = wl_fma_s<0, 0>(b, R.lt[0], a);                  // a + T0 b
+        wl_v2 v = wl_fma_s<1, 0>(a, R.lt[0], b);                  // b - T0 a
+        wl_v2 hi = -v;
+#pragma unroll
+        for (int k = 1; k < KL; ++k) {
+            const wl_v2 d = L.win[k - 1];
+            L.win[k - 1] = v;
+            const wl_v2 n = wl_fma_s<0, 0>(d, R.lt[k], u);         // u + Tk v'
+            if (k < KL - 1) v = wl_fma_s<1, 0>(u, R.lt[k], d);     // v' - Tk u
+            else hi = wl_fma_s<0, 1>(u, R.lt[k], d);               // -(v' - Tk u)
+            u = n;
+        }
+        cl = wl_v2{u.x, hi.x}; ch = wl_v2{u.y, hi.y};             // the lattice filters the (row-lo, row-hi) pair: a renaming of registers
+    }
+    template <bool LAST, bool HALO>
+    static WL_DEV void emit_row(Lane& L, const Role& R, char* smem, wl_v2 cl, wl_v2 ch, int orow, bool keep) {
         const unsigned ob = L.ob;
         L.ob = ob + R.rowb;
         // keep: the row belongs to this segment (wave-uniform); halo rows of a cut plane are computed, not stored
@@ -344,11 +391,17 @@ struct WlAfbRows {
         wl_v2 s0[LT / 2], s1[LT / 2], a0, a1;
         load_rows(L, smem, row0, row1, s0, s1);
         row_pass(R, s0, s1, a0, a1);
+        if constexpr (LAT != 0) {   // (every feed: the lattice's state; the first K - 1 outputs of a segment are the warm-up)
+            wl_v2 cl, ch;
+            lat_feed(L, R, a0, a1, cl, ch);
+            if (emit) emit_row<LAST, HALO>(L, R, smem, cl, ch, orow, keep);
+        } else {
 #pragma unroll
-        for (int t = 0; t < LT - 2; ++t) L.win[t] = L.win[t + 2];
-        L.win[LT - 2] = a0;
-        L.win[LT - 1] = a1;
-        if (emit) col_pass<LAST, HALO>(L, R, smem, L.win, orow, keep);
+            for (int t = 0; t < LT - 2; ++t) L.win[t] = L.win[t + 2];
+            L.win[LT - 2] = a0;
+            L.win[LT - 1] = a1;
+            if (emit) col_pass<LAST, HALO>(L, R, smem, L.win, orow, keep);
+        }
     }
     // two feeds of the steady state (both emit): all four rows are requested from LDS before the first FMA, the
     // window moves once (by four rows) instead of twice
@@ -358,6 +411,16 @@ struct WlAfbRows {
         wl_v2 s0[LT / 2], s1[LT / 2], s2[LT / 2], s3[LT / 2];
         load_rows(L, smem, row0, row1, s0, s1);
         load_rows(L, smem, row2, row3, s2, s3);
+        if constexpr (LAT != 0) {
+            wl_v2 a0, a1, cl, ch;
+            row_pass(R, s0, s1, a0, a1);
+            lat_feed(L, R, a0, a1, cl, ch);
+            emit_row<LAST, HALO>(L, R, smem, cl, ch, orow, keep0);
+            row_pass(R, s2, s3, a0, a1);
+            lat_feed(L, R, a0, a1, cl, ch);
+            emit_row<LAST, HALO>(L, R, smem, cl, ch, orow + 1, keep1);
+            return;
+        }
         wl_v2 w[LT + 4];
 #pragma unroll
         for (int t = 0; t < LT; ++t) w[t] = L.win[t];
@@ -375,10 +438,19 @@ struct WlAfbRows {
         const int k = col0 + lane;
         const bool active = k < g.Kw;
         Role R;
+        if constexpr (LAT != 0) {
+            const float gsc = a.lat[1];                       // the lattice's gain rides on the row taps
 #pragma unroll
-        for (int t = 0; t < LT; ++t) {
-            R.tw[t] = wl_uniform_v2(wl_v2{a.h_w_lo[t], a.h_w_hi[t]});
-            if (!SAME) R.th[SAME ? 0 : t] = wl_uniform_v2(wl_v2{a.h_h_lo[t], a.h_h_hi[t]});
+            for (int u = 0; u < KL; ++u) {
+                R.tw[u] = wl_uniform_v2(wl_v2{a.h_w_lo[u] * gsc, a.h_w_lo[LT - 1 - u] * gsc});
+                R.lt[u] = wl_uniform_v2(wl_v2{a.lat[2 + u], -a.lat[2 + u]});
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < LT; ++t) {
+                R.tw[t] = wl_uniform_v2(wl_v2{a.h_w_lo[t], a.h_w_hi[t]});
+                if (!SAME) R.th[SAME ? 0 : t] = wl_uniform_v2(wl_v2{a.h_h_lo[t], a.h_h_hi[t]});
+            }
         }
         R.last = j == a.nlev - 1;
         const unsigned bplane = (unsigned)g.Kh * (unsigned)g.Kw;
@@ -392,7 +464,7 @@ struct WlAfbRows {
         R.nring = gn.ring_off; R.npitch = gn.ring_pitch;
         Lane L;
 #pragma unroll
-        for (int t = 0; t < LT; ++t) L.win[t] = wl_v2{0.f, 0.f};
+        for (int t = 0; t < (LAT ? (KL > 1 ? KL - 1 : 1) : LT); ++t) L.win[t] = wl_v2{0.f, 0.f};
         L.ob = (unsigned)sg.f0[j] * R.rowb + (unsigned)k * SZ;   // the first row this segment produces is row f0
         L.off = g.pad + (2 * (active ? k : 0) + a.base) * SZ;   // halo cells included: always >= 0
         // the halo cells of the NEXT level's ring rows whose source column is k - at most one on either side
@@ -484,7 +556,8 @@ struct WlAfbRows {
         const int tid = ctx.tid;
         const int wave = wl_uniform(tid >> 6), lane = tid & 63;
         if (LT >= WL_ROWS_SAME_MIN && a.guard) {   // "both axes filter with the same taps", checked against the taps as they are now
-            const bool holds = wl_taps_same(a.h_w_lo, a.h_h_lo, LT) && wl_taps_same(a.h_w_hi, a.h_h_hi, LT);
+            const bool holds = a.lat ? *reinterpret_cast<const unsigned*>(a.lat) == WL_LAT_OK   // (WlTapPrep's verdict: same banks, mirror pair, lattice)
+                                     : wl_taps_same(a.h_w_lo, a.h_h_lo, LT) && wl_taps_same(a.h_w_hi, a.h_h_hi, LT);
             if (!wl_guard_pass(a.guard, holds)) return;
         }
         // workgroup -> (plane, segment)

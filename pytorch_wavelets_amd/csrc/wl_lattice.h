@@ -128,6 +128,49 @@ template <int HI, int NZ> WL_DEV wl_v2 wl_fma_s(wl_v2 w, wl_v2 pair, wl_v2 z) {
     return d;
 }
 
+// ---- the quadrature-mirror form of a tap pair -------------------------------------------------------------------------
+// bank[u] = (lo[u], lo[L-1-u]), u < L/2, in scalar registers; the pair of tap t is (lo[t], hi[t]) with hi[t] = (-1)^t lo[L-1-t]:
+// bank[u] or bank[u] with its halves swapped, the high half negated for odd t - operand modifiers of the packed FMA.
+// acc (+)= (lo[t], hi[t]) * s.x (xy = 0) / s.y (xy = 1); t and xy are compile-time after unrolling: exactly one form survives.
+template <int LT> WL_DEV void wl_qmf_fma(wl_v2& acc, const wl_v2 (&bank)[LT / 2], int t, int xy, wl_v2 s) {
+    const int u = t < LT / 2 ? t : LT - 1 - t;
+    const bool sw = t >= LT / 2, neg = t & 1;
+#if defined(__HIPCC__)
+    if (!sw && !neg) { if (xy) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(bank[u]), "v"(s));
+                       else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(bank[u]), "v"(s)); }
+    else if (!sw && neg) { if (xy) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_hi:[1,0,0]" : "+v"(acc) : "s"(bank[u]), "v"(s));
+                           else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "+v"(acc) : "s"(bank[u]), "v"(s)); }
+    else if (sw && !neg) { if (xy) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(bank[u]), "v"(s));
+                           else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]" : "+v"(acc) : "s"(bank[u]), "v"(s)); }
+    else { if (xy) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "+v"(acc) : "s"(bank[u]), "v"(s));
+           else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "+v"(acc) : "s"(bank[u]), "v"(s)); }
+#else
+    const float c = xy ? s.y : s.x;
+    const float lo = sw ? bank[u].y : bank[u].x, hi = (sw ? bank[u].x : bank[u].y) * (neg ? -1.f : 1.f);
+    acc.x = __builtin_fmaf(lo, c, acc.x); acc.y = __builtin_fmaf(hi, c, acc.y);
+#endif
+}
+template <int LT> WL_DEV wl_v2 wl_qmf_mul(const wl_v2 (&bank)[LT / 2], int t, int xy, wl_v2 s) {
+    const int u = t < LT / 2 ? t : LT - 1 - t;
+    const bool sw = t >= LT / 2, neg = t & 1;
+    wl_v2 r;
+#if defined(__HIPCC__)
+    if (!sw && !neg) { if (xy) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "s"(bank[u]), "v"(s));
+                       else asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "s"(bank[u]), "v"(s)); }
+    else if (!sw && neg) { if (xy) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_hi:[1,0]" : "=v"(r) : "s"(bank[u]), "v"(s));
+                           else asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "s"(bank[u]), "v"(s)); }
+    else if (sw && !neg) { if (xy) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(r) : "s"(bank[u]), "v"(s));
+                           else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0]" : "=v"(r) : "s"(bank[u]), "v"(s)); }
+    else { if (xy) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(r) : "s"(bank[u]), "v"(s));
+           else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "s"(bank[u]), "v"(s)); }
+#else
+    const float c = xy ? s.y : s.x;
+    const float lo = sw ? bank[u].y : bank[u].x, hi = (sw ? bank[u].x : bank[u].y) * (neg ? -1.f : 1.f);
+    r.x = lo * c; r.y = hi * c;
+#endif
+    return r;
+}
+
 // ---- the one-thread kernel in front of a lattice launch ---------------------------------------------------------------
 // Verdict + factorisation of the COLUMN bank (h_h_*) into `out` (WL_TAP_SCRATCH_FLOATS floats of device memory the caller
 // owns for the duration of the launches that read it): accepted iff both highpass banks are the quadrature mirrors of their
@@ -138,6 +181,7 @@ struct WlTapPrepArgs {
     int L;
     float tol;
     int syn;               // the banks are a synthesis pair (WlSfbStrip) / an analysis pair (WlAfbStrip)
+    int same;              // the kernel behind holds ONE bank for both axes (the fused multi-level kernels): w and h banks must be equal
 };
 template <int LT>
 struct WlTapPrep {
@@ -151,6 +195,7 @@ struct WlTapPrep {
 #pragma unroll
         for (int k = 0; k < LT / 2; ++k) T[k] = 0.f;
         bool ok = wl_taps_qmf(a.h_w_lo, a.h_w_hi, LT) && wl_taps_qmf(a.h_h_lo, a.h_h_hi, LT);
+        if (a.same) ok = ok & wl_taps_same(a.h_w_lo, a.h_h_lo, LT) & wl_taps_same(a.h_w_hi, a.h_h_hi, LT);
         ok = wl_lattice_factor<LT>(a.h_h_lo, a.h_h_hi, (double)a.tol, &g, T, a.syn != 0) && ok;
         if (ctx.tid != 0) return;
         unsigned* flag = reinterpret_cast<unsigned*>(a.out);

@@ -239,7 +239,7 @@ def _hinted_taps(bufs, ref, L, syn):
     ent = cache.get(key) if cache is not None else None
     if ent is None:
         taps = tuple(_taps(b, ref) for b in bufs)
-        scratch = torch.empty(TAP_SCRATCH_FLOATS, dtype=torch.float32, device=ref.device) if L >= 12 and STRIP_LATTICE else None
+        scratch = torch.empty(TAP_SCRATCH_FLOATS, dtype=torch.float32, device=ref.device) if L >= min(10, ROWS_LATTICE_MIN) and (STRIP_LATTICE or ROWS_LATTICE) else None
         ent = [taps, scratch, 0]
         if cache is not None:
             cache[key] = ent
@@ -327,18 +327,24 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None):
     N, C, H, W = x.shape
     L = h_w_lo.numel()
     # the launcher's envelope, checked here first so that a decline costs no allocation
-    if (x.dtype == torch.float64 or nlev < 1 or nlev > 3 or h_h_lo.numel() != L or L % 2 or L > 12
+    # hints (bits 2, 3 of `strips`): the row and the column banks hold the same taps / each highpass bank is the quadrature mirror
+    # of its lowpass bank - HINTS: the kernel variants that rely on them verify them on the device, the two-bank variant stands by
+    # behind them, so a stale hint costs an empty launch, never a wrong coefficient.  With both, 10-20 taps run the LATTICE variant
+    # (csrc/wl_lattice.h): the only fused form of 14, 16 and 20 taps.
+    same = bool(getattr(_HINTS, 'same', False))
+    qmf = bool(getattr(_HINTS, 'qmf', False))
+    lattice = same and qmf and ROWS_LATTICE and L in (8, 10, 12, 14, 16, 20) and L >= ROWS_LATTICE_MIN
+    if (x.dtype == torch.float64 or nlev < 1 or nlev > 3 or h_h_lo.numel() != L or L % 2 or (L > 12 and not lattice)
             or (W * x.element_size()) % 16 or (nlev > 1 and mode not in (0, 1, 4)) or x.numel() == 0
             or (strips == 0 and 8 * N * C < 3 * _num_cus(x.device)) or strips > 2):
         return None
     x = x.contiguous()
-    key = ('afb', x.device, x.dtype, N * C, H, W, L, mode, nlev, strips)
+    key = ('afb', x.device, x.dtype, N * C, H, W, L, mode, nlev, strips, lattice)
     if key in _FUSED_DECLINED or x.data_ptr() % 16:
         return None
-    hwl, hwh, hhl, hhh = (_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi))
-    # same_banks_hint: bit 2 of `strips` - a HINT; the one-bank kernel variant compares the two banks on the device and the
-    # two-bank variant stands by behind it, so a stale hint costs an empty launch, never a wrong coefficient
-    same = 4 if getattr(_HINTS, 'same', False) else 0
+    ent = _hinted_taps((h_w_lo, h_w_hi, h_h_lo, h_h_hi), x, L, False) if lattice else [tuple(_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi)), None, 0]
+    (hwl, hwh, hhl, hhh), scratch, prepared = ent
+    same = (4 if same else 0) | (8 if qmf else 0) | (16 if prepared else 0)
     yh = []
     h, w = H, W
     for _ in range(nlev):
@@ -347,11 +353,13 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None):
     yl = torch.empty((N, C, h, w), dtype=x.dtype, device=x.device)
     ptrs = (ctypes.c_void_p * nlev)(*[t.data_ptr() for t in yh])
     rc = _call('wl_dwt2d_analysis_fused', x, x.data_ptr(), yl.data_ptr(), ptrs, _DTYPES[x.dtype], N * C, H, W, nlev,
-               hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(), hhh.data_ptr(), L, mode, strips | same, _stream(x))
+               hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(), hhh.data_ptr(), L, mode, strips | same,
+               None if scratch is None else scratch.data_ptr(), _stream(x))
     if rc == -3:
         _remember_decline(key)
         return None
     _lib.check(rc, 'wl_dwt2d_analysis_fused')
+    _mark_prepared(ent)
     return yl, yh
 
 
@@ -487,6 +495,8 @@ STRIP_MINW_F16 = 256
 ISTRIP_MINW_F16 = 0
 TAP_SCRATCH_FLOATS = 16   # WL_TAP_SCRATCH_FLOATS of csrc/wl_lattice.h
 STRIP_LATTICE = True      # hinted strip launches of 12 taps and more run the lattice variant (False: the QMF variant; A/B measurements)
+ROWS_LATTICE = True       # hinted fused analysis launches of 10-20 taps run the lattice variant (False: A/B measurements; 14-20 taps then go level by level)
+ROWS_LATTICE_MIN = 10     # WL_ROWS_LAT_MIN of csrc/wl_rows_api.inc (8 in the A/B build that tries the lattice on the metric's kernel)
 
 
 def afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=False):

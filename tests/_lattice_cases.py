@@ -233,10 +233,20 @@ def check_lattice_levels_share_one_examination(dev, shape=(1, 2, 128, 1024)):
 def check_tile_kernels_14_18_taps(dev, wave, shape=(2, 2, 100, 104)):
     """db7 / sym7 (14 taps) and db9 / sym9 (18 taps) on the compile-time-tap tile kernels (round 5: before, every narrow level
     of theirs ran on the run-time-tap kernel): J = 2 forward and inverse, every mode, float32 + float16, against the oracle."""
+    from pytorch_wavelets_amd.dwt import lowlevel as _ll
     rng = np.random.RandomState(53)
     h0, h1 = F.dwt_analysis_taps(wave)
     g0, g1 = F.dwt_synthesis_taps(wave)
     L = len(h0)
+    prev = _ll.FUSED_LEVELS
+    _ll.FUSED_LEVELS = False      # (one launch per level: with enough planes 14 taps now have a fused lattice kernel of their own)
+    try:
+        _tile_14_18_modes(dev, wave, shape, rng, h0, h1, g0, g1, L)
+    finally:
+        _ll.FUSED_LEVELS = prev
+
+
+def _tile_14_18_modes(dev, wave, shape, rng, h0, h1, g0, g1, L):
     for mode in ('zero', 'symmetric', 'periodization', 'reflect', 'periodic'):
         for dt, tol in ((torch.float32, 1e-5), (torch.float16, 4e-3)):
             x = torch.tensor(rng.randn(*shape)).to(dt).to(dev)
@@ -254,3 +264,77 @@ def check_tile_kernels_14_18_taps(dev, wave, shape=(2, 2, 100, 104)):
             orec = wo.dwt_inverse(yl.detach().cpu().double().numpy(), [h.detach().cpu().double().numpy() for h in yh], g0, g1, g0, g1, mode)
             errs = [_rel(yl, oyl)] + [_rel(a, b) for a, b in zip(yh, oyh)] + [_rel(r, orec)]
             assert max(errs) <= tol, (wave, mode, dt, errs)
+
+
+ROWS_LATTICE_CASES = [('db5', 'symmetric', 3), ('db6', 'zero', 3), ('sym7', 'reflect', 2), ('db8', 'symmetric', 3), ('sym8', 'zero', 2),
+                      ('db10', 'symmetric', 2), ('coif2', 'reflect', 3), ('db7', 'symmetric', 3)]
+
+
+def _is_lattice_rows(name):
+    return 'WlAfbRows<' in name and name.endswith(', 3, 1, 1>')
+
+
+def check_rows_lattice_vs_oracle(dev, wave, mode, J, shape=(2, 3, 128, 256), dtype=torch.float32):
+    """The fused multi-level analysis kernel in its lattice form (WlAfbRows<.., SAME = 1, LAT = 1>, 10-20 taps: the only fused
+    form of 14, 16 and 20 taps): DWTForward on the (forced) streaming kernel against the oracle on the module's taps."""
+    from pytorch_wavelets_amd import ops
+    rng = np.random.RandomState(59)
+    prev = ops.FUSED_STRIPS
+    ops.FUSED_STRIPS = 1
+    try:
+        x = torch.tensor(rng.randn(*shape), device=dev).to(dtype)
+        xfm = pw.DWTForward(J=J, wave=wave, mode=mode).to(dev).to(dtype)
+        c0 = pw.launch_count()
+        yl, yh = xfm(x)
+        ks = pw.kernels_since(c0)
+        prim = [k for k in ks if not k.endswith(')')]
+        assert prim and all(_is_lattice_rows(k) for k in prim) and ks[0].startswith('WlTapPrep') and ks[-1].endswith('(armed fallback)'), ks
+        oyl, oyh = wo.dwt_forward(x.detach().cpu().double().numpy(), J, _flat(xfm.h0_col), _flat(xfm.h1_col),
+                                  _flat(xfm.h0_row), _flat(xfm.h1_row), mode)
+        tol = 1e-5 if dtype == torch.float32 else 4e-3
+        errs = [_rel(yl, oyl)] + [_rel(a, b) for a, b in zip(yh, oyh)]
+        assert max(errs) <= tol, (wave, mode, J, errs)
+        return max(errs)
+    finally:
+        ops.FUSED_STRIPS = prev
+
+
+def check_rows_lattice_rejections(dev, dtype=torch.float32, shape=(2, 2, 96, 256), tol=1e-5):
+    """Banks the fused lattice launch cannot take - the device rejects them and the armed two-bank kernel does the work (for 16
+    taps that is the direct-form kernel that exists for this purpose only): a random mirror pair on both axes, the column bank
+    edited through `.data` (the hints go stale), the banks of the two axes differing through `.data`."""
+    from pytorch_wavelets_amd import ops
+    rng = np.random.RandomState(61)
+    prev = ops.FUSED_STRIPS
+    ops.FUSED_STRIPS = 1
+    try:
+        x = torch.tensor(rng.randn(*shape), device=dev).to(dtype)
+
+        def run(xfm, J, what):
+            c0 = pw.launch_count()
+            yl, yh = xfm(x)
+            ks = pw.kernels_since(c0)
+            assert any(_is_lattice_rows(k) for k in ks) and ks[-1].endswith('(armed fallback)'), (what, ks)
+            oyl, oyh = wo.dwt_forward(x.detach().cpu().double().numpy(), J, _flat(xfm.h0_col), _flat(xfm.h1_col),
+                                      _flat(xfm.h0_row), _flat(xfm.h1_row), 'symmetric')
+            errs = [_rel(yl, oyl)] + [_rel(a, b) for a, b in zip(yh, oyh)]
+            assert max(errs) <= tol, (what, errs)
+
+        for L in (12, 16):
+            sign = np.array([1.0, -1.0] * (L // 2))
+            lo = rng.randn(L) / 3
+            hi = sign * lo[::-1]
+            xfm = pw.DWTForward(J=2, wave=(lo[::-1].copy(), hi[::-1].copy()), mode='symmetric').to(dev).to(dtype)
+            assert ops.is_qmf_pair(xfm.h0_col, xfm.h1_col)
+            run(xfm, 2, 'random mirror pair, %d taps' % L)
+        for wave in ('db6', 'db8'):
+            xfm = pw.DWTForward(J=2, wave=wave, mode='symmetric').to(dev).to(dtype)
+            run(xfm, 2, 'pristine ' + wave)
+            xfm.h0_col.data[0, 0, 3, 0] += 0.125
+            run(xfm, 2, wave + ': h0_col.data[...] +=')
+            xfm = pw.DWTForward(J=2, wave=wave, mode='symmetric').to(dev).to(dtype)
+            run(xfm, 2, 'pristine (2) ' + wave)
+            xfm.h1_row.data.mul_(2.0)
+            run(xfm, 2, wave + ': h1_row.data.mul_')
+    finally:
+        ops.FUSED_STRIPS = prev

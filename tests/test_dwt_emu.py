@@ -348,9 +348,12 @@ def test_same_banks_variant_of_the_streaming_analysis(wave):
         c0 = pw.launch_count()
         yl2, yh2 = m(x)
         ks2 = pw.kernels_since(c0)
-    # (the one-bank variant checks its relation on the device; the two-bank variant stands by behind it as an armed fallback)
-    assert len(ks) == 2 and ks[0].endswith(', 3, 1>') and ks[1].endswith('(armed fallback)'), ks
-    assert len(ks2) == 1 and 'WlAfbRows' in ks2[0] and not ks2[0].endswith(', 3, 1>'), ks2
+    # (the one-bank variant - round 5: its lattice form, behind the one-thread examination of the banks - checks its relation on
+    # the device; the two-bank variant stands by behind it as an armed fallback)
+    import _mutation_cases as M
+    prim = M.primary(ks)
+    assert len(prim) == 1 and M.is_one_bank_rows(prim[0]) and ks[-1].endswith('(armed fallback)'), ks
+    assert len(ks2) == 1 and 'WlAfbRows' in ks2[0] and not M.is_one_bank_rows(ks2[0]), ks2
     oyl, oyh = wo.dwt_forward(x.double().numpy(), 3, h0, h1, h0, h1, 'symmetric')
     for got, want in zip([yl] + list(yh), [oyl] + list(oyh)):
         assert np.abs(got.numpy() - want).max() <= 1e-5 * np.abs(want).max()
@@ -906,3 +909,19 @@ def test_tile_kernels_for_14_and_18_taps(wave):
     import _lattice_cases as LC
     with emu_backend.emulated():
         LC.check_tile_kernels_14_18_taps('cpu', wave)
+
+
+@pytest.mark.parametrize('wave,mode,J', __import__('_lattice_cases').ROWS_LATTICE_CASES)
+def test_lattice_variant_of_the_fused_analysis_kernel(wave, mode, J):
+    """csrc/wl_lattice.h in the fused multi-level analysis kernel (WlAfbRows<.., 1, 1>): 10-20 taps, all levels in one launch,
+    float32 and float16, against the oracle."""
+    import _lattice_cases as LC
+    with emu_backend.emulated():
+        LC.check_rows_lattice_vs_oracle('cpu', wave, mode, J, shape=(1, 2, 96, 128))
+        LC.check_rows_lattice_vs_oracle('cpu', wave, mode, J, shape=(1, 3, 100, 264), dtype=torch.float16)
+
+
+def test_lattice_variant_of_the_fused_analysis_kernel_rejections():
+    import _lattice_cases as LC
+    with emu_backend.emulated():
+        LC.check_rows_lattice_rejections('cpu', shape=(1, 2, 80, 128))

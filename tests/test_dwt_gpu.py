@@ -871,3 +871,18 @@ def test_lattice_levels_share_one_examination():
 def test_tile_kernels_for_14_and_18_taps(wave):
     import _lattice_cases as LC
     LC.check_tile_kernels_14_18_taps(DEV, wave, shape=(4, 3, 200, 232))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('wave,mode,J', __import__('_lattice_cases').ROWS_LATTICE_CASES)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_lattice_variant_of_the_fused_analysis_kernel(wave, mode, J, dtype):
+    import _lattice_cases as LC
+    LC.check_rows_lattice_vs_oracle(DEV, wave, mode, J, shape=(3, 3, 200, 512), dtype=dtype)
+    LC.check_rows_lattice_vs_oracle(DEV, wave, mode, J, shape=(2, 2, 136, 200), dtype=dtype)
+
+
+@pytest.mark.gpu
+def test_lattice_variant_of_the_fused_analysis_kernel_rejections():
+    import _lattice_cases as LC
+    LC.check_rows_lattice_rejections(DEV, shape=(3, 2, 160, 512))

@@ -13,6 +13,10 @@ import bench
 tag = sys.argv[1] if len(sys.argv) > 1 else os.environ.get('WL_PKG_ROOT', 'new')
 if os.environ.get('WL_NO_LATTICE'):
     ops.STRIP_LATTICE = False
+    if hasattr(ops, 'ROWS_LATTICE'):
+        ops.ROWS_LATTICE = False
+if os.environ.get('WL_ROWS_LAT8'):          # with WL_LIB=ab/libwl_lat8.so (-DWL_ROWS_LAT_MIN=8): the lattice on the metric's forward kernel
+    ops.ROWS_LATTICE_MIN = 8
 dev = 'cuda:0'; sync = torch.cuda.synchronize
 out = {}
 def t(name, fn, n=30):
@@ -21,9 +25,11 @@ def t(name, fn, n=30):
         ms = min(bench.time_seq_fn(fn, n, sync) for _ in range(3))
     out[name] = round(ms, 4); out[name + '_k'] = [k.replace('float', 'f') for k in ks]
 x = torch.randn(128, 3, 512, 512, device=dev)
-for wave in ('db4', 'db6'):
+for wave in ('db4', 'db5', 'db6'):
     m = pw.DWTForward(J=3, wave=wave, mode='symmetric').to(dev); t('fwd_' + wave, lambda: m(x))
     yl, yh = m(x); im = pw.DWTInverse(wave=wave, mode='symmetric').to(dev); t('inv_' + wave, lambda: im((yl, yh)))
+for wave in ('db7', 'db10', 'sym8'):
+    mm = pw.DWTForward(J=3, wave=wave, mode='symmetric').to(dev); t('fwd_' + wave, lambda: mm(x))
 m8 = pw.DWTForward(J=3, wave='db8', mode='symmetric').to(dev); t('fwd_db8', lambda: m8(x))
 yl, yh = m8(x); i8 = pw.DWTInverse(wave='db8', mode='symmetric').to(dev); t('inv_db8', lambda: i8((yl, yh)))
 del x, yl, yh
