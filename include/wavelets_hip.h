@@ -124,12 +124,14 @@ int wl_dwt2d_analysis_fused(const void* x, void* yl, void* const* yh, int dtype,
  * intermediate low-passes stay in LDS rings, every coefficient is read from HBM once (LDS-DMA in whole 1024-byte
  * chunks of the contiguous band planes) and x is written once.  Same even tap count L <= 12 on both axes of every
  * level, F32/F16 data, float taps; zero / symmetric / reflect / periodic (not periodization); row bytes and plane
- * bytes multiples of four.  `strips` as for wl_dwt2d_analysis_fused.  Returns WL_ERR_UNSUPPORTED outside the
+ * bytes multiples of four.  `strips` (incl. the hint bits 2-4) and tap_scratch as for wl_dwt2d_analysis_fused: with both hints and
+ * the scratch the 10-20 tap kernels run their lattice variant (the transposed recurrence of csrc/wl_lattice.h) - the only fused
+ * form of 14, 16 and 20 taps.  Returns WL_ERR_UNSUPPORTED outside the
  * kernel's envelope: the caller then uses wl_dwt2d_synthesis level by level. */
 int wl_dwt2d_synthesis_fused(const void* yl, int64_t yl_plane_stride, int yl_row_stride, int yl_h, int yl_w,
                              const void* const* yh, const int* Kh, const int* Kw, void* y, int dtype,
                              int64_t planes, int nlev, const void* g_w_lo, const void* g_w_hi,
-                             const void* g_h_lo, const void* g_h_hi, int L, int mode, int strips, void* stream);
+                             const void* g_h_lo, const void* g_h_hi, int L, int mode, int strips, void* tap_scratch, void* stream);
 
 /* Non-separable one-level analysis / synthesis with four Ly x Lx point-spread functions = afb2d_nonsep
  * (dwt/lowlevel.py:524-597) / sfb2d_nonsep (:746-798).  `f` / `g`: (4, Ly, Lx) device taps in the accumulate dtype,

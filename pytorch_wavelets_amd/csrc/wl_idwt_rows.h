@@ -22,6 +22,7 @@
 #pragma once
 #include "wl_common.h"
 #include "wl_dwt_rows.h"   // wl_pk_fma_x / _y, wl_pk_mul_x / _y, wl_uniform_v2
+#include "wl_lattice.h"
 
 #define WL_IROWS_MAXLEV 3
 #define WL_IROWS_WAVES 14
@@ -80,6 +81,8 @@ struct WlIRowsArgs {
     int pp, lds_plane;
     WlIRowsLevel g[WL_IROWS_MAXLEV];
     WlIRowsSeg seg[3];             // 0: whole plane, 1: top half, 2: bottom half
+    int guard;                     // tap-relation guard (wl_common.h) of the lattice variant (1) and its armed four-bank fallback (2); 0 = no check
+    const float* lat;              // WlTapPrep's verdict (+ the column lattice for LAT = 1) in device scratch (wl_lattice.h)
 };
 
 // Host-side schedule of one segment (also documents the rules the table encodes).
@@ -106,7 +109,11 @@ struct WlIRowsSched {
     }
 };
 
-template <typename T, int LT>
+// LAT = 1 (round 5): ONE orthogonal bank for both axes - the row synthesis in the quadrature-mirror form (the lowpass pairs only),
+// the column synthesis as the transposed lattice of wl_lattice.h: L packed FMAs and L/2 - 1 delayed values per coefficient row
+// where the direct form needs 2L FMAs, two (L/2 - 1)-row windows and four banks of tap pairs in scalar registers (at 16 taps
+// more than the scalar file holds: the direct form stops at 12).
+template <typename T, int LT, int LAT = 0>
 struct WlSfbRows {
     typedef WlIRowsArgs<T> Args;
     static const int kThreads = 64 * WL_IROWS_WAVES;
@@ -200,7 +207,8 @@ struct WlSfbRows {
     static const int NP = (HL + 1) / 2;        // coefficient pairs a lane reads per band row
     static const int NW = HL > 1 ? HL - 1 : 1; // rows of history in the window
     struct Wave {                              // per-wave / per-lane constants of a compute wave
-        wl_v2 gw0[HL], gw1[HL], gh0[HL], gh1[HL];   // (g[2t], g[2t+1]) tap pairs, wave-uniform
+        wl_v2 gw0[HL], gw1[LAT ? 1 : HL], gh0[LAT ? 1 : HL], gh1[LAT ? 1 : HL];   // (g[2t], g[2t+1]) tap pairs, wave-uniform (LAT: gw0 g only)
+        wl_v2 lt[LAT ? HL : 1];                // LAT: (T_k, -T_k) of the column lattice
         int coff;                              // byte offset of this lane's first coefficient in a ring row
         int llmask;                            // row mask of this level's low-pass source ring
         bool two;                              // the second column of the pair exists (odd widths: not for the last pair)
@@ -230,11 +238,27 @@ struct WlSfbRows {
         load_coeffs(smem + (g.src_off[3] + rb + R.coff), vhh);
         na = wl_pk_mul_x(R.gw0[HL - 1], vll[0]);
         nb = wl_pk_mul_x(R.gw0[HL - 1], vlh[0]);
-        wl_pk_fma_x(na, R.gw1[HL - 1], vhl[0]);
-        wl_pk_fma_x(nb, R.gw1[HL - 1], vhh[0]);
+        if constexpr (LAT != 0) {   // the highpass pair of tap pair t = q(lowpass pair HL-1-t): the lowpass bank alone
+            wl_qmf_syn_fma<0>(na, R.gw0[0], vhl[0]);
+            wl_qmf_syn_fma<0>(nb, R.gw0[0], vhh[0]);
+#pragma unroll
+            for (int u = 1; u < HL; ++u) {
+                const int t = HL - 1 - u;
+                if (u & 1) {
+                    wl_pk_fma_y(na, R.gw0[t], vll[u / 2]); wl_pk_fma_y(nb, R.gw0[t], vlh[u / 2]);
+                    wl_qmf_syn_fma<1>(na, R.gw0[u], vhl[u / 2]); wl_qmf_syn_fma<1>(nb, R.gw0[u], vhh[u / 2]);
+                } else {
+                    wl_pk_fma_x(na, R.gw0[t], vll[u / 2]); wl_pk_fma_x(nb, R.gw0[t], vlh[u / 2]);
+                    wl_qmf_syn_fma<0>(na, R.gw0[u], vhl[u / 2]); wl_qmf_syn_fma<0>(nb, R.gw0[u], vhh[u / 2]);
+                }
+            }
+            return;
+        }
+        wl_pk_fma_x(na, R.gw1[LAT ? 0 : HL - 1], vhl[0]);
+        wl_pk_fma_x(nb, R.gw1[LAT ? 0 : HL - 1], vhh[0]);
 #pragma unroll
         for (int u = 1; u < HL; ++u) {
-            const int t = HL - 1 - u;
+            const int t = LAT ? 0 : HL - 1 - u;
             if (u & 1) {
                 wl_pk_fma_y(na, R.gw0[t], vll[u / 2]); wl_pk_fma_y(nb, R.gw0[t], vlh[u / 2]);
                 wl_pk_fma_y(na, R.gw1[t], vhl[u / 2]); wl_pk_fma_y(nb, R.gw1[t], vhh[u / 2]);
@@ -243,6 +267,22 @@ struct WlSfbRows {
                 wl_pk_fma_x(na, R.gw1[t], vhl[u / 2]); wl_pk_fma_x(nb, R.gw1[t], vhh[u / 2]);
             }
         }
+    }
+    // one coefficient row of the column lattice (wl_lattice.h, the transposed recurrence): (a, b) = the row-synthesised lowpass /
+    // highpass row, packed over the lane's two columns -> y0 = (row m, row m+1) of column n, y1 of column n+1; the K - 1 delayed
+    // values (S = the wa window) move along by one stage
+    static WL_DEV void lat_feed(const Wave& R, wl_v2 (&S)[NW], wl_v2 a, wl_v2 b, wl_v2& y0, wl_v2& y1) {
+        wl_v2 q = wl_fma_s<0, 1>(a, R.lt[HL - 1], b);              // T a - b
+        wl_v2 p = wl_fma_s<0, 0>(b, R.lt[HL - 1], a);              // a + T b
+#pragma unroll
+        for (int k = HL - 1; k >= 1; --k) {
+            const wl_v2 d = S[k - 1];
+            S[k - 1] = q;
+            const wl_v2 n = wl_fma_s<1, 0>(d, R.lt[k - 1], p);     // p - T q'
+            q = wl_fma_s<0, 0>(p, R.lt[k - 1], d);                 // q' + T p
+            p = n;
+        }
+        y0 = wl_v2{p.x, q.x}; y1 = wl_v2{p.y, q.y};                // (row m, row m+1) per column: a renaming of registers
     }
     // polyphase column synthesis from HL consecutive window rows e[OFF .. OFF+HL-1] (oldest first): y0 = (row m, row m+1)
     // of column n (.x of the window pairs), y1 of column n+1 (.y)
@@ -253,10 +293,10 @@ struct WlSfbRows {
         wl_pk_fma_y(y1, R.gh1[0], eb[OFF + HL - 1]);
 #pragma unroll
         for (int t = 1; t < HL; ++t) {
-            wl_pk_fma_x(y0, R.gh0[t], ea[OFF + HL - 1 - t]);
-            wl_pk_fma_y(y1, R.gh0[t], ea[OFF + HL - 1 - t]);
-            wl_pk_fma_x(y0, R.gh1[t], eb[OFF + HL - 1 - t]);
-            wl_pk_fma_y(y1, R.gh1[t], eb[OFF + HL - 1 - t]);
+            wl_pk_fma_x(y0, R.gh0[LAT ? 0 : t], ea[OFF + HL - 1 - t]);
+            wl_pk_fma_y(y1, R.gh0[LAT ? 0 : t], ea[OFF + HL - 1 - t]);
+            wl_pk_fma_x(y0, R.gh1[LAT ? 0 : t], eb[OFF + HL - 1 - t]);
+            wl_pk_fma_y(y1, R.gh1[LAT ? 0 : t], eb[OFF + HL - 1 - t]);
         }
     }
     // output rows m, m+1: to x (8 contiguous bytes per lane and row), or into the low-pass ring of the level below
@@ -303,12 +343,21 @@ struct WlSfbRows {
         const int c = c0 + lane;                         // column pair: output columns 2c, 2c+1
         const bool active = 2 * c < g.OW;
         Wave R;
+        if constexpr (LAT != 0) {
+            const float gsc = a.lat[1];                       // the lattice's gain rides on the row-synthesis taps
 #pragma unroll
-        for (int t = 0; t < HL; ++t) {
-            R.gw0[t] = wl_uniform_v2(wl_v2{a.g_w_lo[2 * t], a.g_w_lo[2 * t + 1]});
-            R.gw1[t] = wl_uniform_v2(wl_v2{a.g_w_hi[2 * t], a.g_w_hi[2 * t + 1]});
-            R.gh0[t] = wl_uniform_v2(wl_v2{a.g_h_lo[2 * t], a.g_h_lo[2 * t + 1]});
-            R.gh1[t] = wl_uniform_v2(wl_v2{a.g_h_hi[2 * t], a.g_h_hi[2 * t + 1]});
+            for (int t = 0; t < HL; ++t) {
+                R.gw0[t] = wl_uniform_v2(wl_v2{a.g_w_lo[2 * t] * gsc, a.g_w_lo[2 * t + 1] * gsc});
+                R.lt[t] = wl_uniform_v2(wl_v2{a.lat[2 + t], -a.lat[2 + t]});
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < HL; ++t) {
+                R.gw0[t] = wl_uniform_v2(wl_v2{a.g_w_lo[2 * t], a.g_w_lo[2 * t + 1]});
+                R.gw1[t] = wl_uniform_v2(wl_v2{a.g_w_hi[2 * t], a.g_w_hi[2 * t + 1]});
+                R.gh0[t] = wl_uniform_v2(wl_v2{a.g_h_lo[2 * t], a.g_h_lo[2 * t + 1]});
+                R.gh1[t] = wl_uniform_v2(wl_v2{a.g_h_hi[2 * t], a.g_h_hi[2 * t + 1]});
+            }
         }
         R.coff = (active ? c : 0) * SZ;
         R.llmask = g.ll_rows - 1;
@@ -342,6 +391,18 @@ struct WlSfbRows {
             if (!active || (WL_IROWS_ABLATE & 4)) continue;
             const int m = 2 * (k - WARM);
             wl_v2 y0, y1;
+            if constexpr (LAT != 0) {                    // (every feed: the lattice's state; its first K - 1 outputs of a segment are the warm-up)
+                wl_v2 na, nb;
+                row_syn(g, R, smem, k, na, nb);
+                lat_feed(R, wa, na, nb, y0, y1);
+                if (k - f0 >= WARM) emit<j>(R, smem, m, y0, y1);
+                if (n == 2) {
+                    row_syn(g, R, smem, k + 1, na, nb);
+                    lat_feed(R, wa, na, nb, y0, y1);
+                    if (k + 1 - f0 >= WARM) emit<j>(R, smem, m + 2, y0, y1);
+                }
+                continue;
+            }
             if (n == 2) {                                // two coefficient rows: one window move for both
                 wl_v2 ea[HL + 1], eb[HL + 1];
                 row_syn(g, R, smem, k, ea[HL - 1], eb[HL - 1]);
@@ -371,6 +432,10 @@ struct WlSfbRows {
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
         const int tid = ctx.tid;
         const int wave = wl_uniform(tid >> 6), lane = tid & 63;
+        if (LT >= WL_ROWS_SAME_MIN && a.guard) {   // the lattice variant / its armed fallback: WlTapPrep's verdict on the banks as they are now
+            const bool holds = a.lat && *reinterpret_cast<const unsigned*>(a.lat) == WL_LAT_OK;
+            if (!wl_guard_pass(a.guard, holds)) return;
+        }
         const int64_t bid = ctx.bid;
         const int sub = wl_uniform(a.role_sub[wave]);
         const int64_t plane = (bid < a.nwhole ? bid : a.nwhole + (bid - a.nwhole) / 2) * a.pp + sub;

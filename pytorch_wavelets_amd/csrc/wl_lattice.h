@@ -171,6 +171,18 @@ template <int LT> WL_DEV wl_v2 wl_qmf_mul(const wl_v2 (&bank)[LT / 2], int t, in
     return r;
 }
 
+// synthesis: the highpass pair of tap pair j is the lowpass pair read backwards with its halves swapped and one half negated,
+// (g1[2j], g1[2j+1]) = (g0[L-1-2j], -g0[L-2-2j]) = q(pair[L/2-1-j]), q(p) = (p.y, -p.x):  acc += q(pair) * s.x (Y = 0) / s.y (Y = 1)
+template <int Y> WL_DEV void wl_qmf_syn_fma(wl_v2& acc, wl_v2 pair, wl_v2 sv) {
+#if defined(__HIPCC__)
+    if (Y) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "+v"(acc) : "s"(pair), "v"(sv));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "+v"(acc) : "s"(pair), "v"(sv));
+#else
+    const float c = Y ? sv.y : sv.x;
+    acc.x = __builtin_fmaf(pair.y, c, acc.x); acc.y = __builtin_fmaf(-pair.x, c, acc.y);
+#endif
+}
+
 // ---- the one-thread kernel in front of a lattice launch ---------------------------------------------------------------
 // Verdict + factorisation of the COLUMN bank (h_h_*) into `out` (WL_TAP_SCRATCH_FLOATS floats of device memory the caller
 // owns for the duration of the launches that read it): accepted iff both highpass banks are the quadrature mirrors of their

@@ -83,13 +83,16 @@ class DWTInverse(nn.Module):
         # streaming synthesis kernels derive the highpass tap pairs from the lowpass ones instead of holding both in scalar
         # registers (ops.qmf_hint).  The reference reads its buffers on every forward (transform2d.py:131-148): so does this.
         self._qmf = ops.TapVerdict(_qmf_banks)
+        # and: one bank for both axes?  (with both hints the fused synthesis kernel runs its lattice variant, 10-20 taps)
+        self._same = ops.TapVerdict(_same_banks)
 
     def forward(self, coeffs):
         yl, yh = coeffs
         mode = lowlevel.mode_to_int(self.mode)
         if len(yh) == 0:
             return yl
-        with ops.qmf_hint(self._qmf(self.g0_col, self.g1_col, self.g0_row, self.g1_row)):
+        with ops.qmf_hint(self._qmf(self.g0_col, self.g1_col, self.g0_row, self.g1_row)), \
+                ops.same_banks_hint(self._same(self.g0_col, self.g1_col, self.g0_row, self.g1_row)):
             return lowlevel.SFB2DMulti.apply(yl, self.g0_col, self.g1_col, self.g0_row, self.g1_row, mode, *yh)
 
 

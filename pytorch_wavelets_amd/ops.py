@@ -447,7 +447,11 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
     N, C, h, w = yl.shape
     L = g_w_lo.numel()
     es = yl.element_size()
-    if (yl.dtype == torch.float64 or nlev < 1 or nlev > 3 or g_h_lo.numel() != L or L % 2 or L > 12 or mode == 2
+    # (hints as in afb2d_fused: with "same banks" and "quadrature-mirror highpass" 10-20 taps run the lattice variant of the kernel)
+    same = bool(getattr(_HINTS, 'same', False))
+    qmf = bool(getattr(_HINTS, 'qmf', False))
+    lattice = same and qmf and ROWS_LATTICE and L in (10, 12, 14, 16, 20)
+    if (yl.dtype == torch.float64 or nlev < 1 or nlev > 3 or g_h_lo.numel() != L or L % 2 or (L > 12 and not lattice) or mode == 2
             or yl.numel() == 0 or (strips == 0 and 8 * N * C < 3 * _num_cus(yl.device)) or strips > 2
             or any(t is None or t.dim() != 5 or t.dtype != yl.dtype or t.shape[:3] != (N, C, 3) or t.numel() == 0
                    or (t.shape[4] * es) % 4 or (t.shape[3] * t.shape[4] * es) % 4 for t in yh)):
@@ -471,21 +475,24 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
     yh = [t.contiguous() for t in yh]
     for t in yh:
         _same_device(yl, t)
-    key = ('sfb', yl.device, yl.dtype, N * C, kh, kw, tuple(tuple(t.shape[3:]) for t in yh), L, mode, strips)
+    key = ('sfb', yl.device, yl.dtype, N * C, kh, kw, tuple(tuple(t.shape[3:]) for t in yh), L, mode, strips, lattice)
     if key in _FUSED_DECLINED or yl.data_ptr() % 4 or any(t.data_ptr() % 4 for t in yh):
         return None
-    gwl, gwh, ghl, ghh = (_taps(g, yl) for g in (g_w_lo, g_w_hi, g_h_lo, g_h_hi))
+    ent = _hinted_taps((g_w_lo, g_w_hi, g_h_lo, g_h_hi), yl, L, True) if lattice else [tuple(_taps(g, yl) for g in (g_w_lo, g_w_hi, g_h_lo, g_h_hi)), None, 0]
+    (gwl, gwh, ghl, ghh), scratch, prepared = ent
+    hint_bits = (4 if same else 0) | (8 if qmf else 0) | (16 if prepared else 0)
     y = torch.empty((N, C, sh, sw), dtype=yl.dtype, device=yl.device)
     ptrs = (ctypes.c_void_p * nlev)(*[t.data_ptr() for t in yh])
     khs = (ctypes.c_int * nlev)(*[t.shape[3] for t in yh])
     kws = (ctypes.c_int * nlev)(*[t.shape[4] for t in yh])
     rc = _call('wl_dwt2d_synthesis_fused', yl, yl.data_ptr(), yl_ps, yl_rs, kh, kw, ptrs, khs, kws,
                y.data_ptr(), _DTYPES[yl.dtype], N * C, nlev, gwl.data_ptr(), gwh.data_ptr(), ghl.data_ptr(),
-               ghh.data_ptr(), L, mode, strips, _stream(yl))
+               ghh.data_ptr(), L, mode, strips | hint_bits, None if scratch is None else scratch.data_ptr(), _stream(yl))
     if rc == -3:
         _remember_decline(key)
         return None
     _lib.check(rc, 'wl_dwt2d_synthesis_fused')
+    _mark_prepared(ent)
     return y
 
 

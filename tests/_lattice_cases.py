@@ -288,7 +288,8 @@ def check_rows_lattice_vs_oracle(dev, wave, mode, J, shape=(2, 3, 128, 256), dty
         yl, yh = xfm(x)
         ks = pw.kernels_since(c0)
         prim = [k for k in ks if not k.endswith(')')]
-        assert prim and all(_is_lattice_rows(k) for k in prim) and ks[0].startswith('WlTapPrep') and ks[-1].endswith('(armed fallback)'), ks
+        # (the finest levels in one lattice launch; a coarsest level whose rows are no whole 16-byte pieces follows on its own kernel)
+        assert prim and _is_lattice_rows(prim[0]) and ks[0].startswith('WlTapPrep') and any(k.endswith('(armed fallback)') for k in ks), ks
         oyl, oyh = wo.dwt_forward(x.detach().cpu().double().numpy(), J, _flat(xfm.h0_col), _flat(xfm.h1_col),
                                   _flat(xfm.h0_row), _flat(xfm.h1_row), mode)
         tol = 1e-5 if dtype == torch.float32 else 4e-3
@@ -314,7 +315,7 @@ def check_rows_lattice_rejections(dev, dtype=torch.float32, shape=(2, 2, 96, 256
             c0 = pw.launch_count()
             yl, yh = xfm(x)
             ks = pw.kernels_since(c0)
-            assert any(_is_lattice_rows(k) for k in ks) and ks[-1].endswith('(armed fallback)'), (what, ks)
+            assert any(_is_lattice_rows(k) for k in ks) and any(k.endswith('(armed fallback)') for k in ks), (what, ks)
             oyl, oyh = wo.dwt_forward(x.detach().cpu().double().numpy(), J, _flat(xfm.h0_col), _flat(xfm.h1_col),
                                       _flat(xfm.h0_row), _flat(xfm.h1_row), 'symmetric')
             errs = [_rel(yl, oyl)] + [_rel(a, b) for a, b in zip(yh, oyh)]
@@ -336,5 +337,78 @@ def check_rows_lattice_rejections(dev, dtype=torch.float32, shape=(2, 2, 96, 256
             run(xfm, 2, 'pristine (2) ' + wave)
             xfm.h1_row.data.mul_(2.0)
             run(xfm, 2, wave + ': h1_row.data.mul_')
+    finally:
+        ops.FUSED_STRIPS = prev
+
+
+def _is_lattice_irows(name):
+    if 'WlSfbRows<' not in name:
+        return False
+    args = [a.strip() for a in name[name.index('<') + 1:name.rindex('>')].split(',')]   # <T, L, LAT = 0>
+    return len(args) >= 3 and args[2] == '1'
+
+
+def check_irows_lattice_vs_oracle(dev, wave, mode, J, shape=(2, 3, 128, 256), dtype=torch.float32):
+    """The fused multi-level synthesis kernel in its lattice form (WlSfbRows<T, L, LAT = 1>, 10-20 taps: the only fused form of
+    14, 16 and 20 taps): DWTInverse on the (forced) streaming kernel against the oracle on the module's taps."""
+    from pytorch_wavelets_amd import ops
+    rng = np.random.RandomState(67)
+    prev = ops.FUSED_STRIPS
+    ops.FUSED_STRIPS = 1
+    try:
+        h0, h1 = F.dwt_analysis_taps(wave)
+        oyl, oyh = wo.dwt_forward(rng.randn(*shape), J, h0, h1, h0, h1, mode)
+        yl = torch.tensor(oyl, device=dev).to(dtype)
+        yh = [torch.tensor(v, device=dev).to(dtype) for v in oyh]
+        ifm = pw.DWTInverse(wave=wave, mode=mode).to(dev).to(dtype)
+        c0 = pw.launch_count()
+        r = ifm((yl, yh))
+        ks = pw.kernels_since(c0)
+        assert any(_is_lattice_irows(k) for k in ks) and any(k.startswith('WlTapPrep') for k in ks) and any(k.endswith('(armed fallback)') for k in ks), ks
+        want = wo.dwt_inverse(yl.detach().cpu().double().numpy(), [h.detach().cpu().double().numpy() for h in yh],
+                              _flat(ifm.g0_col), _flat(ifm.g1_col), _flat(ifm.g0_row), _flat(ifm.g1_row), mode)
+        e = _rel(r, want)
+        assert e <= (1e-5 if dtype == torch.float32 else 4e-3), (wave, mode, J, e)
+        return e
+    finally:
+        ops.FUSED_STRIPS = prev
+
+
+def check_irows_lattice_rejections(dev, dtype=torch.float32, shape=(2, 2, 96, 256), tol=1e-5):
+    """Synthesis banks the fused lattice launch cannot take: a random mirror pair, banks edited through `.data` - the device
+    rejects them, the armed four-bank kernel does the work; equal to the oracle on the taps in the buffers."""
+    from pytorch_wavelets_amd import ops
+    rng = np.random.RandomState(71)
+    prev = ops.FUSED_STRIPS
+    ops.FUSED_STRIPS = 1
+    try:
+        def run(ifm, yl, yh, what):
+            c0 = pw.launch_count()
+            r = ifm((yl, yh))
+            ks = pw.kernels_since(c0)
+            assert any(_is_lattice_irows(k) for k in ks) and any(k.endswith('(armed fallback)') for k in ks), (what, ks)
+            want = wo.dwt_inverse(yl.detach().cpu().double().numpy(), [h.detach().cpu().double().numpy() for h in yh],
+                                  _flat(ifm.g0_col), _flat(ifm.g1_col), _flat(ifm.g0_row), _flat(ifm.g1_row), 'symmetric')
+            assert _rel(r, want) <= tol, (what, _rel(r, want))
+
+        for wave in ('db6', 'db8'):
+            h0, h1 = F.dwt_analysis_taps(wave)
+            L = len(h0)
+            oyl, oyh = wo.dwt_forward(rng.randn(*shape), 2, h0, h1, h0, h1, 'symmetric')
+            yl = torch.tensor(oyl, device=dev).to(dtype)
+            yh = [torch.tensor(v, device=dev).to(dtype) for v in oyh]
+            sign = np.array([1.0, -1.0] * (L // 2))
+            lo = rng.randn(L) / 3
+            ifm = pw.DWTInverse(wave=(lo, sign * lo[::-1]), mode='symmetric').to(dev).to(dtype)
+            assert ops.is_qmf_pair(ifm.g0_col, ifm.g1_col)
+            run(ifm, yl, yh, 'random mirror pair, %d taps' % L)
+            ifm = pw.DWTInverse(wave=wave, mode='symmetric').to(dev).to(dtype)
+            run(ifm, yl, yh, 'pristine ' + wave)
+            ifm.g0_row.data[0, 0, 0, 2] += 0.25
+            run(ifm, yl, yh, wave + ': g0_row.data[...] +=')
+            ifm = pw.DWTInverse(wave=wave, mode='symmetric').to(dev).to(dtype)
+            run(ifm, yl, yh, 'pristine (2) ' + wave)
+            ifm.g1_col.data.mul_(-1.0)
+            run(ifm, yl, yh, wave + ': g1_col.data.mul_')
     finally:
         ops.FUSED_STRIPS = prev

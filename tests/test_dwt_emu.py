@@ -925,3 +925,16 @@ def test_lattice_variant_of_the_fused_analysis_kernel_rejections():
     import _lattice_cases as LC
     with emu_backend.emulated():
         LC.check_rows_lattice_rejections('cpu', shape=(1, 2, 80, 128))
+
+
+@pytest.mark.parametrize('wave,mode,J', __import__('_lattice_cases').ROWS_LATTICE_CASES)
+def test_lattice_variant_of_the_fused_synthesis_kernel(wave, mode, J):
+    import _lattice_cases as LC
+    with emu_backend.emulated():
+        LC.check_irows_lattice_vs_oracle('cpu', wave, mode, J, shape=(1, 2, 96, 128))
+
+
+def test_lattice_variant_of_the_fused_synthesis_kernel_rejections():
+    import _lattice_cases as LC
+    with emu_backend.emulated():
+        LC.check_irows_lattice_rejections('cpu', shape=(1, 2, 80, 128))

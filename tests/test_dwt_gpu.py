@@ -886,3 +886,18 @@ def test_lattice_variant_of_the_fused_analysis_kernel(wave, mode, J, dtype):
 def test_lattice_variant_of_the_fused_analysis_kernel_rejections():
     import _lattice_cases as LC
     LC.check_rows_lattice_rejections(DEV, shape=(3, 2, 160, 512))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('wave,mode,J', __import__('_lattice_cases').ROWS_LATTICE_CASES)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_lattice_variant_of_the_fused_synthesis_kernel(wave, mode, J, dtype):
+    import _lattice_cases as LC
+    # (float16: coefficient rows must be whole 4-byte words for the fused synthesis - widths chosen so that every level's are)
+    LC.check_irows_lattice_vs_oracle(DEV, wave, mode, J, shape=(3, 3, 200, 512), dtype=dtype)
+
+
+@pytest.mark.gpu
+def test_lattice_variant_of_the_fused_synthesis_kernel_rejections():
+    import _lattice_cases as LC
+    LC.check_irows_lattice_rejections(DEV, shape=(3, 2, 160, 512))

@@ -30,6 +30,8 @@ for wave in ('db4', 'db5', 'db6'):
     yl, yh = m(x); im = pw.DWTInverse(wave=wave, mode='symmetric').to(dev); t('inv_' + wave, lambda: im((yl, yh)))
 for wave in ('db7', 'db10', 'sym8'):
     mm = pw.DWTForward(J=3, wave=wave, mode='symmetric').to(dev); t('fwd_' + wave, lambda: mm(x))
+    yy = mm(x); ii = pw.DWTInverse(wave=wave, mode='symmetric').to(dev); t('inv_' + wave, lambda: ii(yy))
+    del yy
 m8 = pw.DWTForward(J=3, wave='db8', mode='symmetric').to(dev); t('fwd_db8', lambda: m8(x))
 yl, yh = m8(x); i8 = pw.DWTInverse(wave='db8', mode='symmetric').to(dev); t('inv_db8', lambda: i8((yl, yh)))
 del x, yl, yh

@@ -1,12 +1,11 @@
 #!/bin/bash
-# Round 5, GPU call I: parity tests, then the same-box A/B (old package | no lattice | this one | the lattice also at 8 taps)
+# Round 5, GPU call I: parity tests, then the same-box A/B (old package | this one)
 TAG=${1:-r05i}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -q -x > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_gpu.log
 for i in 1 2; do
   WL_PKG_ROOT=ab/old_pkg timeout 600 python tools/gpu_r5_ab.py old 2>> $OUT/ab.err | tail -1 >> $OUT/ab.jsonl
   timeout 600 python tools/gpu_r5_ab.py new 2>> $OUT/ab.err | tail -1 >> $OUT/ab.jsonl
-  WL_LIB=ab/libwl_lat8.so WL_ROWS_LAT8=1 timeout 600 python tools/gpu_r5_ab.py lat8 2>> $OUT/ab.err | tail -1 >> $OUT/ab.jsonl
 done
 python - $OUT <<'PY'
 import json, sys
