@@ -113,6 +113,11 @@ struct WlIRowsSched {
 // the column synthesis as the transposed lattice of wl_lattice.h: L packed FMAs and L/2 - 1 delayed values per coefficient row
 // where the direct form needs 2L FMAs, two (L/2 - 1)-row windows and four banks of tap pairs in scalar registers (at 16 taps
 // more than the scalar file holds: the direct form stops at 12).
+#ifndef WL_IROWS_LAT_MIN
+#define WL_IROWS_LAT_MIN 8      // tap counts from which the lattice variant of the fused synthesis exists.  8 = the metric's db4: same-box
+                                // A/B of the inverse 0.1887-0.1899 -> 0.1768-0.1782 ms (-6 %) WITH the examination kernel and the armed
+                                // fallback in the figure (the analysis kernel at 8 taps measured +2 %: its lattice starts at 10)
+#endif
 template <typename T, int LT, int LAT = 0>
 struct WlSfbRows {
     typedef WlIRowsArgs<T> Args;
@@ -432,7 +437,7 @@ struct WlSfbRows {
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
         const int tid = ctx.tid;
         const int wave = wl_uniform(tid >> 6), lane = tid & 63;
-        if (LT >= WL_ROWS_SAME_MIN && a.guard) {   // the lattice variant / its armed fallback: WlTapPrep's verdict on the banks as they are now
+        if (LT >= WL_IROWS_LAT_MIN && a.guard) {   // the lattice variant / its armed fallback: WlTapPrep's verdict on the banks as they are now
             const bool holds = a.lat && *reinterpret_cast<const unsigned*>(a.lat) == WL_LAT_OK;
             if (!wl_guard_pass(a.guard, holds)) return;
         }

@@ -239,7 +239,7 @@ def _hinted_taps(bufs, ref, L, syn):
     ent = cache.get(key) if cache is not None else None
     if ent is None:
         taps = tuple(_taps(b, ref) for b in bufs)
-        scratch = torch.empty(TAP_SCRATCH_FLOATS, dtype=torch.float32, device=ref.device) if L >= min(10, ROWS_LATTICE_MIN) and (STRIP_LATTICE or ROWS_LATTICE) else None
+        scratch = torch.empty(TAP_SCRATCH_FLOATS, dtype=torch.float32, device=ref.device) if L >= min(ROWS_LATTICE_MIN, IROWS_LATTICE_MIN) and (STRIP_LATTICE or ROWS_LATTICE) else None
         ent = [taps, scratch, 0]
         if cache is not None:
             cache[key] = ent
@@ -450,7 +450,7 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
     # (hints as in afb2d_fused: with "same banks" and "quadrature-mirror highpass" 10-20 taps run the lattice variant of the kernel)
     same = bool(getattr(_HINTS, 'same', False))
     qmf = bool(getattr(_HINTS, 'qmf', False))
-    lattice = same and qmf and ROWS_LATTICE and L in (10, 12, 14, 16, 20)
+    lattice = same and qmf and ROWS_LATTICE and L in (8, 10, 12, 14, 16, 20) and L >= IROWS_LATTICE_MIN
     if (yl.dtype == torch.float64 or nlev < 1 or nlev > 3 or g_h_lo.numel() != L or L % 2 or (L > 12 and not lattice) or mode == 2
             or yl.numel() == 0 or (strips == 0 and 8 * N * C < 3 * _num_cus(yl.device)) or strips > 2
             or any(t is None or t.dim() != 5 or t.dtype != yl.dtype or t.shape[:3] != (N, C, 3) or t.numel() == 0
@@ -504,6 +504,7 @@ TAP_SCRATCH_FLOATS = 16   # WL_TAP_SCRATCH_FLOATS of csrc/wl_lattice.h
 STRIP_LATTICE = True      # hinted strip launches of 12 taps and more run the lattice variant (False: the QMF variant; A/B measurements)
 ROWS_LATTICE = True       # hinted fused analysis launches of 10-20 taps run the lattice variant (False: A/B measurements; 14-20 taps then go level by level)
 ROWS_LATTICE_MIN = 10     # WL_ROWS_LAT_MIN of csrc/wl_rows_api.inc (8 in the A/B build that tries the lattice on the metric's kernel)
+IROWS_LATTICE_MIN = 8     # WL_IROWS_LAT_MIN of csrc/wl_idwt_rows.h: the fused synthesis takes the lattice from 8 taps on (the metric's inverse: -6 %)
 
 
 def afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=False):

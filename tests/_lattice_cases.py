@@ -348,7 +348,7 @@ def _is_lattice_irows(name):
     return len(args) >= 3 and args[2] == '1'
 
 
-def check_irows_lattice_vs_oracle(dev, wave, mode, J, shape=(2, 3, 128, 256), dtype=torch.float32):
+def check_irows_lattice_vs_oracle(dev, wave, mode, J, shape=(2, 3, 128, 256), dtype=torch.float32, require=True):
     """The fused multi-level synthesis kernel in its lattice form (WlSfbRows<T, L, LAT = 1>, 10-20 taps: the only fused form of
     14, 16 and 20 taps): DWTInverse on the (forced) streaming kernel against the oracle on the module's taps."""
     from pytorch_wavelets_amd import ops
@@ -364,7 +364,9 @@ def check_irows_lattice_vs_oracle(dev, wave, mode, J, shape=(2, 3, 128, 256), dt
         c0 = pw.launch_count()
         r = ifm((yl, yh))
         ks = pw.kernels_since(c0)
-        assert any(_is_lattice_irows(k) for k in ks) and any(k.startswith('WlTapPrep') for k in ks) and any(k.endswith('(armed fallback)') for k in ks), ks
+        # (require = False: float16 levels whose coefficient rows are no whole 4-byte words - 263 halves - stay off the fused kernel)
+        if require or any(_is_lattice_irows(k) for k in ks):
+            assert any(_is_lattice_irows(k) for k in ks) and any(k.startswith('WlTapPrep') for k in ks) and any(k.endswith('(armed fallback)') for k in ks), ks
         want = wo.dwt_inverse(yl.detach().cpu().double().numpy(), [h.detach().cpu().double().numpy() for h in yh],
                               _flat(ifm.g0_col), _flat(ifm.g1_col), _flat(ifm.g0_row), _flat(ifm.g1_row), mode)
         e = _rel(r, want)

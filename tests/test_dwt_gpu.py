@@ -750,7 +750,7 @@ def test_mutated_highpass_bank_on_the_production_policy_path():
     ifm = pw.DWTInverse(wave='db8', mode='symmetric').to(DEV)
     yl, yh = xfm(x)
     r0 = ifm((yl, yh))
-    assert 'WlSfbStrip' in pw.last_kernel()
+    assert 'WlSfbRows<float, 16, 1>' in pw.last_kernel()      # (round 5: the fused kernel's lattice variant takes an orthogonal 16-tap bank)
     ifm.g1_col.mul_(0.5)
     ifm.g1_row.mul_(0.5)
     r1 = ifm((yl, yh))
@@ -893,8 +893,8 @@ def test_lattice_variant_of_the_fused_analysis_kernel_rejections():
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
 def test_lattice_variant_of_the_fused_synthesis_kernel(wave, mode, J, dtype):
     import _lattice_cases as LC
-    # (float16: coefficient rows must be whole 4-byte words for the fused synthesis - widths chosen so that every level's are)
-    LC.check_irows_lattice_vs_oracle(DEV, wave, mode, J, shape=(3, 3, 200, 512), dtype=dtype)
+    # (float16: coefficient rows must be whole 4-byte words for the fused synthesis - where a level's are not, the level kernels run)
+    LC.check_irows_lattice_vs_oracle(DEV, wave, mode, J, shape=(3, 3, 200, 512), dtype=dtype, require=dtype == torch.float32)
 
 
 @pytest.mark.gpu
