@@ -104,6 +104,7 @@ class SFB2DMulti(Function):
         _check_bank_mode(mode)
         ctx.save_for_backward(g0_row, g1_row, g0_col, g1_col)
         ctx.mode = mode
+        ctx.hints = ops.current_hints()     # (the module's kernel-variant hints, re-installed around the backward pass: autograd's thread)
         ctx.has_highs = [h is not None for h in yh]
         J = len(yh)
         ll_shapes = [None] * J          # the low-pass handed to level j, before the 'unpad'
@@ -150,6 +151,11 @@ class SFB2DMulti(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
+        with ops.hints(*ctx.hints):
+            return SFB2DMulti._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         J = len(ctx.has_highs)
         grads = [None] * J
         d = None
@@ -187,6 +193,7 @@ class AFB2DMulti(Function):
         _check_bank_mode(mode)
         ctx.save_for_backward(h0_row, h1_row, h0_col, h1_col)
         ctx.mode = mode
+        ctx.hints = ops.current_hints()     # (see SFB2DMulti: the backward pass is an inverse transform with these taps - same hints)
         shapes, yh, ll, done = [], [], x, 0
         while done < J:
             n = min(4, J - done)
@@ -215,6 +222,11 @@ class AFB2DMulti(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dyl, *dyh):
+        with ops.hints(*ctx.hints):
+            return AFB2DMulti._backward(ctx, dyl, *dyh)
+
+    @staticmethod
+    def _backward(ctx, dyl, *dyh):
         dx = None
         if ctx.needs_input_grad[0]:
             h0_row, h1_row, h0_col, h1_col = ctx.saved_tensors

@@ -253,6 +253,19 @@ def _mark_prepared(ent):
         ent[2] = 4
 
 
+def current_hints():
+    """(qmf, same) as the calling module set them: an autograd Function keeps them in its ctx and re-installs them around its backward
+    pass (`hints`), which runs on autograd's own thread, outside the module's contexts.  They stay HINTS there too: every variant they
+    select verifies its relation on the device."""
+    return bool(getattr(_HINTS, 'qmf', False)), bool(getattr(_HINTS, 'same', False))
+
+
+@contextlib.contextmanager
+def hints(qmf, same):
+    with qmf_hint(qmf), same_banks_hint(same):
+        yield
+
+
 def banks_equal(lo_a, hi_a, lo_b, hi_b):
     """Are the two filter banks the same taps, element for element (whatever their shapes)?"""
     f = lambda t: t.detach().reshape(-1).double().cpu()   # noqa: E731
