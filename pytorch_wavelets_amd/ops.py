@@ -178,7 +178,7 @@ class TapVerdict(object):
     the host when that key changes: in-place edits (mul_, copy_, load_state_dict), re-assigned attributes, .half() / .double() /
     .to(...) all change it.  What the key cannot see (writes through `.data`, whose alias has a version counter of its own; a
     re-assigned buffer that reuses an address) leaves a stale hint, which costs one empty launch and nothing else.  Buffers without
-    a version counter (inference tensors) get no hint at all.  `fn` must be a module-level function (modules stay picklable)."""
+    a version counter (inference tensors) are keyed without it.  `fn` must be a module-level function (modules stay picklable)."""
 
     def __init__(self, fn):
         self.fn = fn
@@ -189,7 +189,12 @@ class TapVerdict(object):
         try:
             key = tuple((b.data_ptr(), b._version, b.dtype, b.device, tuple(b.shape)) for b in bufs)
         except (RuntimeError, AttributeError):
-            return False
+            # inference tensors have no version counter: the key does without it - a hint may then outlive an in-place edit, which
+            # costs an empty launch (the device verifies every relation), not a coefficient
+            try:
+                key = tuple((b.data_ptr(), -1, b.dtype, b.device, tuple(b.shape)) for b in bufs)
+            except (RuntimeError, AttributeError):
+                return False
         if key != self.key:
             self.val = bool(self.fn(*bufs))
             self.key = key
@@ -235,7 +240,8 @@ def _hinted_taps(bufs, ref, L, syn):
     `.half()` module - one conversion of the taps.  The scratch stays referenced until the context ends: the allocator hands
     it out again on this stream only, behind the launches that read it."""
     cache = getattr(_HINTS, 'tapcache', None)
-    key = (tuple((b.data_ptr(), b.dtype, b._version) for b in bufs), ref.device, ref.dtype, L, bool(syn))
+    # (no version counter in the key: the cache lives for ONE module call, during which nobody edits the buffers)
+    key = (tuple((b.data_ptr(), b.dtype) for b in bufs), ref.device, ref.dtype, L, bool(syn))
     ent = cache.get(key) if cache is not None else None
     if ent is None:
         taps = tuple(_taps(b, ref) for b in bufs)

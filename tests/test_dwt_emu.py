@@ -938,3 +938,30 @@ def test_lattice_variant_of_the_fused_synthesis_kernel_rejections():
     import _lattice_cases as LC
     with emu_backend.emulated():
         LC.check_irows_lattice_rejections('cpu', shape=(1, 2, 80, 128))
+
+
+def test_inference_mode_tensors_take_the_hinted_kernels_and_stay_correct():
+    """Inference tensors have no version counter: the host's hint cache keys them without one, so an in-place edit leaves a STALE
+    hint - which the device rejects (csrc/wl_common.h, tap-relation guards): the armed two-bank kernel computes the edited bank."""
+    from pytorch_wavelets_amd import ops
+    from oracle import wavelet_oracle as wo
+    prev = ops.FUSED_STRIPS
+    ops.FUSED_STRIPS = 1
+    try:
+        with emu_backend.emulated(), torch.inference_mode():
+            m = pw.DWTForward(J=2, wave='db8', mode='symmetric')
+            x = torch.randn(1, 3, 96, 128)
+            yl, yh = m(x)
+            assert pw.last_kernel().endswith(', 3, 1, 1>'), pw.last_kernel()
+            m.h0_col.mul_(2.0)
+            c0 = pw.launch_count()
+            yl2, yh2 = m(x)
+            ks = pw.kernels_since(c0)
+            assert ks[-1].endswith('(armed fallback)'), ks
+        flat = lambda b: b.detach().double().numpy().ravel()
+        oyl, oyh = wo.dwt_forward(x.double().numpy(), 2, flat(m.h0_col), flat(m.h1_col), flat(m.h0_row), flat(m.h1_row), 'symmetric')
+        assert np.abs(yl2.numpy() - oyl).max() <= 1e-5 * np.abs(oyl).max()
+        for a, b in zip(yh2, oyh):
+            assert np.abs(a.numpy() - b).max() <= 1e-5 * np.abs(b).max()
+    finally:
+        ops.FUSED_STRIPS = prev
