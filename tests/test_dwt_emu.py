@@ -949,8 +949,8 @@ def test_inference_mode_tensors_take_the_hinted_kernels_and_stay_correct():
     ops.FUSED_STRIPS = 1
     try:
         with emu_backend.emulated(), torch.inference_mode():
-            m = pw.DWTForward(J=2, wave='db8', mode='symmetric')
-            x = torch.randn(1, 3, 96, 128)
+            m = pw.DWTForward(J=2, wave='db8', mode='symmetric').float()
+            x = torch.randn(1, 3, 96, 128, dtype=torch.float32)
             yl, yh = m(x)
             assert pw.last_kernel().endswith(', 3, 1, 1>'), pw.last_kernel()
             m.h0_col.mul_(2.0)
