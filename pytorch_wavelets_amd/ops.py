@@ -352,7 +352,8 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None):
     # (csrc/wl_lattice.h): the only fused form of 14, 16 and 20 taps.
     same = bool(getattr(_HINTS, 'same', False))
     qmf = bool(getattr(_HINTS, 'qmf', False))
-    lattice = same and qmf and ROWS_LATTICE and L in (8, 10, 12, 14, 16, 20) and L >= ROWS_LATTICE_MIN
+    lattice = (same and qmf and ROWS_LATTICE and L in (8, 10, 12, 14, 16, 20) and L >= ROWS_LATTICE_MIN
+               and (L > 12 or x.numel() >= LATTICE_MIN_ELEMS))
     if (x.dtype == torch.float64 or nlev < 1 or nlev > 3 or h_h_lo.numel() != L or L % 2 or (L > 12 and not lattice)
             or (W * x.element_size()) % 16 or (nlev > 1 and mode not in (0, 1, 4)) or x.numel() == 0
             or (strips == 0 and 8 * N * C < 3 * _num_cus(x.device)) or strips > 2):
@@ -469,7 +470,9 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
     # (hints as in afb2d_fused: with "same banks" and "quadrature-mirror highpass" 10-20 taps run the lattice variant of the kernel)
     same = bool(getattr(_HINTS, 'same', False))
     qmf = bool(getattr(_HINTS, 'qmf', False))
-    lattice = same and qmf and ROWS_LATTICE and L in (8, 10, 12, 14, 16, 20) and L >= IROWS_LATTICE_MIN
+    lattice = (same and qmf and ROWS_LATTICE and L in (8, 10, 12, 14, 16, 20) and L >= IROWS_LATTICE_MIN
+               and (L > 12 or (nlev >= 1 and yh[0] is not None and yh[0].dim() == 5
+                               and 4 * yh[0].shape[3] * yh[0].shape[4] * N * C >= LATTICE_MIN_ELEMS)))
     if (yl.dtype == torch.float64 or nlev < 1 or nlev > 3 or g_h_lo.numel() != L or L % 2 or (L > 12 and not lattice) or mode == 2
             or yl.numel() == 0 or (strips == 0 and 8 * N * C < 3 * _num_cus(yl.device)) or strips > 2
             or any(t is None or t.dim() != 5 or t.dtype != yl.dtype or t.shape[:3] != (N, C, 3) or t.numel() == 0
@@ -523,6 +526,10 @@ TAP_SCRATCH_FLOATS = 16   # WL_TAP_SCRATCH_FLOATS of csrc/wl_lattice.h
 STRIP_LATTICE = True      # hinted strip launches of 12 taps and more run the lattice variant (False: the QMF variant; A/B measurements)
 ROWS_LATTICE = True       # hinted fused analysis launches of 10-20 taps run the lattice variant (False: A/B measurements; 14-20 taps then go level by level)
 ROWS_LATTICE_MIN = 10     # WL_ROWS_LAT_MIN of csrc/wl_rows_api.inc (8 in the A/B build that tries the lattice on the metric's kernel)
+# Up to 12 taps the direct-form fused kernels exist too, and the lattice launch carries two short extra launches (the examination of the
+# banks ~5 us, the armed fallback ~5 us): it pays from about 40 M elements on (128x3x512x512 = 100 M: inverse -6 % at 8 taps, -15 % at 12;
+# 128x3x224x224 = 19 M: the extra launches are 15 % of a 65 us transform).  From 14 taps on the lattice is the only fused form.
+LATTICE_MIN_ELEMS = 40000000
 IROWS_LATTICE_MIN = 8     # WL_IROWS_LAT_MIN of csrc/wl_idwt_rows.h: the fused synthesis takes the lattice from 8 taps on (the metric's inverse: -6 %)
 
 

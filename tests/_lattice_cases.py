@@ -279,8 +279,8 @@ def check_rows_lattice_vs_oracle(dev, wave, mode, J, shape=(2, 3, 128, 256), dty
     form of 14, 16 and 20 taps): DWTForward on the (forced) streaming kernel against the oracle on the module's taps."""
     from pytorch_wavelets_amd import ops
     rng = np.random.RandomState(59)
-    prev = ops.FUSED_STRIPS
-    ops.FUSED_STRIPS = 1
+    prev = ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS
+    ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS = 1, 0      # (the engine's size policy for the lattice at <= 12 taps: off)
     try:
         x = torch.tensor(rng.randn(*shape), device=dev).to(dtype)
         xfm = pw.DWTForward(J=J, wave=wave, mode=mode).to(dev).to(dtype)
@@ -297,7 +297,7 @@ def check_rows_lattice_vs_oracle(dev, wave, mode, J, shape=(2, 3, 128, 256), dty
         assert max(errs) <= tol, (wave, mode, J, errs)
         return max(errs)
     finally:
-        ops.FUSED_STRIPS = prev
+        ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS = prev
 
 
 def check_rows_lattice_rejections(dev, dtype=torch.float32, shape=(2, 2, 96, 256), tol=1e-5):
@@ -306,8 +306,8 @@ def check_rows_lattice_rejections(dev, dtype=torch.float32, shape=(2, 2, 96, 256
     edited through `.data` (the hints go stale), the banks of the two axes differing through `.data`."""
     from pytorch_wavelets_amd import ops
     rng = np.random.RandomState(61)
-    prev = ops.FUSED_STRIPS
-    ops.FUSED_STRIPS = 1
+    prev = ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS
+    ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS = 1, 0      # (the engine's size policy for the lattice at <= 12 taps: off)
     try:
         x = torch.tensor(rng.randn(*shape), device=dev).to(dtype)
 
@@ -338,7 +338,7 @@ def check_rows_lattice_rejections(dev, dtype=torch.float32, shape=(2, 2, 96, 256
             xfm.h1_row.data.mul_(2.0)
             run(xfm, 2, wave + ': h1_row.data.mul_')
     finally:
-        ops.FUSED_STRIPS = prev
+        ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS = prev
 
 
 def _is_lattice_irows(name):
@@ -353,8 +353,8 @@ def check_irows_lattice_vs_oracle(dev, wave, mode, J, shape=(2, 3, 128, 256), dt
     14, 16 and 20 taps): DWTInverse on the (forced) streaming kernel against the oracle on the module's taps."""
     from pytorch_wavelets_amd import ops
     rng = np.random.RandomState(67)
-    prev = ops.FUSED_STRIPS
-    ops.FUSED_STRIPS = 1
+    prev = ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS
+    ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS = 1, 0      # (the engine's size policy for the lattice at <= 12 taps: off)
     try:
         h0, h1 = F.dwt_analysis_taps(wave)
         oyl, oyh = wo.dwt_forward(rng.randn(*shape), J, h0, h1, h0, h1, mode)
@@ -373,7 +373,7 @@ def check_irows_lattice_vs_oracle(dev, wave, mode, J, shape=(2, 3, 128, 256), dt
         assert e <= (1e-5 if dtype == torch.float32 else 4e-3), (wave, mode, J, e)
         return e
     finally:
-        ops.FUSED_STRIPS = prev
+        ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS = prev
 
 
 def check_irows_lattice_rejections(dev, dtype=torch.float32, shape=(2, 2, 96, 256), tol=1e-5):
@@ -381,8 +381,8 @@ def check_irows_lattice_rejections(dev, dtype=torch.float32, shape=(2, 2, 96, 25
     rejects them, the armed four-bank kernel does the work; equal to the oracle on the taps in the buffers."""
     from pytorch_wavelets_amd import ops
     rng = np.random.RandomState(71)
-    prev = ops.FUSED_STRIPS
-    ops.FUSED_STRIPS = 1
+    prev = ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS
+    ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS = 1, 0      # (the engine's size policy for the lattice at <= 12 taps: off)
     try:
         def run(ifm, yl, yh, what):
             c0 = pw.launch_count()
@@ -413,4 +413,4 @@ def check_irows_lattice_rejections(dev, dtype=torch.float32, shape=(2, 2, 96, 25
             ifm.g1_col.data.mul_(-1.0)
             run(ifm, yl, yh, wave + ': g1_col.data.mul_')
     finally:
-        ops.FUSED_STRIPS = prev
+        ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS = prev
