@@ -453,7 +453,7 @@ struct WlDtFwd12Strip {
                                 const float r = wl_sqrt(0.5f * (d * d + e * e) + b2);
                                 *reinterpret_cast<T*>(zp + zmag + (size_t)o6 * zplane) = (T)(r - b);
                                 if (MODE == 3) {
-                                    const float ir = k / r;
+                                    const float ir = k * wl_rcp(r);
                                     char* const dp = reinterpret_cast<char*>(f.drdx) + dbase + (size_t)o6 * zplane + (size_t)(qrow * SZ) + voff1;
                                     char* const dq = reinterpret_cast<char*>(f.drdy) + dbase + (size_t)o6 * zplane + (size_t)(qrow * SZ) + voff1;
                                     *reinterpret_cast<T*>(dp) = (T)(d * ir);

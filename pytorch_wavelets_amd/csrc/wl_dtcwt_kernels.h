@@ -19,8 +19,20 @@
 #include <math.h>
 
 #define WL_SQRT1_2 0.70710678118654752440
+// The magnitudes of the scattering epilogues: float32 square root and reciprocal as ONE hardware instruction each (v_sqrt_f32 /
+// v_rcp_f32, 1 ulp).  `sqrtf` / `/` compile to the correctly rounded sequences (scaling for denormals, the instruction, two
+// fused multiply-adds and three selects to fix the last bit: 16 instructions per root - six roots per quad made a third of what a
+// level-1 lane of the ScatLayer kernel issues, and that kernel is bound by the instructions it issues).  The parity tolerance is
+// 1e-5 of the largest value; float64 planes keep the exact forms.
+#if defined(__HIPCC__)
+WL_DEV float wl_sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
+WL_DEV float wl_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+#else
 WL_DEV float wl_sqrt(float v) { return sqrtf(v); }
+WL_DEV float wl_rcp(float v) { return 1.0f / v; }
+#endif
 WL_DEV double wl_sqrt(double v) { return sqrt(v); }
+WL_DEV double wl_rcp(double v) { return 1.0 / v; }
 
 // orientation slots: lh -> (0, 5), hh -> (1, 4), hl -> (2, 3)   (transform_funcs.py:61-72)
 
@@ -121,8 +133,9 @@ WL_DEV void wl_dtfwd1_quad_out(const WlDtFwd1Args<T>& a, int64_t plane, int ch, 
             zp[(size_t)o * a.C * qplane] = (T)(r - a.magbias);
             if (a.drdx) {
                 const size_t so = (((size_t)n * 6 + o) * a.C + c) * qplane + q;
-                a.drdx[so] = (T)(re[o] / r);
-                a.drdy[so] = (T)(im[o] / r);
+                const A ir = wl_rcp(r);
+                a.drdx[so] = (T)(re[o] * ir);
+                a.drdy[so] = (T)(im[o] * ir);
             }
         }
     } else {
@@ -146,8 +159,8 @@ WL_DEV void wl_dtfwd1_quad_out(const WlDtFwd1Args<T>& a, int64_t plane, int ch, 
                 if (a.drdx) {
                     for (int c3 = 0; c3 < 3; ++c3) {
                         const size_t so = (((size_t)n * 6 + o) * 3 + c3) * qplane + q;
-                        a.drdx[so] = (T)((A)a.drdx[so] / r);
-                        a.drdy[so] = (T)((A)a.drdy[so] / r);
+                        a.drdx[so] = (T)((A)a.drdx[so] * wl_rcp(r));
+                        a.drdy[so] = (T)((A)a.drdy[so] * wl_rcp(r));
                     }
                 }
             }

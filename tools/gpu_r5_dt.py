@@ -18,4 +18,14 @@ yl, yh = d(xd); di = pw.DTCWTInverse().to(dev); t('inv_j3', lambda: di((yl, yh))
 d2 = pw.DTCWTForward(J=2).to(dev); t('fwd_j2', lambda: d2(xd))
 d1 = pw.DTCWTForward(J=1).to(dev); t('fwd_j1', lambda: d1(xd))
 s = pw.ScatLayer().to(dev); xs = torch.randn(256, 3, 256, 256, device=dev); t('scat', lambda: s(xs))
+xg = xs.clone().requires_grad_(True)
+def train():
+    with torch.enable_grad():
+        z = s(xg); z.backward(torch.ones_like(z))
+out['scat_train'] = round(min(bench.time_seq_fn(train, 20, sync) for _ in range(3)), 4)
+del xg
+x2 = torch.randn(64, 3, 256, 256, device=dev)
+s2 = pw.ScatLayerj2().to(dev); t('scatj2', lambda: s2(x2))
+sr = pw.ScatLayer(biort='near_sym_b_bp').to(dev); t('scat_rot', lambda: sr(x2))
+x5 = torch.randn(64, 3, 512, 512, device=dev); t('scat_512', lambda: s(x5))
 print(json.dumps(out), flush=True)
