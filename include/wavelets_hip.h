@@ -55,8 +55,10 @@ const char* wl_last_kernel(void);
  * can then be labelled launch by launch.  A name that contains "wl_launch_armed" is the two-bank variant queued behind a kernel
  * variant that relies on a relation between the filter banks (it returns at once unless the device finds the relation broken),
  * "wl_launch_aux" a helper launch (the one-thread examination of the banks in front of a lattice launch); wl_last_kernel names
- * neither. */
+ * neither.  wl_last_grid(): workgroups of the launch wl_last_kernel names (a test can see how a launcher cut the work: planes per
+ * workgroup, row segments). */
 long long wl_launch_count(void);
+long long wl_last_grid(void);
 const char* wl_kernel_history(int back);
 
 /* Coefficient count of one 1-D analysis level: (n+L-1)/2, or (n+1)/2 for periodization.

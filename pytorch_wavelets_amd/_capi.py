@@ -12,6 +12,7 @@ PROTOTYPES = {
     'wl_get_option': (I, [C.c_char_p]),
     'wl_last_kernel': (C.c_char_p, []),
     'wl_launch_count': (C.c_longlong, []),
+    'wl_last_grid': (C.c_longlong, []),
     'wl_kernel_history': (C.c_char_p, [I]),
     'wl_dwt_coeff_len': (I, [I, I, I]),
     'wl_dwt2d_analysis': (I, [P, P, P, I, L, I, I, P, P, I, P, P, I, I, P]),

@@ -24,6 +24,8 @@ __global__ void __launch_bounds__(K::kThreads, K::kMinWaves) wl_kernel(const typ
 #include <atomic>
 inline std::atomic<const char*> wl_last_kernel_ptr{""};
 static const char* wl_last_kernel_name() { return wl_last_kernel_ptr.load(std::memory_order_relaxed); }
+inline std::atomic<long long> wl_last_grid_v{0};   // workgroups of that launch (wl_last_grid() of the C ABI)
+static long long wl_last_grid_value() { return wl_last_grid_v.load(std::memory_order_relaxed); }
 // ... and the last 32, with a running count of launches: a benchmark names EVERY kernel of a multi-launch transform
 inline std::atomic<const char*> wl_kernel_log_buf[32] = {};
 inline std::atomic<long long> wl_kernel_log_n{0};
@@ -56,7 +58,7 @@ template <typename K>
 static int wl_launch_named(const typename K::Args& a, int64_t nblocks, size_t lds, void* stream, const char* name, bool primary) {
     if (nblocks <= 0) return 0;
     if (nblocks > 2147483647LL || lds > 160 * 1024) return -2;
-    if (primary) wl_last_kernel_ptr.store(name, std::memory_order_relaxed);
+    if (primary) { wl_last_kernel_ptr.store(name, std::memory_order_relaxed); wl_last_grid_v.store(nblocks, std::memory_order_relaxed); }
     wl_kernel_log(name);
     if (lds > 48 * 1024) {
         // opt in to large dynamic LDS once per kernel (idempotent, cheap)

@@ -117,6 +117,7 @@ struct WlStripArgs {
     int dma_off, dma_pitch;        // DMA ring: WL_STRIP_D slots x 4 rows x dma_pitch bytes (input type)
     int st_off, st_pitch;          // staged ring: 2 slots x 4 rows x st_pitch bytes (float32)
     int lds_bytes;
+    int pp, ring;                  // planes per workgroup (1, 2, 4: narrow strips, see run()) and the bytes of one plane's staged ring
     int pair_ok;                   // every output-column pair of every band row is one aligned 2-element store (even Kw, ll_rs)
     int guard;                     // tap-relation guard (wl_common.h): 1 = run only if both highpass banks are the quadrature mirrors of
                                    // their lowpass banks (the QMF variant), 2 = only if not (its armed two-bank fallback), 0 = no check
@@ -352,10 +353,16 @@ struct WlAfbStrip {
     // NGL = groups per lane and row (compile-time, so that every load of a half-batch is unconditional: the compiler
     // can then count them and wait for exactly the older register set; with predicated loads it waits for all of them,
     // i.e. for the loads it has just issued - measured 36 % slower)
-    template <int NGL>
+    // PP = planes of this workgroup (run()): the wave takes row `sidx` of every half-batch of each of them, into that plane's ring
+    template <int NGL, int PP>
     static WL_DEV void stager_direct(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int lane, int sidx) {
         static_assert(LROWS == 1, "the direct stager takes one row per wave and half-batch");
-        const char* xp = reinterpret_cast<const char*>(a.x + (size_t)plane * a.x_ps);
+        const char* xp[PP];
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {      // (a last workgroup with fewer planes stages its last plane again: nobody reads it)
+            const int64_t pl = plane + p < a.NC ? plane + p : a.NC - 1;
+            xp[p] = reinterpret_cast<const char*>(a.x + (size_t)pl * a.x_ps);
+        }
         const int row_stride = a.x_rs * SZ;
         const bool wrap = wraps(a.ext);
         const int e_first = a.base + 2 * s.o_lo;
@@ -408,26 +415,32 @@ struct WlAfbStrip {
             e = e < e_last ? e : e_last;
             return (unsigned)e < (unsigned)a.H ? e : wl_ext(e, a.H, a.ext);   // -1: a row of zeros
         };
-        auto load = [&](int h, RowRegs& rr) {
+        auto load = [&](int h, RowRegs (&rr)[PP]) {
             int r = src_row(h);
             r = r < 0 ? 0 : r;
-            const char* grow = xp + (size_t)r * row_stride;
 #pragma unroll
-            for (int i = 0; i < NGL; ++i) rr.g[i] = *reinterpret_cast<const Quad4*>(grow + goff[i]);   // (off lanes: the row's first group)
+            for (int p = 0; p < PP; ++p) {
+                const char* grow = xp[p] + (size_t)r * row_stride;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) rr.h[u] = *reinterpret_cast<const T*>(grow + hoff[u]);
+                for (int i = 0; i < NGL; ++i) rr[p].g[i] = *reinterpret_cast<const Quad4*>(grow + goff[i]);   // (off lanes: the row's first group)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) rr[p].h[u] = *reinterpret_cast<const T*>(grow + hoff[u]);
+            }
         };
-        auto stage = [&](int hb, const RowRegs& rr) {
-            char* srow0 = ctx.smem + a.st_off + ((hb & 1) * 4 + sidx) * a.st_pitch;
-            char* drow = srow0 + lane * 16 + (4 - s.dm) * 4;
+        auto stage = [&](int hb, const RowRegs (&rr)[PP]) {
             const bool zero = src_row(hb) < 0;
             if (!(WL_STRIP_ABLATE & 2)) {
-                if (s.dm == 0) stage_regs<0, NGL>(rr, drow, imin, imax, zero);
-                else if (s.dm == 2) stage_regs<2, NGL>(rr, drow, imin, imax, zero);
-                else stage_regs<1, NGL>(rr, drow, imin, imax, zero);
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if (hdst[u] >= 0) *reinterpret_cast<float*>(srow0 + hdst[u]) = zero ? 0.f : (float)rr.h[u];
+                for (int p = 0; p < PP; ++p) {
+                    char* srow0 = ctx.smem + a.st_off + p * a.ring + ((hb & 1) * 4 + sidx) * a.st_pitch;
+                    char* drow = srow0 + lane * 16 + (4 - s.dm) * 4;
+                    if (s.dm == 0) stage_regs<0, NGL>(rr[p], drow, imin, imax, zero);
+                    else if (s.dm == 2) stage_regs<2, NGL>(rr[p], drow, imin, imax, zero);
+                    else stage_regs<1, NGL>(rr[p], drow, imin, imax, zero);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        if (hdst[u] >= 0) *reinterpret_cast<float*>(srow0 + hdst[u]) = zero ? 0.f : (float)rr[p].h[u];
+                }
             }
         };
         // PF register sets: the rows of the next PF - 1 half-batches are in flight while one is staged.  Measured on config 5
@@ -435,7 +448,7 @@ struct WlAfbStrip {
         // every per-row branch hoisted out of its loop (2.20 ms) and one with aligned, conflict-free staging writes (2.13 ms,
         // a timing build): the level-1 kernel is bound by what the compute waves issue (VALU 0.67 of the cycles) next to a
         // memory system that is moving 4 TB/s, not by its stagers
-        RowRegs rr[PF];
+        RowRegs rr[PF][PP];
 #pragma unroll
         for (int u = 0; u < PF - 1; ++u)
             if (u < s.nhb) load(u, rr[u]);
@@ -567,7 +580,8 @@ struct WlAfbStrip {
         if (R.two) *reinterpret_cast<T*>(p + SZ) = (T)vb;
     }
 
-    static WL_DEV void compute(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int cw, int lane) {
+    // cw = the wave's run of 64 column pairs inside the strip, sub = which of the workgroup's planes (its staged ring)
+    static WL_DEV void compute(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int cw, int lane, int sub) {
         const int jp = 64 * cw + lane;                        // column pair inside the strip
         const int kA = s.k0 + 2 * jp;
         const bool active = kA < s.k1;
@@ -619,7 +633,7 @@ struct WlAfbStrip {
                 tbar += c1 - c0;
                 const int left = s.nfeeds - fed;
                 const int n = left > 2 ? 2 : left;
-                const char* slot = smem + a.st_off + (hb & 1) * 4 * a.st_pitch + soff;
+                const char* slot = smem + a.st_off + sub * a.ring + (hb & 1) * 4 * a.st_pitch + soff;
                 if (active && !(WL_STRIP_ABLATE & 1)) {
                     // Short filters: all four rows of the half-batch are requested from LDS before the first FMA.  From 14
                     // taps on the registers do not allow that at four waves per SIMD: the rows of the second feed are
@@ -681,7 +695,7 @@ struct WlAfbStrip {
                 tmath += WL_STICK() - c1;
             }
         }
-        if ((WL_STRIP_ABLATE & 8) && lane == 0 && cw == 0 && s.k0 == 0 && s.o_lo == 0) {
+        if ((WL_STRIP_ABLATE & 8) && lane == 0 && cw == 0 && sub == 0 && s.k0 == 0 && s.o_lo == 0) {
             T* o = a.ll + (size_t)plane * a.ll_ps;
             o[0] = (T)(float)(tbar >> 10); o[1] = (T)(float)(tmath >> 10);
         }
@@ -697,10 +711,16 @@ struct WlAfbStrip {
         }
         // workgroup -> (plane, segment, strip): strips of one plane and segment are neighbours on the same XCD (they
         // share halo columns), segments next
+        // A NARROW strip (the deeper levels of a wide pyramid: a whole row of 256 / 128 output columns) keeps two / one of the four
+        // compute waves busy, and the workgroup's cadence - one barrier per half-batch, ~3000 cycles whatever the width - does not
+        // speed up for it (config 5, per-level counters: the 512- and 256-column levels ran at 0.34 / 0.23 of the VALU issue rate
+        // against 0.60 for the wide ones).  Such a workgroup takes pp = 2 / 4 PLANES at once: compute waves [sub * 4 / pp, ..)
+        // work on plane `sub` out of its own staged ring, every stager takes its row of each plane.
         const int64_t lbid = wl_xcd_remap(ctx.bid, a.nblocks);
         const int per_plane = a.nstrips * a.nseg;
-        const int64_t plane = lbid / per_plane;
-        const int rem = (int)(lbid - plane * per_plane);
+        const int64_t pgroup = lbid / per_plane;
+        const int64_t plane = pgroup * a.pp;
+        const int rem = (int)(lbid - pgroup * per_plane);
         const int seg = rem / a.nstrips, strip = rem - seg * a.nstrips;
         const Strip s = geometry(a, strip, seg);
         // LDS starts as zeros: staged cells nobody writes are the zero padding
@@ -715,17 +735,28 @@ struct WlAfbStrip {
 #endif
             const int sidx = wave - WL_STRIP_CWAVES;
             if (WL_STRIP_DIRECT) {
-                switch ((s.ng + 63) >> 6) {
-                    case 1: stager_direct<1>(a, s, ctx, plane, lane, sidx); break;
-                    case 2: stager_direct<2>(a, s, ctx, plane, lane, sidx); break;
-                    case 3: stager_direct<3>(a, s, ctx, plane, lane, sidx); break;
-                    case 4: stager_direct<4>(a, s, ctx, plane, lane, sidx); break;
-                    case 5: stager_direct<5>(a, s, ctx, plane, lane, sidx); break;
-                    default: stager_direct<6>(a, s, ctx, plane, lane, sidx); break;
+                const int ngl = (s.ng + 63) >> 6;
+                if (a.pp == 4) {            // (the launcher: ngl <= 2 with four planes, <= 3 with two)
+                    if (ngl == 1) stager_direct<1, 4>(a, s, ctx, plane, lane, sidx); else stager_direct<2, 4>(a, s, ctx, plane, lane, sidx);
+                } else if (a.pp == 2) {
+                    if (ngl == 1) stager_direct<1, 2>(a, s, ctx, plane, lane, sidx);
+                    else if (ngl == 2) stager_direct<2, 2>(a, s, ctx, plane, lane, sidx);
+                    else stager_direct<3, 2>(a, s, ctx, plane, lane, sidx);
+                } else switch (ngl) {
+                    case 1: stager_direct<1, 1>(a, s, ctx, plane, lane, sidx); break;
+                    case 2: stager_direct<2, 1>(a, s, ctx, plane, lane, sidx); break;
+                    case 3: stager_direct<3, 1>(a, s, ctx, plane, lane, sidx); break;
+                    case 4: stager_direct<4, 1>(a, s, ctx, plane, lane, sidx); break;
+                    case 5: stager_direct<5, 1>(a, s, ctx, plane, lane, sidx); break;
+                    default: stager_direct<6, 1>(a, s, ctx, plane, lane, sidx); break;
                 }
             } else stager(a, s, ctx, plane, lane, sidx);
-        } else if (64 * 2 * wave < s.k1 - s.k0) {
-            compute(a, s, ctx, plane, wave, lane);
+            return;
+        }
+        const int nact = WL_STRIP_CWAVES / a.pp;              // compute waves per plane
+        const int sub = wave / nact, cw = wave - sub * nact;
+        if (plane + sub < a.NC && 64 * 2 * cw < s.k1 - s.k0) {
+            compute(a, s, ctx, plane + sub, cw, lane, sub);
         } else {
             for (int hb = 0; hb < s.nhb; ++hb) ctx.sync();   // spare wave (narrow strip): keeps the barrier count
         }

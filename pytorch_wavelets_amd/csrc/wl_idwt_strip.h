@@ -46,6 +46,7 @@ struct WlIStripArgs {
     int dma_off, dma_pitch;        // DMA ring: WL_STRIP_D slots x 8 rows (4 sources x 2 coefficient rows) x dma_pitch bytes
     int st_off, st_pitch;          // staged ring: 2 slots x 8 rows x st_pitch bytes (float32)
     int lds_bytes;
+    int pp, ring;                  // planes per workgroup (1, 2, 4: narrow strips, see WlAfbStrip::run) and the bytes of one plane's staged ring
     int quad_ok;                   // every lane's 4 output columns are one aligned store (OW % 4 == 0, aligned y)
     int guard;                     // tap-relation guard (wl_common.h): 1 = run only if both highpass banks are the quadrature mirrors of
                                    // their lowpass banks (the QMF variant), 2 = only if not (its armed two-bank fallback), 0 = no check
@@ -183,10 +184,16 @@ struct WlSfbStrip {
     static const int MAXG = 6;
     typedef T Quad4 __attribute__((ext_vector_type(4), aligned(sizeof(T)), may_alias));   // element-aligned: any row width / pitch
     template <int NGL> struct RowRegs { Quad4 g[2][NGL]; T t[2]; };
-    template <int NGL>
+    // PP = planes of this workgroup: the wave takes the two rows of its band for each of them, into that plane's ring
+    template <int NGL, int PP>
     static WL_DEV void stager_direct(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int lane, int b) {
-        const char* bp = b == 0 ? reinterpret_cast<const char*>(a.ll + (size_t)plane * a.ll_ps)
-                                : reinterpret_cast<const char*>(a.highs + ((size_t)plane * 3 + (b - 1)) * ((size_t)a.Kh * a.Kw));
+        const char* bp[PP];
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {      // (a last workgroup with fewer planes stages its last plane again: nobody reads it)
+            const int64_t pl = plane + p < a.NC ? plane + p : a.NC - 1;
+            bp[p] = b == 0 ? reinterpret_cast<const char*>(a.ll + (size_t)pl * a.ll_ps)
+                           : reinterpret_cast<const char*>(a.highs + ((size_t)pl * 3 + (b - 1)) * ((size_t)a.Kh * a.Kw));
+        }
         const int row_stride = (b == 0 ? a.ll_rs : a.Kw) * SZ;
         const int e_last = s.e_first + s.nfeeds - 1;
         int goff[NGL];
@@ -216,20 +223,26 @@ struct WlSfbStrip {
             const int NTL = (!a.per && t0 <= q_hi && t0 < a.Kw) ? a.Kw - t0 : 0;
             if (lane < NTL) { tdst = (t0 + lane - s.c0a + s.dm) * 4; toff = (t0 + lane) * SZ; }
         }
-        auto load = [&](int h, RowRegs<NGL>& rr) {
+        auto load = [&](int h, RowRegs<NGL> (&rrp)[PP]) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 int e = s.e_first + 2 * h + r;
                 e = e < e_last ? e : e_last;
                 const int row = a.per ? wl_pmod(e, a.Kh) : e;
-                const char* grow = bp + (size_t)row * row_stride;
 #pragma unroll
-                for (int i = 0; i < NGL; ++i) rr.g[r][i] = *reinterpret_cast<const Quad4*>(grow + goff[i]);
-                rr.t[r] = *reinterpret_cast<const T*>(grow + toff);
+                for (int p = 0; p < PP; ++p) {
+                    const char* grow = bp[p] + (size_t)row * row_stride;
+#pragma unroll
+                    for (int i = 0; i < NGL; ++i) rrp[p].g[r][i] = *reinterpret_cast<const Quad4*>(grow + goff[i]);
+                    rrp[p].t[r] = *reinterpret_cast<const T*>(grow + toff);
+                }
             }
         };
-        auto stage = [&](int hb, const RowRegs<NGL>& rr) {
-            char* sslot = ctx.smem + a.st_off + (hb & 1) * 8 * a.st_pitch + 2 * b * a.st_pitch;
+        auto stage = [&](int hb, const RowRegs<NGL> (&rrp)[PP]) {
+#pragma unroll
+          for (int p = 0; p < PP; ++p) {
+            const RowRegs<NGL>& rr = rrp[p];
+            char* sslot = ctx.smem + a.st_off + p * a.ring + (hb & 1) * 8 * a.st_pitch + 2 * b * a.st_pitch;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 char* drow = sslot + r * a.st_pitch + lane * 16 + s.dm * 4;
@@ -248,10 +261,11 @@ struct WlSfbStrip {
                 }
                 if (tdst >= 0) *reinterpret_cast<float*>(sslot + r * a.st_pitch + tdst) = (float)rr.t[r];
             }
+          }
         };
         // PF register sets (WL_STRIP_PF, see wl_dwt_strip.h): the coefficient rows of PF - 1 half-batches in flight
         static const int PF = WL_STRIP_PF;
-        RowRegs<NGL> rr[PF];
+        RowRegs<NGL> rr[PF][PP];
 #pragma unroll
         for (int u = 0; u < PF - 1; ++u)
             if (u < s.nhb) load(u, rr[u]);
@@ -406,7 +420,8 @@ struct WlSfbStrip {
         }
     }
 
-    static WL_DEV void compute(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int cw, int lane) {
+    // cw = the wave's run of 64 lane units inside the strip, sub = which of the workgroup's planes (its staged ring)
+    static WL_DEV void compute(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int cw, int lane, int sub) {
         const int u = s.u0 + 64 * cw + lane;                  // lane unit: output columns 4u .. 4u+3
         const bool active = u < s.u1;
         Wave R;
@@ -454,7 +469,7 @@ struct WlSfbStrip {
                 ctx.sync();
                 const int left = s.nfeeds - fed;
                 const int n = left > 2 ? 2 : left;
-                const char* slot = smem + a.st_off + (hb & 1) * 8 * a.st_pitch + soff;
+                const char* slot = smem + a.st_off + sub * a.ring + (hb & 1) * 8 * a.st_pitch + soff;
                 if (active) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
@@ -517,10 +532,12 @@ struct WlSfbStrip {
                                      : wl_taps_qmf(a.g_w_lo, a.g_w_hi, LT) && wl_taps_qmf(a.g_h_lo, a.g_h_hi, LT);
             if (!wl_guard_pass(a.guard, holds)) return;
         }
+        // (a narrow strip - one or two compute waves' worth - takes pp = 4 / 2 planes per workgroup: WlAfbStrip::run)
         const int64_t lbid = wl_xcd_remap(ctx.bid, a.nblocks);
         const int per_plane = a.nstrips * a.nseg;
-        const int64_t plane = lbid / per_plane;
-        const int rem = (int)(lbid - plane * per_plane);
+        const int64_t pgroup = lbid / per_plane;
+        const int64_t plane = pgroup * a.pp;
+        const int rem = (int)(lbid - pgroup * per_plane);
         const int seg = rem / a.nstrips, strip = rem - seg * a.nstrips;
         const Strip s = geometry(a, strip, seg);
         for (int i = tid * 16; i < a.lds_bytes; i += kThreads * 16) {
@@ -534,17 +551,27 @@ struct WlSfbStrip {
 #endif
             const int b = wave - WL_STRIP_CWAVES;
             if (WL_STRIP_DIRECT) {
-                switch ((s.ng + 63) >> 6) {
-                    case 1: stager_direct<1>(a, s, ctx, plane, lane, b); break;
-                    case 2: stager_direct<2>(a, s, ctx, plane, lane, b); break;
-                    case 3: stager_direct<3>(a, s, ctx, plane, lane, b); break;
-                    case 4: stager_direct<4>(a, s, ctx, plane, lane, b); break;
-                    case 5: stager_direct<5>(a, s, ctx, plane, lane, b); break;
-                    default: stager_direct<6>(a, s, ctx, plane, lane, b); break;
+                const int ngl = (s.ng + 63) >> 6;
+                // (the launcher: ngl = 1 with four planes, <= 2 with two - what strips of one / two compute waves need; a wave holds
+                // 2 rows x ngl x pp groups x WL_STRIP_PF sets in registers, 128 of them at <2, 4> in float32)
+                if (a.pp == 4) stager_direct<1, 4>(a, s, ctx, plane, lane, b);
+                else if (a.pp == 2) {
+                    if (ngl == 1) stager_direct<1, 2>(a, s, ctx, plane, lane, b); else stager_direct<2, 2>(a, s, ctx, plane, lane, b);
+                } else switch (ngl) {
+                    case 1: stager_direct<1, 1>(a, s, ctx, plane, lane, b); break;
+                    case 2: stager_direct<2, 1>(a, s, ctx, plane, lane, b); break;
+                    case 3: stager_direct<3, 1>(a, s, ctx, plane, lane, b); break;
+                    case 4: stager_direct<4, 1>(a, s, ctx, plane, lane, b); break;
+                    case 5: stager_direct<5, 1>(a, s, ctx, plane, lane, b); break;
+                    default: stager_direct<6, 1>(a, s, ctx, plane, lane, b); break;
                 }
             } else stager(a, s, ctx, plane, lane, b);
-        } else if (64 * wave < s.u1 - s.u0) {
-            compute(a, s, ctx, plane, wave, lane);
+            return;
+        }
+        const int nact = WL_STRIP_CWAVES / a.pp;              // compute waves per plane
+        const int sub = wave / nact, cw = wave - sub * nact;
+        if (plane + sub < a.NC && 64 * cw < s.u1 - s.u0) {
+            compute(a, s, ctx, plane + sub, cw, lane, sub);
         } else {
             for (int hb = 0; hb < s.nhb; ++hb) ctx.sync();
         }

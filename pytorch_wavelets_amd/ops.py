@@ -518,10 +518,10 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
     return y
 
 
-# narrowest float16 level (columns) the one-level strip kernels take without `force`; 0 = the byte rule of float32 (rows of
-# 2 KiB analysis / 1 KiB synthesis).  Mirrors WL_STRIP_MINW / WL_ISTRIP_MINW of csrc/wl_strip_api.inc.
-STRIP_MINW_F16 = 256
-ISTRIP_MINW_F16 = 0
+# narrowest level (columns) the one-level strip kernels are asked for without `force`.  The launchers (csrc/wl_strip_api.inc) decide:
+# rows of 2 KiB (analysis; float16: 256 columns) / 1 KiB (synthesis) and wider always, narrower ones when the launch can give every
+# compute wave of its workgroups a plane's strip (several planes per workgroup, round 5), workgroups for every CU in both cases.
+STRIP_MINW = 128
 TAP_SCRATCH_FLOATS = 16   # WL_TAP_SCRATCH_FLOATS of csrc/wl_lattice.h
 STRIP_LATTICE = True      # hinted strip launches of 12 taps and more run the lattice variant (False: the QMF variant; A/B measurements)
 ROWS_LATTICE = True       # hinted fused analysis launches of 10-20 taps run the lattice variant (False: A/B measurements; 14-20 taps then go level by level)
@@ -544,8 +544,8 @@ def afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=False):
     if (x.dtype == torch.float64 or h_h_lo.numel() != L or L % 2 or L > 20 or W < 2 * L or H < 2 or x.numel() == 0
             or (mode in (2, 6) and W % 4) or (mode == 2 and (H + (H & 1) < L - 1 or W + (W & 1) < L - 1))):
         return None
-    if not force and (W < STRIP_MINW_F16 if es == 2 and STRIP_MINW_F16 else W * es < 2048):
-        return None                      # the engine's policy: narrower rows stay on the tile kernels
+    if not force and W < STRIP_MINW:
+        return None                      # the engine's policy: narrower rows stay on the tile kernels (the launcher decides the rest)
     x, x_ps, x_rs = _planes(x)
     qmf = bool(getattr(_HINTS, 'qmf', False))
     key = ('afbs', x.device, x.dtype, N * C, H, W, x_ps, x_rs, L, mode, bool(force), qmf)
@@ -585,7 +585,7 @@ def sfb2d_stream(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None, f
     OW = 2 * Kw if mode == 2 else 2 * Kw - L + 2
     if out_hw is not None:
         OH, OW = min(OH, out_hw[0]), min(OW, out_hw[1])
-    if not force and ((OW < ISTRIP_MINW_F16 if es == 2 and ISTRIP_MINW_F16 else OW * es < 1024) or OW % 4):
+    if not force and (OW < STRIP_MINW or OW % 4):
         return None                      # the engine's policy: narrow rows / unaligned 4-column groups stay on the other kernels
     ll, ll_ps, ll_rs = _planes(ll)
     highs = highs.contiguous()

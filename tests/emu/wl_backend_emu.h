@@ -20,6 +20,8 @@
 inline int wl_num_cus() { return 2; }
 inline const char* wl_last_kernel_ptr = "";
 inline const char* wl_last_kernel_name() { return wl_last_kernel_ptr; }
+inline long long wl_last_grid_v = 0;
+inline long long wl_last_grid_value() { return wl_last_grid_v; }
 inline const char* wl_kernel_log_buf[32] = {};
 inline long long wl_kernel_log_n = 0;
 inline long long wl_launch_count_value() { return wl_kernel_log_n; }
@@ -116,7 +118,7 @@ template <typename K>
 static int wl_launch_named(const typename K::Args& a, int64_t nblocks, size_t lds, void* /*stream*/, const char* name, bool primary) {
     if (nblocks <= 0) return 0;
     if (lds > 160 * 1024) return -2;
-    if (primary) wl_last_kernel_ptr = name;
+    if (primary) { wl_last_kernel_ptr = name; wl_last_grid_v = nblocks; }
     wl_kernel_log_buf[wl_kernel_log_n++ & 31] = name;
     const int nt = K::kThreads;
     const size_t kStack = 256 * 1024;

@@ -965,3 +965,13 @@ def test_inference_mode_tensors_take_the_hinted_kernels_and_stay_correct():
             assert np.abs(a.numpy() - b).max() <= 1e-5 * np.abs(b).max()
     finally:
         ops.FUSED_STRIPS = prev
+
+
+@pytest.mark.parametrize('wave,mode,dtype,H,W', __import__('_packed_cases').PACKED_CASES)
+def test_strip_kernels_take_several_planes_per_workgroup_on_narrow_levels(wave, mode, dtype, H, W):
+    """csrc/wl_dwt_strip.h / wl_idwt_strip.h: a level whose whole row is one or two compute waves' worth of columns runs four / two
+    planes per workgroup (own staged ring and compute waves per plane) - against the oracle, incl. the short last plane group;
+    the grid of the launch is the witness."""
+    import _packed_cases as PC
+    with emu_backend.emulated():
+        PC.check_packed('cpu', wave, mode, dtype, H, W, planes=19)

@@ -901,3 +901,12 @@ def test_lattice_variant_of_the_fused_synthesis_kernel(wave, mode, J, dtype):
 def test_lattice_variant_of_the_fused_synthesis_kernel_rejections():
     import _lattice_cases as LC
     LC.check_irows_lattice_rejections(DEV, shape=(3, 2, 160, 512))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('wave,mode,dtype,H,W', __import__('_packed_cases').PACKED_CASES)
+def test_strip_kernels_take_several_planes_per_workgroup_on_narrow_levels(wave, mode, dtype, H, W):
+    """Narrow levels on the one-level strip kernels: four / two planes per workgroup (csrc/wl_dwt_strip.h `run`) - 2051 planes (the
+    chip stays full, the last plane group is short) against the oracle; the grid of the launch is the witness."""
+    import _packed_cases as PC
+    PC.check_packed('cuda:0', wave, mode, dtype, H, W, planes=2051)
