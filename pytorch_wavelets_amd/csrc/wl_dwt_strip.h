@@ -356,7 +356,7 @@ struct WlAfbStrip {
     // PP = planes of this workgroup (run()): the wave takes row `sidx` of every half-batch of each of them, into that plane's ring
     template <int NGL, int PP>
     static WL_DEV void stager_direct(const Args& a, const Strip& s, const WlCtx& ctx, int64_t plane, int lane, int sidx) {
-        static_assert(LROWS == 1, "the direct stager takes one row per wave and half-batch");
+        static_assert(LROWS == 1 || PP == 1, "several planes per workgroup: four stager waves, one row each");
         const char* xp[PP];
 #pragma unroll
         for (int p = 0; p < PP; ++p) {      // (a last workgroup with fewer planes stages its last plane again: nobody reads it)
@@ -410,36 +410,37 @@ struct WlAfbStrip {
                 }
             }
         }
-        auto src_row = [&](int h) {
-            int e = e_first + 4 * h + sidx;
+        // (register rows of a half-batch: q = p * LROWS + r - plane p of the workgroup, row sidx * LROWS + r of the half-batch)
+        auto src_row = [&](int h, int r) {
+            int e = e_first + 4 * h + sidx * LROWS + r;
             e = e < e_last ? e : e_last;
             return (unsigned)e < (unsigned)a.H ? e : wl_ext(e, a.H, a.ext);   // -1: a row of zeros
         };
-        auto load = [&](int h, RowRegs (&rr)[PP]) {
-            int r = src_row(h);
-            r = r < 0 ? 0 : r;
+        auto load = [&](int h, RowRegs (&rr)[PP * LROWS]) {
 #pragma unroll
-            for (int p = 0; p < PP; ++p) {
-                const char* grow = xp[p] + (size_t)r * row_stride;
+            for (int q = 0; q < PP * LROWS; ++q) {
+                int r = src_row(h, q % LROWS);
+                r = r < 0 ? 0 : r;
+                const char* grow = xp[q / LROWS] + (size_t)r * row_stride;
 #pragma unroll
-                for (int i = 0; i < NGL; ++i) rr[p].g[i] = *reinterpret_cast<const Quad4*>(grow + goff[i]);   // (off lanes: the row's first group)
+                for (int i = 0; i < NGL; ++i) rr[q].g[i] = *reinterpret_cast<const Quad4*>(grow + goff[i]);   // (off lanes: the row's first group)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) rr[p].h[u] = *reinterpret_cast<const T*>(grow + hoff[u]);
+                for (int u = 0; u < 2; ++u) rr[q].h[u] = *reinterpret_cast<const T*>(grow + hoff[u]);
             }
         };
-        auto stage = [&](int hb, const RowRegs (&rr)[PP]) {
-            const bool zero = src_row(hb) < 0;
+        auto stage = [&](int hb, const RowRegs (&rr)[PP * LROWS]) {
             if (!(WL_STRIP_ABLATE & 2)) {
 #pragma unroll
-                for (int p = 0; p < PP; ++p) {
-                    char* srow0 = ctx.smem + a.st_off + p * a.ring + ((hb & 1) * 4 + sidx) * a.st_pitch;
+                for (int q = 0; q < PP * LROWS; ++q) {
+                    const bool zero = src_row(hb, q % LROWS) < 0;
+                    char* srow0 = ctx.smem + a.st_off + (q / LROWS) * a.ring + ((hb & 1) * 4 + sidx * LROWS + q % LROWS) * a.st_pitch;
                     char* drow = srow0 + lane * 16 + (4 - s.dm) * 4;
-                    if (s.dm == 0) stage_regs<0, NGL>(rr[p], drow, imin, imax, zero);
-                    else if (s.dm == 2) stage_regs<2, NGL>(rr[p], drow, imin, imax, zero);
-                    else stage_regs<1, NGL>(rr[p], drow, imin, imax, zero);
+                    if (s.dm == 0) stage_regs<0, NGL>(rr[q], drow, imin, imax, zero);
+                    else if (s.dm == 2) stage_regs<2, NGL>(rr[q], drow, imin, imax, zero);
+                    else stage_regs<1, NGL>(rr[q], drow, imin, imax, zero);
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
-                        if (hdst[u] >= 0) *reinterpret_cast<float*>(srow0 + hdst[u]) = zero ? 0.f : (float)rr[p].h[u];
+                        if (hdst[u] >= 0) *reinterpret_cast<float*>(srow0 + hdst[u]) = zero ? 0.f : (float)rr[q].h[u];
                 }
             }
         };
@@ -448,7 +449,7 @@ struct WlAfbStrip {
         // every per-row branch hoisted out of its loop (2.20 ms) and one with aligned, conflict-free staging writes (2.13 ms,
         // a timing build): the level-1 kernel is bound by what the compute waves issue (VALU 0.67 of the cycles) next to a
         // memory system that is moving 4 TB/s, not by its stagers
-        RowRegs rr[PF][PP];
+        RowRegs rr[PF][PP * LROWS];
 #pragma unroll
         for (int u = 0; u < PF - 1; ++u)
             if (u < s.nhb) load(u, rr[u]);
@@ -736,13 +737,19 @@ struct WlAfbStrip {
             const int sidx = wave - WL_STRIP_CWAVES;
             if (WL_STRIP_DIRECT) {
                 const int ngl = (s.ng + 63) >> 6;
-                if (a.pp == 4) {            // (the launcher: ngl <= 2 with four planes, <= 3 with two)
-                    if (ngl == 1) stager_direct<1, 4>(a, s, ctx, plane, lane, sidx); else stager_direct<2, 4>(a, s, ctx, plane, lane, sidx);
-                } else if (a.pp == 2) {
-                    if (ngl == 1) stager_direct<1, 2>(a, s, ctx, plane, lane, sidx);
-                    else if (ngl == 2) stager_direct<2, 2>(a, s, ctx, plane, lane, sidx);
-                    else stager_direct<3, 2>(a, s, ctx, plane, lane, sidx);
-                } else switch (ngl) {
+                if constexpr (LROWS == 1) {   // (several planes: four stager waves, one row of each plane per wave)
+                    if (a.pp == 4) {          // (the launcher: ngl <= 2 with four planes, <= 3 with two)
+                        if (ngl == 1) stager_direct<1, 4>(a, s, ctx, plane, lane, sidx); else stager_direct<2, 4>(a, s, ctx, plane, lane, sidx);
+                        return;
+                    }
+                    if (a.pp == 2) {
+                        if (ngl == 1) stager_direct<1, 2>(a, s, ctx, plane, lane, sidx);
+                        else if (ngl == 2) stager_direct<2, 2>(a, s, ctx, plane, lane, sidx);
+                        else stager_direct<3, 2>(a, s, ctx, plane, lane, sidx);
+                        return;
+                    }
+                }
+                switch (ngl) {
                     case 1: stager_direct<1, 1>(a, s, ctx, plane, lane, sidx); break;
                     case 2: stager_direct<2, 1>(a, s, ctx, plane, lane, sidx); break;
                     case 3: stager_direct<3, 1>(a, s, ctx, plane, lane, sidx); break;

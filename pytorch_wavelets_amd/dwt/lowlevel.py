@@ -15,6 +15,7 @@ _MODE_TO_INT = {'zero': 0, 'symmetric': 1, 'per': 2, 'periodization': 2, 'consta
 _INT_TO_MODE = {0: 'zero', 1: 'symmetric', 2: 'periodization', 3: 'constant', 4: 'reflect',
                 5: 'replicate', 6: 'periodic'}
 FUSED_LEVELS = True   # set False to force one launch per level (A/B measurements)
+WIDE_ONE_LEVEL = 640  # coefficient-row pairs: a synthesis level left on its own whose output is at least this wide goes to the one-level strip kernel (SFB2DMulti.forward)
 _FILTERBANK_MODES = (0, 1, 2, 4, 6)   # the ones afb1d/sfb1d accept upstream (dwt/lowlevel.py:134-170)
 
 
@@ -123,10 +124,24 @@ class SFB2DMulti(Function):
                 if FUSED_LEVELS and m < n:
                     res = ops.sfb2d_small(ll, list(yh[j - m + 1:j + 1]), g0_row, g1_row, g0_col, g1_col, mode)
                 n = m
+            took_strip = False
             while FUSED_LEVELS and n >= 1 and res is None:
+                if n == 1 and 2 * yh[j].shape[-1] >= WIDE_ONE_LEVEL:
+                    # a single WIDE level: the one-level strip kernel is ahead of the fused kernel's one-level form (same-box, float32,
+                    # tools/gpu_r5u.py: 64x3x1024^2 0.333 -> 0.309 ms, 128x3x768^2 0.362 -> 0.342, 128x3x640^2 0.244 -> 0.228);
+                    # when it declines (few planes, a width that is no multiple of four) the fused kernel is asked as before
+                    h = yh[j]
+                    lc = ll[..., :h.shape[-2], :h.shape[-1]]
+                    one = ops.sfb2d_stream(lc, h, g0_row, g1_row, g0_col, g1_col, mode)
+                    if one is not None:
+                        ll_shapes[j] = tuple(ll.shape[-2:])
+                        ll, j, took_strip = one, j - 1, True
+                        break
                 res = ops.sfb2d_fused(ll, list(yh[j - n + 1:j + 1]), g0_row, g1_row, g0_col, g1_col, mode)
                 if res is None:
                     n -= 1
+            if took_strip:
+                continue
             if res is not None:
                 L = g0_row.numel()
                 sh = tuple(ll.shape[-2:])

@@ -595,7 +595,7 @@ def test_grayscale_channels_last_strides_are_not_trusted(fused):
     from pytorch_wavelets_amd.dwt import lowlevel as ll
     torch.manual_seed(3)
     x = torch.randn(4, 1, 20, 20)
-    xfm, ifm = pw.DWTForward(J=2, wave='db2', mode='symmetric'), pw.DWTInverse(wave='db2', mode='symmetric')
+    xfm, ifm = pw.DWTForward(J=1, wave='db2', mode='symmetric'), pw.DWTInverse(wave='db2', mode='symmetric')
     dx, di = pw.DTCWTForward(J=2), pw.DTCWTInverse()
     prev = ll.FUSED_LEVELS
     ll.FUSED_LEVELS = fused
@@ -977,3 +977,22 @@ def test_strip_kernels_take_several_planes_per_workgroup_on_narrow_levels(wave, 
     import _packed_cases as PC
     with emu_backend.emulated():
         PC.check_packed('cpu', wave, mode, dtype, H, W, planes=19)
+
+
+def test_wide_single_synthesis_level_prefers_the_strip_kernel():
+    """SFB2DMulti's ladder: a level left on its own whose output is at least lowlevel.WIDE_ONE_LEVEL columns wide goes to the one-level
+    strip kernel when that takes it (width a multiple of four), to the fused kernel's one-level form otherwise - both against the oracle."""
+    from oracle import wavelet_oracle as wo
+    rng = np.random.RandomState(7)
+    for W, want in ((704, 'WlSfbStrip<'), (698, 'WlSfbRows<')):
+        x = rng.randn(2, 2, 40, W)
+        xfm, ifm = pw.DWTForward(J=1, wave='db2', mode='symmetric'), pw.DWTInverse(wave='db2', mode='symmetric')
+        f = [b.double().numpy().ravel() for b in (ifm.g0_col, ifm.g1_col, ifm.g0_row, ifm.g1_row)]
+        with emu_backend.emulated():
+            yl, yh = xfm(torch.tensor(x, dtype=torch.float32))
+            rec = ifm((yl, yh))
+            kern = emu_backend.handle().wl_last_kernel().decode()
+        assert want in kern, (W, kern)
+        ref = wo.dwt_inverse(yl.double().numpy(), [h.double().numpy() for h in yh], f[0], f[1], f[2], f[3], 'symmetric')
+        assert float(np.abs(rec.double().numpy() - ref).max()) <= 1e-5 * float(np.abs(ref).max())
+        assert float(np.abs(rec.double().numpy() - x).max()) < 1e-4
