@@ -115,6 +115,15 @@ int wl_dwt2d_synthesis(const void* ll, int64_t ll_plane_stride, int ll_row_strid
 int wl_dwt2d_analysis_fused(const void* x, void* yl, void* const* yh, int dtype, int64_t planes, int H,
                             int W, int nlev, const void* h_w_lo, const void* h_w_hi, const void* h_h_lo,
                             const void* h_h_hi, int L, int mode, int strips, void* tap_scratch, void* stream);
+/* The same with x (planes, H, W) through a plane stride and a row pitch (elements; both whole 16-byte pieces, x 16-byte aligned):
+ * the input of the level loop's SECOND and later iterations when the first level ran on another kernel (reference
+ * dwt/transform2d.py:63-74: `ll` of one AFB2D.forward feeds the next).  W itself need not be a whole number of pieces then - the
+ * odd-width ll below a 1024-wide image, 515 columns - as long as the row's last piece lies inside the pitch (the caller owns the
+ * elements behind the row; the kernel overwrites what it loaded from there before any lane reads it). */
+int wl_dwt2d_analysis_fused_strided(const void* x, int64_t x_plane_stride, int x_row_stride, void* yl, void* const* yh,
+                                    int dtype, int64_t planes, int H, int W, int nlev, const void* h_w_lo,
+                                    const void* h_w_hi, const void* h_h_lo, const void* h_h_hi, int L, int mode,
+                                    int strips, void* tap_scratch, void* stream);
 
 /* All `nlev` (1..3) synthesis levels in ONE launch = the body of DWTInverse.forward's level loop
  * (dwt/transform2d.py:131-148) = nlev x SFB2D.forward (dwt/lowlevel.py:671-680): yl (planes, Kh[nlev-1],

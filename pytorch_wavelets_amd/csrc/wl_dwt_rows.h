@@ -208,7 +208,9 @@ struct WlAfbRows {
         for (int u = 0; u < 2; ++u) {
             const int it = lane + 64 * u;
             hdst[u] = hsrc[u] = -1;
-            if (ext != WL_EXT_ZERO && it < LROWS * NH) {
+            // (zero mode: the halo cells stay zero - unless the row ends inside its last 16-byte piece, whose tail then lands in the
+            // right halo cells: they are cleared like the mirrored cells of the other modes are written, wl_ext = -1)
+            if ((ext != WL_EXT_ZERO || row_bytes % 16 != 0) && it < LROWS * NH) {
                 const int r = rfirst + it / NH, c = it % NH;
                 const int e = c < g.hl ? c - g.hl : g.Ws + (c - g.hl);
                 const int s = wl_ext(e, g.Ws, ext);

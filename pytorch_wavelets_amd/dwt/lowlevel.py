@@ -217,13 +217,13 @@ class AFB2DMulti(Function):
             if res is None:
                 n = min(3, J - done)
             while FUSED_LEVELS and n >= 1 and res is None:   # e.g. periodization: one level per streaming launch
-                res = ops.afb2d_fused(ll, h0_row, h1_row, h0_col, h1_col, mode, n)
+                res = ops.afb2d_fused(ll, h0_row, h1_row, h0_col, h1_col, mode, n, whole=J == 1)
                 if res is None:
                     n -= 1
             if res is None:
                 n = 1
                 shapes.append(tuple(ll.shape[-2:]))
-                ll, high = ops.afb2d_best(ll, h0_row, h1_row, h0_col, h1_col, mode, pad_ll=_PAD_LL and done + 1 < J)
+                ll, high = ops.afb2d_best(ll, h0_row, h1_row, h0_col, h1_col, mode, pad_ll=_PAD_LL and done + 1 < J, more_levels=done + 1 < J)
                 yh.append(high)
             else:
                 shapes.append(tuple(ll.shape[-2:]))

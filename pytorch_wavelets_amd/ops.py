@@ -334,11 +334,13 @@ def _num_cus(device):
     return _CU_COUNT[idx]
 
 
-def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None):
+def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None, whole=True):
     """`nlev` (1..3) analysis levels in ONE launch of the streaming kernel (one workgroup per plane, LL_j stay in LDS,
     HBM traffic = the algorithmic minimum).  Returns (yl, [yh_0..]) or None when the kernel does not cover the
     configuration (caller goes level by level).  strips: 0 = only when the planes alone fill the chip (the engine cuts
-    some planes in two to fill whole rounds), 1 = force, whole planes only, 2 = force, every plane cut in two."""
+    some planes in two to fill whole rounds), 1 = force, whole planes only, 2 = force, every plane cut in two.  x may be a row-padded
+    view (rows on 16-byte addresses; the width itself need not be a whole number of 16-byte pieces then).  `whole`: this launch is the
+    entire transform (a one-level launch on rows of 2-3 KiB is taken only then: inside a longer pyramid the strip kernel is ahead)."""
     import ctypes
     _check_tensor(x, 'x')
     if strips is None:
@@ -355,12 +357,22 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None):
     lattice = (same and qmf and ROWS_LATTICE and L in (8, 10, 12, 14, 16, 20) and L >= ROWS_LATTICE_MIN
                and (L > 12 or x.numel() >= LATTICE_MIN_ELEMS))
     if (x.dtype == torch.float64 or nlev < 1 or nlev > 3 or h_h_lo.numel() != L or L % 2 or (L > 12 and not lattice)
-            or (W * x.element_size()) % 16 or (nlev > 1 and mode not in (0, 1, 4)) or x.numel() == 0
+            or (nlev > 1 and mode not in (0, 1, 4)) or x.numel() == 0
             or (strips == 0 and 8 * N * C < 3 * _num_cus(x.device)) or strips > 2):
         return None
-    x = x.contiguous()
-    key = ('afb', x.device, x.dtype, N * C, H, W, L, mode, nlev, strips, lattice)
-    if key in _FUSED_DECLINED or x.data_ptr() % 16:
+    # rows as whole 16-byte pieces: a dense x whose width is one, or a row-padded view (the ll that afb2d_stream(pad_ll=True) /
+    # afb2d(pad_ll=True) return: any width, the pitch a whole number of pieces and wide enough for the row's last piece)
+    es = x.element_size()
+    # float32 rows of 2-3 KiB (three pieces per row, round 5): two and more levels per launch, or a one-level transform.  A single
+    # level of a longer pyramid stays with the strip kernel (tools/gpu_r5v.py, same process: 128x3x768^2 J = 3 as strip + two fused levels
+    # 0.438 ms, as fused + strip + fused 0.464; the last level of 64x3x1024^2 J = 2 on the padded ll 0.465 against 0.456 on the strip kernel)
+    if W * es > 2048 and (not ROWS_3KIB or (nlev < 2 and not whole)):
+        return None
+    x, x_ps, x_rs = _planes(x)
+    if (x_rs * es) % 16 or (x_ps * es) % 16 or x.data_ptr() % 16 or (W * es + 15) // 16 * 16 > x_rs * es:
+        return None
+    key = ('afb', x.device, x.dtype, N * C, H, W, x_ps, x_rs, L, mode, nlev, strips, lattice)
+    if key in _FUSED_DECLINED:
         return None
     ent = _hinted_taps((h_w_lo, h_w_hi, h_h_lo, h_h_hi), x, L, False) if lattice else [tuple(_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi)), None, 0]
     (hwl, hwh, hhl, hhh), scratch, prepared = ent
@@ -372,13 +384,13 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None):
         yh.append(torch.empty((N, C, 3, h, w), dtype=x.dtype, device=x.device))
     yl = torch.empty((N, C, h, w), dtype=x.dtype, device=x.device)
     ptrs = (ctypes.c_void_p * nlev)(*[t.data_ptr() for t in yh])
-    rc = _call('wl_dwt2d_analysis_fused', x, x.data_ptr(), yl.data_ptr(), ptrs, _DTYPES[x.dtype], N * C, H, W, nlev,
+    rc = _call('wl_dwt2d_analysis_fused_strided', x, x.data_ptr(), x_ps, x_rs, yl.data_ptr(), ptrs, _DTYPES[x.dtype], N * C, H, W, nlev,
                hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(), hhh.data_ptr(), L, mode, strips | same,
                None if scratch is None else scratch.data_ptr(), _stream(x))
     if rc == -3:
         _remember_decline(key)
         return None
-    _lib.check(rc, 'wl_dwt2d_analysis_fused')
+    _lib.check(rc, 'wl_dwt2d_analysis_fused_strided')
     _mark_prepared(ent)
     return yl, yh
 
@@ -533,10 +545,15 @@ LATTICE_MIN_ELEMS = 40000000
 IROWS_LATTICE_MIN = 8     # WL_IROWS_LAT_MIN of csrc/wl_idwt_rows.h: the fused synthesis takes the lattice from 8 taps on (the metric's inverse: -6 %)
 
 
-def afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=False):
+ROWS_3KIB = True        # float32 rows of 2-3 KiB on the fused analysis kernel (three 1 KiB pieces per row; False: A/B measurements)
+PAD_ODD_LL = True    # an inner-level ll of the strip kernel whose rows are no whole 16-byte pieces is written at a padded row pitch (A/B: False)
+
+
+def afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=False, pad_ll=False):
     """One analysis level on the streaming strip kernel (wl_dwt2d_analysis_stream): x (N,C,H,W) -> (ll, highs) like afb2d,
     or None when the kernel does not cover the configuration (rows that are not whole 16-byte pieces, odd tap counts,
-    float64, too few workgroups to fill the chip unless `force`)."""
+    float64, too few workgroups to fill the chip unless `force`).  `pad_ll`: an ll whose rows are no whole 16-byte pieces comes
+    back as a view of a buffer with such a row pitch (what afb2d_fused needs of its input)."""
     _check_tensor(x, 'x')
     N, C, H, W = x.shape
     L = h_w_lo.numel()
@@ -548,15 +565,19 @@ def afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=False):
         return None                      # the engine's policy: narrower rows stay on the tile kernels (the launcher decides the rest)
     x, x_ps, x_rs = _planes(x)
     qmf = bool(getattr(_HINTS, 'qmf', False))
-    key = ('afbs', x.device, x.dtype, N * C, H, W, x_ps, x_rs, L, mode, bool(force), qmf)
+    key = ('afbs', x.device, x.dtype, N * C, H, W, x_ps, x_rs, L, mode, bool(force), qmf, bool(pad_ll))
     if key in _FUSED_DECLINED:
         return None
     ent = _hinted_taps((h_w_lo, h_w_hi, h_h_lo, h_h_hi), x, L, False) if qmf else [tuple(_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi)), None, 0]
     (hwl, hwh, hhl, hhh), scratch, prepared = ent
     Kh, Kw = coeff_len(H, L, mode), coeff_len(W, L, mode)
-    ll = torch.empty((N, C, Kh, Kw), dtype=x.dtype, device=x.device)
+    q = 16 // es
+    Kp = (Kw + q - 1) // q * q if pad_ll else Kw
+    ll = torch.empty((N, C, Kh, Kp), dtype=x.dtype, device=x.device)
+    if Kp != Kw:
+        ll = ll[..., :Kw]
     highs = torch.empty((N, C, 3, Kh, Kw), dtype=x.dtype, device=x.device)
-    rc = _call('wl_dwt2d_analysis_stream', x, x.data_ptr(), x_ps, x_rs, ll.data_ptr(), Kh * Kw, Kw, highs.data_ptr(),
+    rc = _call('wl_dwt2d_analysis_stream', x, x.data_ptr(), x_ps, x_rs, ll.data_ptr(), Kh * Kp, Kp, highs.data_ptr(),
                _DTYPES[x.dtype], N * C, H, W, hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(), hhh.data_ptr(), L, mode,
                (1 if force else 0) | (2 if qmf else 0) | prepared, None if scratch is None else scratch.data_ptr(), _stream(x))
     if rc == -3:
@@ -614,14 +635,16 @@ def sfb2d_best(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None):
     return res if res is not None else sfb2d(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=out_hw)
 
 
-def afb2d_best(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, pad_ll=False):
+def afb2d_best(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, pad_ll=False, more_levels=False):
     """One analysis level on whichever single-level kernel the engine prefers for the shape: the streaming strip kernel
-    (rows of 2 KiB and more, enough workgroups for the chip), else the tile kernels."""
+    (rows of 2 KiB and more, enough workgroups for the chip), else the tile kernels.  `more_levels`: the ll feeds another level -
+    it comes back as a row-padded view (rows on 16-byte addresses) when its width is no whole number of 16-byte pieces, so that
+    the fused multi-level kernel can take the remaining levels (afb2d_fused)."""
     if x.dim() == 4:                                                             # small planes: several per workgroup
         res = afb2d_small(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, 1)
         if res is not None:
             return res[0], res[1][0]
-    res = afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=STREAM_FORCE)
+    res = afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=STREAM_FORCE, pad_ll=more_levels and PAD_ODD_LL)
     return res if res is not None else afb2d(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, pad_ll=pad_ll)
 
 

@@ -69,3 +69,64 @@ def check_packed(dev, wave, mode, dtype, H, W, planes, packed=True):
         return e, e2
     finally:
         ops.STREAM_FORCE, _ll.FUSED_LEVELS, ops.LATTICE_MIN_ELEMS = prev
+
+
+# ---- the fused multi-level analysis on a ROW-PADDED input (wl_dwt2d_analysis_fused_strided) ------------------------------------
+PADDED_FUSED_CASES = [
+    # (wave, mode, H, W, nlev): W * 4 no multiple of 16 - the row ends inside its last 16-byte piece
+    ('db4', 'symmetric', 75, 515, 2),      # the ll below a 1024-wide image: three 1 KiB pieces per row
+    ('db2', 'zero', 40, 515, 2),           # zero mode: the cells behind the row must be cleared, not left to the (NaN) padding
+    ('db3', 'reflect', 44, 261, 3),
+    ('haar', 'zero', 36, 130, 2),
+    ('db4', 'zero', 52, 259, 1),
+    ('db6', 'symmetric', 48, 323, 2),
+]
+
+
+def check_padded_fused(dev, wave, mode, H, W, nlev, planes=6, dtype=torch.float32):
+    """afb2d_fused on a view of a buffer whose row pitch is the next whole number of 16-byte pieces and whose padding holds NaN:
+    equal to the oracle, no NaN anywhere (what lies behind a row is loaded with its last piece and must never be read)."""
+    from pytorch_wavelets_amd import ops
+    rng = np.random.RandomState(43)
+    q = 16 // torch.tensor([], dtype=dtype).element_size()
+    pitch = (W + q - 1) // q * q
+    assert pitch != W
+    buf = torch.full((planes, 1, H, pitch), float('nan'), dtype=dtype, device=dev)
+    x = torch.tensor(rng.randn(planes, 1, H, W), dtype=dtype, device=dev)
+    buf[..., :W] = x
+    xfm = pw.DWTForward(J=nlev, wave=wave, mode=mode).to(dev).to(dtype)
+    imode = {'zero': 0, 'symmetric': 1, 'reflect': 4}[mode]
+    prev = ops.FUSED_STRIPS
+    ops.FUSED_STRIPS = 1
+    try:
+        res = ops.afb2d_fused(buf[..., :W], xfm.h0_col, xfm.h1_col, xfm.h0_row, xfm.h1_row, imode, nlev)
+    finally:
+        ops.FUSED_STRIPS = prev
+    assert res is not None, 'the fused kernel declined a row-padded input'
+    assert 'WlAfbRows<' in pw.last_kernel()
+    yl, yh = res
+    oyl, oyh = wo.dwt_forward(x.detach().cpu().double().numpy(), nlev, _flat(xfm.h0_col), _flat(xfm.h1_col), _flat(xfm.h0_row), _flat(xfm.h1_row), mode)
+    assert bool(torch.isfinite(yl).all()) and all(bool(torch.isfinite(h).all()) for h in yh)
+    e = max([_rel(yl, oyl)] + [_rel(a, b) for a, b in zip(yh, oyh)])
+    assert e <= (1e-5 if dtype == torch.float32 else 3e-3), (wave, mode, e)
+    return e
+
+
+def check_wide_pyramid(dev, wave='db4', mode='symmetric', shape=(2, 3, 96, 1024), J=3):
+    """A 1024-wide pyramid through the module: level 1 on the strip kernel (its ll, 515 columns, written at a padded pitch), the
+    remaining levels in ONE launch of the fused kernel - against the oracle, forward and gradient-free inverse round trip."""
+    rng = np.random.RandomState(47)
+    x = torch.tensor(rng.randn(*shape), dtype=torch.float32, device=dev)
+    xfm = pw.DWTForward(J=J, wave=wave, mode=mode).to(dev)
+    ifm = pw.DWTInverse(wave=wave, mode=mode).to(dev)
+    c0 = pw.launch_count()
+    yl, yh = xfm(x)
+    ks = [k for k in pw.kernels_since(c0) if 'armed' not in k and 'aux' not in k]
+    assert len(ks) == 2 and ks[0].startswith('WlAfbStrip<') and ks[1].startswith('WlAfbRows<'), ks
+    assert yl.is_contiguous() and all(h.is_contiguous() for h in yh)
+    oyl, oyh = wo.dwt_forward(x.detach().cpu().double().numpy(), J, _flat(xfm.h0_col), _flat(xfm.h1_col), _flat(xfm.h0_row), _flat(xfm.h1_row), mode)
+    e = max([_rel(yl, oyl)] + [_rel(a, b) for a, b in zip(yh, oyh)])
+    assert e <= 1e-5, e
+    rec = ifm((yl, yh))
+    assert float((rec - x).abs().max()) <= 1e-4 * float(x.abs().max())
+    return e

@@ -996,3 +996,19 @@ def test_wide_single_synthesis_level_prefers_the_strip_kernel():
         ref = wo.dwt_inverse(yl.double().numpy(), [h.double().numpy() for h in yh], f[0], f[1], f[2], f[3], 'symmetric')
         assert float(np.abs(rec.double().numpy() - ref).max()) <= 1e-5 * float(np.abs(ref).max())
         assert float(np.abs(rec.double().numpy() - x).max()) < 1e-4
+
+
+@pytest.mark.parametrize('wave,mode,H,W,nlev', __import__('_packed_cases').PADDED_FUSED_CASES)
+def test_fused_analysis_on_a_row_padded_input(wave, mode, H, W, nlev):
+    """wl_dwt2d_analysis_fused_strided: rows that end inside their last 16-byte piece (the odd-width ll of a strip-kernel level), the
+    padding behind them NaN - against the oracle, every mode of the multi-level kernel."""
+    import _packed_cases as PC
+    with emu_backend.emulated():
+        PC.check_padded_fused('cpu', wave, mode, H, W, nlev, planes=3)
+
+
+def test_wide_pyramid_is_a_strip_level_and_one_fused_launch():
+    import _packed_cases as PC
+    with emu_backend.emulated():
+        PC.check_wide_pyramid('cpu', shape=(1, 2, 72, 1024))
+        PC.check_wide_pyramid('cpu', wave='db2', mode='zero', shape=(1, 2, 70, 1028))

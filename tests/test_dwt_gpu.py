@@ -910,3 +910,19 @@ def test_strip_kernels_take_several_planes_per_workgroup_on_narrow_levels(wave, 
     chip stays full, the last plane group is short) against the oracle; the grid of the launch is the witness."""
     import _packed_cases as PC
     PC.check_packed('cuda:0', wave, mode, dtype, H, W, planes=2051)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('wave,mode,H,W,nlev', __import__('_packed_cases').PADDED_FUSED_CASES)
+def test_fused_analysis_on_a_row_padded_input(wave, mode, H, W, nlev):
+    """wl_dwt2d_analysis_fused_strided: rows that end inside their last 16-byte piece, NaN behind them - against the oracle."""
+    import _packed_cases as PC
+    PC.check_padded_fused('cuda:0', wave, mode, H, W, nlev, planes=300)
+
+
+@pytest.mark.gpu
+def test_wide_pyramid_is_a_strip_level_and_one_fused_launch():
+    """64 x 3 x 1024^2-style pyramids: level 1 on the strip kernel, the remaining levels in one fused launch on its padded ll."""
+    import _packed_cases as PC
+    PC.check_wide_pyramid('cuda:0', shape=(32, 3, 256, 1024))
+    PC.check_wide_pyramid('cuda:0', wave='db2', mode='zero', shape=(32, 3, 130, 1028))
