@@ -132,7 +132,7 @@ class SFB2DMulti(Function):
                     # when it declines (few planes, a width that is no multiple of four) the fused kernel is asked as before
                     h = yh[j]
                     lc = ll[..., :h.shape[-2], :h.shape[-1]]
-                    one = ops.sfb2d_stream(lc, h, g0_row, g1_row, g0_col, g1_col, mode)
+                    one = ops.sfb2d_stream(lc, h, g0_row, g1_row, g0_col, g1_col, mode, force=ops.STREAM_FORCE)
                     if one is not None:
                         ll_shapes[j] = tuple(ll.shape[-2:])
                         ll, j, took_strip = one, j - 1, True
@@ -260,12 +260,21 @@ class AFB2DMulti(Function):
                         grp = list(dyh[j - n + 1:j + 1])
                         if all(g is not None for g in grp):
                             res = ops.sfb2d_small(dx, grp, h0_row, h1_row, h0_col, h1_col, ctx.mode)
+                took_strip = False
                 while FUSED_LEVELS and n >= 1 and res is None:
                     grp = list(dyh[j - n + 1:j + 1])
                     ok = all(g is not None for g in grp)
+                    if ok and n == 1 and 2 * grp[0].shape[-1] >= WIDE_ONE_LEVEL:
+                        # a single wide level: the strip kernel first (SFB2DMulti.forward has the measurements)
+                        one = ops.sfb2d_stream(dx, grp[0], h0_row, h1_row, h0_col, h1_col, ctx.mode, out_hw=ctx.shapes[j], force=ops.STREAM_FORCE)
+                        if one is not None:
+                            dx, j, took_strip = one, j - 1, True
+                            break
                     res = ops.sfb2d_fused(dx, grp, h0_row, h1_row, h0_col, h1_col, ctx.mode) if ok else None
                     if res is None:
                         n -= 1
+                if took_strip:
+                    continue
                 if res is not None:
                     j -= n
                     H, W = ctx.shapes[j + 1]

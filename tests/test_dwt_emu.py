@@ -1012,3 +1012,32 @@ def test_wide_pyramid_is_a_strip_level_and_one_fused_launch():
     with emu_backend.emulated():
         PC.check_wide_pyramid('cpu', shape=(1, 2, 72, 1024))
         PC.check_wide_pyramid('cpu', wave='db2', mode='zero', shape=(1, 2, 70, 1028))
+
+
+def test_wide_pyramid_gradients_through_the_new_ladders():
+    """Gradients of DWTForward / DWTInverse on a 1024-wide plane (strip level + fused levels on the padded ll; a wide lone synthesis
+    level on the strip kernel in the backward passes) against the per-level tile kernels."""
+    from pytorch_wavelets_amd import ops
+    from pytorch_wavelets_amd.dwt import lowlevel as _ll
+    rng = np.random.RandomState(5)
+    x0 = torch.tensor(rng.randn(1, 2, 40, 1024), dtype=torch.float32)
+    outs = []
+    for tiles in (False, True):
+        xfm, ifm = pw.DWTForward(J=2, wave='db2', mode='symmetric'), pw.DWTInverse(wave='db2', mode='symmetric')
+        x = x0.clone().requires_grad_(True)
+        prev = _ll.FUSED_LEVELS
+        with emu_backend.emulated():
+            h = emu_backend.handle()
+            if tiles:
+                _ll.FUSED_LEVELS = False; h.wl_set_option(b'no_stream', 1); ops._FUSED_DECLINED.clear()
+            try:
+                yl, yh = xfm(x)
+                rec = ifm((yl * 1.5, [hh * 0.5 for hh in yh]))
+                (rec.square().sum() + yh[0].sum()).backward()
+            finally:
+                if tiles:
+                    _ll.FUSED_LEVELS = prev; h.wl_set_option(b'no_stream', 0); ops._FUSED_DECLINED.clear()
+        outs.append((rec.detach(), x.grad.detach()))
+    (r0, g0), (r1, g1) = outs
+    assert float((r0 - r1).abs().max()) <= 1e-5 * float(r1.abs().max())
+    assert float((g0 - g1).abs().max()) <= 1e-5 * float(g1.abs().max())
