@@ -17,7 +17,8 @@
 #define WL_BACKEND_NAME "emu"
 
 // a deliberately tiny "chip" so that persistent kernels walk several tiles per workgroup in the tests
-inline int wl_num_cus() { return 2; }
+inline int wl_emu_cus_v = 2;       // (wl_emu_set_cus of tests/emu/wl_emu_api.cpp: launcher policies that depend on the chip's size)
+inline int wl_num_cus() { return wl_emu_cus_v; }
 inline const char* wl_last_kernel_ptr = "";
 inline const char* wl_last_kernel_name() { return wl_last_kernel_ptr; }
 inline long long wl_last_grid_v = 0;

@@ -34,3 +34,15 @@ def emulated():
         yield
     finally:
         ops._TEST_BACKEND = prev
+
+
+@contextlib.contextmanager
+def chip_of(cus):
+    """The emulated chip with `cus` compute units (default 2) - for launcher policies that depend on the chip's size."""
+    handle()
+    lib = ctypes.CDLL(_SO)
+    lib.wl_emu_set_cus(int(cus))
+    try:
+        yield
+    finally:
+        lib.wl_emu_set_cus(2)

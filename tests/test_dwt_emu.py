@@ -1041,3 +1041,31 @@ def test_wide_pyramid_gradients_through_the_new_ladders():
     (r0, g0), (r1, g1) = outs
     assert float((r0 - r1).abs().max()) <= 1e-5 * float(r1.abs().max())
     assert float((g0 - g1).abs().max()) <= 1e-5 * float(g1.abs().max())
+
+
+def test_fused_kernels_pack_and_cut_few_narrow_planes():
+    """wl_rows_pack_and_cut (csrc/wl_rows_api.inc): 12 narrow planes on an 8-CU chip - too few for the packing rule (a workgroup for
+    every CU), so one plane per workgroup, four of them as halves (16 workgroups of up to a whole plane's rows); packed three to a
+    workgroup AND cut they are 8 workgroups of half a plane's rows.  Forward and inverse against the oracle; the grids are the witness."""
+    from oracle import wavelet_oracle as wo
+    rng = np.random.RandomState(11)
+    x = rng.randn(4, 3, 96, 80)
+    # (expected grids: what the waves of a workgroup allow - three / two planes of these widths and level counts - times two halves)
+    for wave, mode, J, want in (('db2', 'symmetric', 2, (8, 12)), ('db4', 'zero', 1, (6, 6)), ('haar', 'reflect', 3, (16, 24))):
+        xfm, ifm = pw.DWTForward(J=J, wave=wave, mode=mode), pw.DWTInverse(wave=wave, mode=mode)
+        f = [b.double().numpy().ravel() for b in (xfm.h0_col, xfm.h1_col, xfm.h0_row, xfm.h1_row)]
+        g = [b.double().numpy().ravel() for b in (ifm.g0_col, ifm.g1_col, ifm.g0_row, ifm.g1_row)]
+        with emu_backend.emulated(), emu_backend.chip_of(8):
+            h = emu_backend.handle()
+            yl, yh = xfm(torch.tensor(x, dtype=torch.float32))
+            kf, gf = h.wl_last_kernel().decode(), int(h.wl_last_grid())
+            rec = ifm((yl, yh))
+            ki, gi = h.wl_last_kernel().decode(), int(h.wl_last_grid())
+        assert 'WlAfbRows<' in kf and 'WlSfbRows<' in ki, (kf, ki)
+        assert (gf, gi) == want, (wave, mode, J, gf, gi)
+        oyl, oyh = wo.dwt_forward(x, J, f[0], f[1], f[2], f[3], mode)
+        assert float(np.abs(yl.double().numpy() - oyl).max()) <= 1e-5 * float(np.abs(oyl).max())
+        for a, b in zip(yh, oyh):
+            assert float(np.abs(a.double().numpy() - b).max()) <= 1e-5 * float(np.abs(b).max())
+        orec = wo.dwt_inverse(yl.double().numpy(), [t.double().numpy() for t in yh], g[0], g[1], g[2], g[3], mode)
+        assert float(np.abs(rec.double().numpy() - orec).max()) <= 1e-5 * float(np.abs(orec).max())
