@@ -1051,7 +1051,7 @@ def test_fused_kernels_pack_and_cut_few_narrow_planes():
     rng = np.random.RandomState(11)
     x = rng.randn(4, 3, 96, 80)
     # (expected grids: what the waves of a workgroup allow - three / two planes of these widths and level counts - times two halves)
-    for wave, mode, J, want in (('db2', 'symmetric', 2, (8, 12)), ('db4', 'zero', 1, (6, 6)), ('haar', 'reflect', 3, (16, 24))):
+    for wave, mode, J, want in (('db2', 'symmetric', 2, (8, 8)), ('db4', 'zero', 1, (6, 6)), ('haar', 'reflect', 3, (16, 12))):
         xfm, ifm = pw.DWTForward(J=J, wave=wave, mode=mode), pw.DWTInverse(wave=wave, mode=mode)
         f = [b.double().numpy().ravel() for b in (xfm.h0_col, xfm.h1_col, xfm.h0_row, xfm.h1_row)]
         g = [b.double().numpy().ravel() for b in (ifm.g0_col, ifm.g1_col, ifm.g0_row, ifm.g1_row)]

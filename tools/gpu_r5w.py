@@ -9,7 +9,7 @@ dev = 'cuda:0'; sync = torch.cuda.synchronize
 def t(fn, n=100):
     with torch.no_grad():
         return round(min(bench.time_seq_fn(fn, n, sync) for _ in range(5)), 4)
-for shape in ((128, 3, 224, 224), (256, 3, 224, 224), (128, 3, 256, 256), (64, 3, 224, 224), (128, 3, 160, 160), (128, 3, 128, 128), (96, 3, 299, 299)):
+for shape in ((128, 3, 224, 224), (256, 3, 224, 224), (128, 3, 256, 256), (64, 3, 224, 224), (128, 3, 160, 160), (128, 3, 128, 128), (96, 3, 299, 299), (512, 3, 224, 224), (1024, 3, 112, 112), (512, 3, 128, 128)):
     for J in (1, 2, 3):
         x = torch.randn(*shape, device=dev)
         f = pw.DWTForward(J=J, wave='db4', mode='symmetric').to(dev); i = pw.DWTInverse(wave='db4', mode='symmetric').to(dev)
