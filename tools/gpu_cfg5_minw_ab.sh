@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 4.  The python-side knobs STRIP_MINW_F16 / ISTRIP_MINW_F16 became ops.STRIP_MINW in round 5 - the launchers decide the rest - so the
+# attribute assignment below no longer changes anything; the library-side macros of the A/B builds still do.)
 # float16 levels narrower than 2 KiB / 1 KiB rows on the strip kernels?  A/B builds ab/libwl_a<W>[i<W>].so (tools/build_ab_strip.sh
 # <tag> -DWL_STRIP_MINW=<W> [-DWL_ISTRIP_MINW=<W>]) + the python-side mirror of the rule, config 5.
 for v in "0 0 " "512 0 ab/libwl_a512.so" "256 0 ab/libwl_a256.so" "256 256 ab/libwl_a256i256.so" "512 256 ab/libwl_a512i256.so" "0 0 "; do
