@@ -98,7 +98,8 @@ int wl_dwt2d_synthesis(const void* ll, int64_t ll_plane_stride, int ll_row_strid
  * (dwt/transform2d.py:63-74): x (planes,H,W) dense -> yh[j] (planes,3,H_j,W_j) for j < nlev and the last
  * level's low-pass yl; one workgroup streams one plane top to bottom, the intermediate LL_j stay in LDS rings and
  * HBM traffic is the algorithmic minimum.  `yh` is a HOST array of nlev device pointers.  Same taps (even length
- * L <= 12; 14, 16, 20 in the lattice form, see `strips`) on both axes of every level, F32/F16 data, float taps; rows of 16-byte multiples up to ~630 outputs wide;
+ * L <= 12; 14, 16, 20 in the lattice form, see `strips`) on both axes of every level, F32/F16 data, float taps; rows of 16-byte multiples of up to
+ * 2 KiB (F32: 3 KiB) and ~630 outputs;
  * zero / symmetric / reflect for nlev > 1, any mode for nlev == 1.  `strips`: 0 = let the engine decide (it declines
  * below about 3/8 as many planes as compute units, where the tile kernels win; with fewer planes than compute units it
  * cuts planes in two so that every workgroup has a compute unit of its own), 1 = force this kernel, whole planes,
@@ -251,7 +252,10 @@ int wl_scat_bwd_level1(const void* dz, const void* drdx, const void* drdy, void*
 /* ONE analysis level by the streaming strip kernel (csrc/wl_dwt_strip.h): the same operator as wl_dwt2d_analysis_strided
  * (AFB2D.forward, dwt/lowlevel.py:336-347) for one square filter length L (even, <= 20), float32 / float16, every mode, rows
  * of any width that are a whole number of 16-byte pieces: every input sample is read once per column strip and row
- * segment.  policy bit 0: 0 = the engine decides whether the launch pays (enough workgroups for the chip), 1 = force;
+ * segment; a level whose whole row is one or two compute waves' worth of columns (128 / 256 output columns) runs four / two PLANES
+ * per workgroup when the chip still gets a workgroup for every slot.  policy bit 0: 0 = the engine decides whether the launch pays
+ * (workgroups for every CU; rows of 2 KiB and more, float16 256 columns, or narrower levels from 128 columns on when the planes pack
+ * so that the workgroups' compute waves all have work), 1 = force;
  * bit 1 (value 2) = a HINT that each highpass bank is the quadrature mirror of its lowpass bank, h_hi[t] == (-1)^t h_lo[L-1-t]
  * (the pair of every orthogonal wavelet as stored): from 12 taps on the engine then launches a kernel variant that relies on
  * the relation - it holds the lowpass banks only - and VERIFIES it on the device against the taps as they are when it runs;
