@@ -484,7 +484,7 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
     qmf = bool(getattr(_HINTS, 'qmf', False))
     lattice = (same and qmf and ROWS_LATTICE and L in (8, 10, 12, 14, 16, 20) and L >= IROWS_LATTICE_MIN
                and (L > 12 or (nlev >= 1 and yh[0] is not None and yh[0].dim() == 5
-                               and 4 * yh[0].shape[3] * yh[0].shape[4] * N * C >= LATTICE_MIN_ELEMS)))
+                               and 4 * yh[0].shape[3] * yh[0].shape[4] * N * C >= (LATTICE_MIN_ELEMS if nlev == 1 else min(LATTICE_MIN_ELEMS, LATTICE_MIN_ELEMS_ML)))))
     if (yl.dtype == torch.float64 or nlev < 1 or nlev > 3 or g_h_lo.numel() != L or L % 2 or (L > 12 and not lattice) or mode == 2
             or yl.numel() == 0 or (strips == 0 and 8 * N * C < 3 * _num_cus(yl.device)) or strips > 2
             or any(t is None or t.dim() != 5 or t.dtype != yl.dtype or t.shape[:3] != (N, C, 3) or t.numel() == 0
@@ -542,6 +542,9 @@ ROWS_LATTICE_MIN = 10     # WL_ROWS_LAT_MIN of csrc/wl_rows_api.inc (8 in the A/
 # banks ~5 us, the armed fallback ~5 us): it pays from about 40 M elements on (128x3x512x512 = 100 M: inverse -6 % at 8 taps, -15 % at 12;
 # 128x3x224x224 = 19 M: the extra launches are 15 % of a 65 us transform).  From 14 taps on the lattice is the only fused form.
 LATTICE_MIN_ELEMS = 40000000
+# ... two and three synthesis levels in one launch run long enough for the lattice earlier (tools/gpu_r5w.py, 8 taps, same box: 128x3x224^2 J = 2 / 3
+# 0.064 / 0.057 -> 0.057 / 0.049 ms, 128x3x256^2 0.081 / 0.080 -> 0.071 / 0.069, 96x3x299^2 0.082 / 0.098 -> 0.067 / 0.081; at 64x3x224^2 - 10 M - it loses)
+LATTICE_MIN_ELEMS_ML = 16000000
 IROWS_LATTICE_MIN = 8     # WL_IROWS_LAT_MIN of csrc/wl_idwt_rows.h: the fused synthesis takes the lattice from 8 taps on (the metric's inverse: -6 %)
 
 
