@@ -37,7 +37,15 @@ extern "C" {
 #define WL_ERR_TAPS (-5)        /* tap count out of range (1..WL_MAX_TAPS)                    */
 #define WL_MAX_TAPS 128
 
-/* library version (major*10000 + minor*100 + patch) and build flavour ("hip-gfx950" / "emu") */
+/* library version (major*10000 + minor*100 + patch) and build flavour ("hip-gfx950" / "emu").
+ * ABI history: an entry point never changes its argument list under the same name.
+ *   100, 200 (rounds 1-4): wl_dwt2d_analysis_fused / _synthesis_fused / _analysis_stream / _synthesis_stream WITHOUT device scratch.
+ *   200 (round 5): those four names took a `tap_scratch` pointer in front of `stream` without a version change (a mistake: same
+ *          symbol, other arguments).
+ *   210 (this header): the four names are back to their round-4 argument lists; the lattice variants that need device scratch are
+ *          reached through the new *_ex entry points (tap_scratch + the caller-owned `tap_state`), and
+ *          wl_dwt2d_analysis_fused_strided is gone (wl_dwt2d_analysis_fused_ex takes the strides).  A caller built against 2.0.0
+ *          must be recompiled against this header (check wl_version() >= 210). */
 int wl_version(void);
 const char* wl_backend(void);
 
@@ -107,24 +115,30 @@ int wl_dwt2d_synthesis(const void* ll, int64_t ll_plane_stride, int ll_row_strid
  * 10- and 12-tap kernels then run their one-bank variant (one set of tap pairs in scalar registers), which compares the two
  * banks on the device first, with the two-bank variant queued behind it for the case that they differ (identical POINTERS for
  * both axes need no hint and no check); + 8 (bit 3) = a HINT that each highpass bank is the quadrature mirror of its lowpass bank.
- * With BOTH hints and tap_scratch (NULL, or WL_TAP_SCRATCH_BYTES of device memory as for wl_dwt2d_analysis_stream) the 10- to
- * 20-tap kernels (10, 12, 14, 16, 20) run their LATTICE variant (csrc/wl_lattice.h) behind the one-thread examination of the banks,
- * the two-bank variant armed behind it: the only fused multi-level form of 14, 16 and 20 taps (without the hints and the scratch
- * those lengths return WL_ERR_UNSUPPORTED); + 16 (bit 4) = tap_scratch already holds the examination of exactly these banks (an
- * earlier launch of the same transform on this stream).  Returns WL_ERR_UNSUPPORTED outside the
+ * The LATTICE variant of 10 - 20 taps (the only fused multi-level form of 14, 16 and 20 taps) needs device scratch: see
+ * wl_dwt2d_analysis_fused_ex; here those lengths return WL_ERR_UNSUPPORTED.  Returns WL_ERR_UNSUPPORTED outside the
  * kernel's envelope: the caller then uses wl_dwt2d_analysis level by level. */
 int wl_dwt2d_analysis_fused(const void* x, void* yl, void* const* yh, int dtype, int64_t planes, int H,
                             int W, int nlev, const void* h_w_lo, const void* h_w_hi, const void* h_h_lo,
-                            const void* h_h_hi, int L, int mode, int strips, void* tap_scratch, void* stream);
-/* The same with x (planes, H, W) through a plane stride and a row pitch (elements; both whole 16-byte pieces, x 16-byte aligned):
+                            const void* h_h_hi, int L, int mode, int strips, void* stream);
+/* The same with (a) x (planes, H, W) through a plane stride and a row pitch (elements; both whole 16-byte pieces, x 16-byte aligned):
  * the input of the level loop's SECOND and later iterations when the first level ran on another kernel (reference
  * dwt/transform2d.py:63-74: `ll` of one AFB2D.forward feeds the next).  W itself need not be a whole number of pieces then - the
  * odd-width ll below a 1024-wide image, 515 columns - as long as the row's last piece lies inside the pitch (the caller owns the
- * elements behind the row; the kernel overwrites what it loaded from there before any lane reads it). */
-int wl_dwt2d_analysis_fused_strided(const void* x, int64_t x_plane_stride, int x_row_stride, void* yl, void* const* yh,
-                                    int dtype, int64_t planes, int H, int W, int nlev, const void* h_w_lo,
-                                    const void* h_w_hi, const void* h_h_lo, const void* h_h_hi, int L, int mode,
-                                    int strips, void* tap_scratch, void* stream);
+ * elements behind the row; the kernel overwrites what it loaded from there before any lane reads it);
+ * and (b) device scratch for the LATTICE variant (csrc/wl_lattice.h): with BOTH hints (strips | 4 | 8) and tap_scratch =
+ * WL_TAP_SCRATCH_BYTES of device memory that stay valid until the launches of this call have run (stream order), the 10- to
+ * 20-tap kernels (10, 12, 14, 16, 20) run their lattice variant behind a one-thread examination of the banks (WlTapPrep), the
+ * two-bank variant armed behind it.  tap_state: NULL, or a HOST int the caller keeps next to the scratch block - 0 when the
+ * block is fresh, when any of the four tap pointers, their contents, L, the data type or the direction (analysis / synthesis)
+ * changed; the library sets bit 0 when it has run the examination of exactly these banks into the block, bit 1 when that
+ * examination included "one bank for both axes", and skips the one-thread kernel when the bits it needs are set (the levels of
+ * one transform share one examination).  Only a launcher that actually ran the examination sets bits: a launch that has no use
+ * for the scratch leaves *tap_state alone, so no later launch trusts an unexamined block. */
+int wl_dwt2d_analysis_fused_ex(const void* x, int64_t x_plane_stride, int x_row_stride, void* yl, void* const* yh,
+                               int dtype, int64_t planes, int H, int W, int nlev, const void* h_w_lo,
+                               const void* h_w_hi, const void* h_h_lo, const void* h_h_hi, int L, int mode,
+                               int strips, void* tap_scratch, int* tap_state, void* stream);
 
 /* All `nlev` (1..3) synthesis levels in ONE launch = the body of DWTInverse.forward's level loop
  * (dwt/transform2d.py:131-148) = nlev x SFB2D.forward (dwt/lowlevel.py:671-680): yl (planes, Kh[nlev-1],
@@ -136,14 +150,19 @@ int wl_dwt2d_analysis_fused_strided(const void* x, int64_t x_plane_stride, int x
  * intermediate low-passes stay in LDS rings, every coefficient is read from HBM once (LDS-DMA in whole 1024-byte
  * chunks of the contiguous band planes) and x is written once.  Same even tap count L <= 12 on both axes of every
  * level, F32/F16 data, float taps; zero / symmetric / reflect / periodic (not periodization); row bytes and plane
- * bytes multiples of four.  `strips` (incl. the hint bits 2-4) and tap_scratch as for wl_dwt2d_analysis_fused: with both hints and
- * the scratch the 10-20 tap kernels run their lattice variant (the transposed recurrence of csrc/wl_lattice.h) - the only fused
- * form of 14, 16 and 20 taps.  Returns WL_ERR_UNSUPPORTED outside the
- * kernel's envelope: the caller then uses wl_dwt2d_synthesis level by level. */
+ * bytes multiples of four.  `strips` (incl. the hint bits 2-3) as for wl_dwt2d_analysis_fused.  Returns WL_ERR_UNSUPPORTED
+ * outside the kernel's envelope: the caller then uses wl_dwt2d_synthesis level by level. */
 int wl_dwt2d_synthesis_fused(const void* yl, int64_t yl_plane_stride, int yl_row_stride, int yl_h, int yl_w,
                              const void* const* yh, const int* Kh, const int* Kw, void* y, int dtype,
                              int64_t planes, int nlev, const void* g_w_lo, const void* g_w_hi,
-                             const void* g_h_lo, const void* g_h_hi, int L, int mode, int strips, void* tap_scratch, void* stream);
+                             const void* g_h_lo, const void* g_h_hi, int L, int mode, int strips, void* stream);
+/* The same with tap_scratch / tap_state as for wl_dwt2d_analysis_fused_ex: with both hints and the scratch the 8-20 tap kernels
+ * run their lattice variant (the transposed recurrence of csrc/wl_lattice.h) - the only fused form of 14, 16 and 20 taps. */
+int wl_dwt2d_synthesis_fused_ex(const void* yl, int64_t yl_plane_stride, int yl_row_stride, int yl_h, int yl_w,
+                                const void* const* yh, const int* Kh, const int* Kw, void* y, int dtype,
+                                int64_t planes, int nlev, const void* g_w_lo, const void* g_w_hi,
+                                const void* g_h_lo, const void* g_h_hi, int L, int mode, int strips, void* tap_scratch,
+                                int* tap_state, void* stream);
 
 /* Non-separable one-level analysis / synthesis with four Ly x Lx point-spread functions = afb2d_nonsep
  * (dwt/lowlevel.py:524-597) / sfb2d_nonsep (:746-798).  `f` / `g`: (4, Ly, Lx) device taps in the accumulate dtype,
@@ -260,19 +279,24 @@ int wl_scat_bwd_level1(const void* dz, const void* drdx, const void* drdy, void*
  * (the pair of every orthogonal wavelet as stored): from 12 taps on the engine then launches a kernel variant that relies on
  * the relation - it holds the lowpass banks only - and VERIFIES it on the device against the taps as they are when it runs;
  * the two-bank variant is queued behind it and does the work when the relation does not hold (a wrong hint costs an empty
- * launch, never a wrong coefficient).  tap_scratch: NULL, or WL_TAP_SCRATCH_BYTES of device memory that stay valid until the
- * launches of this call have run (stream order): with the hint the hinted variant is then the LATTICE kernel
- * (csrc/wl_lattice.h: the column pass as K = L/2 plane rotations, half the multiplications), whose coefficients a one-thread
- * kernel derives from the column bank on the device and accepts only if they reproduce the bank to 2^-22 (float32 data) /
- * 2^-12 (float16 data) of its largest tap - else the two-bank variant runs as above.  policy bit 2 (value 4): tap_scratch
- * already holds that examination of exactly these four banks for this dtype, written by an earlier call of this function on
- * this stream (the levels of one transform share it): the one-thread kernel is not launched again.
+ * launch, never a wrong coefficient).
  * Returns WL_ERR_UNSUPPORTED outside its envelope (callers then use wl_dwt2d_analysis_strided). */
 #define WL_TAP_SCRATCH_BYTES 64
 int wl_dwt2d_analysis_stream(const void* x, int64_t x_plane_stride, int x_row_stride, void* ll, int64_t ll_plane_stride,
                              int ll_row_stride, void* highs, int dtype, int64_t planes, int H, int W, const void* h_w_lo,
                              const void* h_w_hi, const void* h_h_lo, const void* h_h_hi, int L, int mode, int policy,
-                             void* tap_scratch, void* stream);
+                             void* stream);
+/* The same with device scratch: tap_scratch = NULL, or WL_TAP_SCRATCH_BYTES of device memory that stay valid until the
+ * launches of this call have run (stream order): with the hint (policy | 2) the hinted variant of 12, 14, 16 and 20 taps is
+ * then the LATTICE kernel (csrc/wl_lattice.h: the column pass as K = L/2 plane rotations, half the multiplications), whose
+ * coefficients a one-thread kernel derives from the column bank on the device and accepts only if they reproduce the bank to
+ * 2^-22 (float32 data) / 2^-12 (float16 data) of its largest tap - else the two-bank variant runs as above.  tap_state: NULL or
+ * the caller-owned record of what the block holds, exactly as for wl_dwt2d_analysis_fused_ex (the levels of one transform
+ * share one examination; a launch that makes no use of the scratch - other tap counts, no hint - leaves it untouched). */
+int wl_dwt2d_analysis_stream_ex(const void* x, int64_t x_plane_stride, int x_row_stride, void* ll, int64_t ll_plane_stride,
+                                int ll_row_stride, void* highs, int dtype, int64_t planes, int H, int W, const void* h_w_lo,
+                                const void* h_w_hi, const void* h_h_lo, const void* h_h_hi, int L, int mode, int policy,
+                                void* tap_scratch, int* tap_state, void* stream);
 
 /* ONE synthesis level by the streaming strip kernel (csrc/wl_idwt_strip.h): the same operator as wl_dwt2d_synthesis
  * (SFB2D.forward, dwt/lowlevel.py:671-680; the (OH, OW) crop is AFB2D.backward's, :356-364) for one square filter length L
@@ -281,13 +305,17 @@ int wl_dwt2d_analysis_stream(const void* x, int64_t x_plane_stride, int x_row_st
  * the quadrature mirror of its lowpass bank, g_hi[t] = (-1)^t g_lo[L-1-t] (the reconstruction pair of every orthogonal
  * wavelet): from 12 taps on the hinted kernel variant derives the highpass tap pairs from the lowpass ones by operand modifiers
  * instead of holding both banks in scalar registers (same arithmetic, same results) after verifying the relation on the device;
- * the two-bank variant stands by behind it as for the analysis.  tap_scratch as for wl_dwt2d_analysis_stream (NULL, or
- * WL_TAP_SCRATCH_BYTES of device memory: the hinted variant is then the lattice kernel, from 12 taps on, 14 included).
- * Returns WL_ERR_UNSUPPORTED outside its envelope. */
+ * the two-bank variant stands by behind it as for the analysis.  Returns WL_ERR_UNSUPPORTED outside its envelope. */
 int wl_dwt2d_synthesis_stream(const void* ll, int64_t ll_plane_stride, int ll_row_stride, const void* highs, void* y,
                               int dtype, int64_t planes, int Kh, int Kw, int OH, int OW, const void* g_w_lo,
                               const void* g_w_hi, const void* g_h_lo, const void* g_h_hi, int L, int mode, int policy,
-                              void* tap_scratch, void* stream);
+                              void* stream);
+/* The same with tap_scratch / tap_state as for wl_dwt2d_analysis_stream_ex (the hinted variant is then the lattice kernel, from
+ * 12 taps on, 14 included). */
+int wl_dwt2d_synthesis_stream_ex(const void* ll, int64_t ll_plane_stride, int ll_row_stride, const void* highs, void* y,
+                                 int dtype, int64_t planes, int Kh, int Kw, int OH, int OW, const void* g_w_lo,
+                                 const void* g_w_hi, const void* g_h_lo, const void* g_h_hi, int L, int mode, int policy,
+                                 void* tap_scratch, int* tap_state, void* stream);
 
 /* Gradients of the two non-separable banks, as autograd gives them upstream (where afb2d_nonsep / sfb2d_nonsep are
  * plain differentiable ATen chains, dwt/lowlevel.py:524-597, :746-798):

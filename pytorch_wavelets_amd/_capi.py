@@ -18,11 +18,14 @@ PROTOTYPES = {
     'wl_dwt2d_analysis': (I, [P, P, P, I, L, I, I, P, P, I, P, P, I, I, P]),
     'wl_dwt2d_analysis_strided': (I, [P, L, I, P, L, I, P, I, L, I, I, P, P, I, P, P, I, I, P]),
     'wl_dwt2d_synthesis': (I, [P, L, I, P, P, I, L, I, I, I, I, P, P, I, P, P, I, I, P]),
-    'wl_dwt2d_analysis_fused': (I, [P, P, C.POINTER(P), I, L, I, I, I, P, P, P, P, I, I, I, P, P]),
-    'wl_dwt2d_analysis_fused_strided': (I, [P, L, I, P, C.POINTER(P), I, L, I, I, I, P, P, P, P, I, I, I, P, P]),
-    'wl_dwt2d_synthesis_fused': (I, [P, L, I, I, I, C.POINTER(P), C.POINTER(I), C.POINTER(I), P, I, L, I, P, P, P, P, I, I, I, P, P]),
-    'wl_dwt2d_analysis_stream': (I, [P, L, I, P, L, I, P, I, L, I, I, P, P, P, P, I, I, I, P, P]),
-    'wl_dwt2d_synthesis_stream': (I, [P, L, I, P, P, I, L, I, I, I, I, P, P, P, P, I, I, I, P, P]),
+    'wl_dwt2d_analysis_fused': (I, [P, P, C.POINTER(P), I, L, I, I, I, P, P, P, P, I, I, I, P]),
+    'wl_dwt2d_analysis_fused_ex': (I, [P, L, I, P, C.POINTER(P), I, L, I, I, I, P, P, P, P, I, I, I, P, C.POINTER(I), P]),
+    'wl_dwt2d_synthesis_fused': (I, [P, L, I, I, I, C.POINTER(P), C.POINTER(I), C.POINTER(I), P, I, L, I, P, P, P, P, I, I, I, P]),
+    'wl_dwt2d_synthesis_fused_ex': (I, [P, L, I, I, I, C.POINTER(P), C.POINTER(I), C.POINTER(I), P, I, L, I, P, P, P, P, I, I, I, P, C.POINTER(I), P]),
+    'wl_dwt2d_analysis_stream': (I, [P, L, I, P, L, I, P, I, L, I, I, P, P, P, P, I, I, I, P]),
+    'wl_dwt2d_analysis_stream_ex': (I, [P, L, I, P, L, I, P, I, L, I, I, P, P, P, P, I, I, I, P, C.POINTER(I), P]),
+    'wl_dwt2d_synthesis_stream': (I, [P, L, I, P, P, I, L, I, I, I, I, P, P, P, P, I, I, I, P]),
+    'wl_dwt2d_synthesis_stream_ex': (I, [P, L, I, P, P, I, L, I, I, I, I, P, P, P, P, I, I, I, P, C.POINTER(I), P]),
     'wl_dwt2d_analysis_nonsep': (I, [P, P, I, L, I, I, P, I, I, I, P]),
     'wl_dwt2d_synthesis_nonsep': (I, [P, P, I, L, I, I, I, I, P, I, I, I, P]),
     'wl_dwt2d_analysis_nonsep_bwd': (I, [P, P, I, L, I, I, P, I, I, I, P]),

@@ -557,7 +557,7 @@ struct WlAfbRows {
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
         const int tid = ctx.tid;
         const int wave = wl_uniform(tid >> 6), lane = tid & 63;
-        if (LT >= WL_ROWS_SAME_MIN && a.guard) {   // "both axes filter with the same taps", checked against the taps as they are now
+        if (a.guard) {   // "both axes filter with the same taps", checked against the taps as they are now (whatever tap count an A/B build arms)
             const bool holds = a.lat ? *reinterpret_cast<const unsigned*>(a.lat) == WL_LAT_OK   // (WlTapPrep's verdict: same banks, mirror pair, lattice)
                                      : wl_taps_same(a.h_w_lo, a.h_h_lo, LT) && wl_taps_same(a.h_w_hi, a.h_h_hi, LT);
             if (!wl_guard_pass(a.guard, holds)) return;

@@ -195,6 +195,14 @@ struct WlTapPrepArgs {
     int syn;               // the banks are a synthesis pair (WlSfbStrip) / an analysis pair (WlAfbStrip)
     int same;              // the kernel behind holds ONE bank for both axes (the fused multi-level kernels): w and h banks must be equal
 };
+// The CALLER-OWNED record of what a scratch block holds (`int* tap_state` of the *_ex entry points; zero for a fresh block, for
+// other banks, another tap count or the other direction): bit 0 = this library ran WlTapPrep on exactly these banks into this
+// block, bit 1 = that examination included "one bank for both axes" (`same`, what the fused multi-level kernels rely on).  Only
+// the launcher that queues WlTapPrep sets the bits - a launch that never looked at the scratch (8 / 10 taps on the strip kernels,
+// the direct-form variants) leaves them alone, so a later launch of the same transform never trusts an unexamined block.
+static inline bool wl_tap_examined(const int* st, int need) { return st && (*st & need) == need; }
+static inline void wl_tap_mark(int* st, int bits) { if (st) *st |= bits; }
+
 template <int LT>
 struct WlTapPrep {
     typedef WlTapPrepArgs Args;

@@ -130,9 +130,13 @@ class SFB2DMulti(Function):
                     # a single WIDE level: the one-level strip kernel is ahead of the fused kernel's one-level form (same-box, float32,
                     # tools/gpu_r5u.py: 64x3x1024^2 0.333 -> 0.309 ms, 128x3x768^2 0.362 -> 0.342, 128x3x640^2 0.244 -> 0.228);
                     # when it declines (few planes, a width that is no multiple of four) the fused kernel is asked as before
+                    # (the reference's 'unpad' drops exactly ONE surplus row / column, dwt/transform2d.py:141-146: a low-pass that is
+                    # larger than that is malformed and takes the per-level path below, which raises like every other path)
                     h = yh[j]
+                    dh, dw = ll.shape[-2] - h.shape[-2], ll.shape[-1] - h.shape[-1]
                     lc = ll[..., :h.shape[-2], :h.shape[-1]]
-                    one = ops.sfb2d_stream(lc, h, g0_row, g1_row, g0_col, g1_col, mode, force=ops.STREAM_FORCE)
+                    one = (ops.sfb2d_stream(lc, h, g0_row, g1_row, g0_col, g1_col, mode, force=ops.STREAM_FORCE)
+                           if 0 <= dh <= 1 and 0 <= dw <= 1 else None)
                     if one is not None:
                         ll_shapes[j] = tuple(ll.shape[-2:])
                         ll, j, took_strip = one, j - 1, True

@@ -1,6 +1,7 @@
 """Tensor-level wrappers over the C ABI: allocate outputs with torch, pass raw device pointers and
 the current HIP stream down, nothing else.  (PyTorch is plumbing here: memory + streams.)"""
 import contextlib
+import ctypes
 import threading
 import torch
 
@@ -234,8 +235,10 @@ def qmf_hint(flag):
 def _hinted_taps(bufs, ref, L, syn):
     """The four banks of a hinted strip launch as float32 device taps + the lattice variant's device scratch (csrc/wl_lattice.h:
     a one-thread kernel leaves its verdict on the banks and the column lattice there; the lattice kernel and its armed two-bank
-    fallback read it) + policy bit 2 when the scratch was already filled for exactly these buffers by an earlier level of the
-    SAME module call.  The cache lives in the qmf_hint context of that call (no user code runs between its levels) and is keyed
+    fallback read it) + the `tap_state` word of the *_ex entry points (include/wavelets_hip.h): what the LIBRARY has examined
+    into that scratch so far - its launchers set the bits when they run the one-thread kernel and only then, so a level that has no
+    use for the scratch (8 / 10 taps on the strip kernels) never makes a later level of the same module call trust an unexamined,
+    recycled block.  The cache lives in the qmf_hint context of that call (no user code runs between its levels) and is keyed
     on the buffers' addresses, dtypes and the data type: the levels of a transform then share one examination and - for a
     `.half()` module - one conversion of the taps.  The scratch stays referenced until the context ends: the allocator hands
     it out again on this stream only, behind the launches that read it."""
@@ -245,18 +248,22 @@ def _hinted_taps(bufs, ref, L, syn):
     ent = cache.get(key) if cache is not None else None
     if ent is None:
         taps = tuple(_taps(b, ref) for b in bufs)
-        scratch = torch.empty(TAP_SCRATCH_FLOATS, dtype=torch.float32, device=ref.device) if L >= min(ROWS_LATTICE_MIN, IROWS_LATTICE_MIN) and (STRIP_LATTICE or ROWS_LATTICE) else None
-        ent = [taps, scratch, 0]
+        scratch = _new_tap_scratch(ref.device) if L >= min(ROWS_LATTICE_MIN, IROWS_LATTICE_MIN) and (STRIP_LATTICE or ROWS_LATTICE) else None
+        ent = [taps, scratch, ctypes.c_int(0)]
         if cache is not None:
             cache[key] = ent
     return ent
 
 
-def _mark_prepared(ent):
-    """A hinted strip launch went through (rc == 0): its scratch now holds the examination of these banks (only then - a launcher
-    that declines returns before its one-thread kernel, and a recycled block may hold the verdict of another module's taps)."""
-    if ent[1] is not None:
-        ent[2] = 4
+def _new_tap_scratch(device):
+    """WL_TAP_SCRATCH_BYTES of device memory, contents undefined (a recycled block may hold another module's verdict: the library
+    trusts it only after its own examination, tap_state).  A function of its own so that a test can hand out poisoned blocks."""
+    return torch.empty(TAP_SCRATCH_FLOATS, dtype=torch.float32, device=device)
+
+
+def _plain_taps(bufs, ref):
+    """The entry of an unhinted launch: converted taps, no scratch, a state word nobody reads."""
+    return [tuple(_taps(b, ref) for b in bufs), None, ctypes.c_int(0)]
 
 
 def current_hints():
@@ -374,9 +381,9 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None, whol
     key = ('afb', x.device, x.dtype, N * C, H, W, x_ps, x_rs, L, mode, nlev, strips, lattice)
     if key in _FUSED_DECLINED:
         return None
-    ent = _hinted_taps((h_w_lo, h_w_hi, h_h_lo, h_h_hi), x, L, False) if lattice else [tuple(_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi)), None, 0]
-    (hwl, hwh, hhl, hhh), scratch, prepared = ent
-    same = (4 if same else 0) | (8 if qmf else 0) | (16 if prepared else 0)
+    ent = _hinted_taps((h_w_lo, h_w_hi, h_h_lo, h_h_hi), x, L, False) if lattice else _plain_taps((h_w_lo, h_w_hi, h_h_lo, h_h_hi), x)
+    (hwl, hwh, hhl, hhh), scratch, tstate = ent
+    same = (4 if same else 0) | (8 if qmf else 0)
     yh = []
     h, w = H, W
     for _ in range(nlev):
@@ -384,14 +391,13 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None, whol
         yh.append(torch.empty((N, C, 3, h, w), dtype=x.dtype, device=x.device))
     yl = torch.empty((N, C, h, w), dtype=x.dtype, device=x.device)
     ptrs = (ctypes.c_void_p * nlev)(*[t.data_ptr() for t in yh])
-    rc = _call('wl_dwt2d_analysis_fused_strided', x, x.data_ptr(), x_ps, x_rs, yl.data_ptr(), ptrs, _DTYPES[x.dtype], N * C, H, W, nlev,
+    rc = _call('wl_dwt2d_analysis_fused_ex', x, x.data_ptr(), x_ps, x_rs, yl.data_ptr(), ptrs, _DTYPES[x.dtype], N * C, H, W, nlev,
                hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(), hhh.data_ptr(), L, mode, strips | same,
-               None if scratch is None else scratch.data_ptr(), _stream(x))
+               None if scratch is None else scratch.data_ptr(), ctypes.byref(tstate), _stream(x))
     if rc == -3:
         _remember_decline(key)
         return None
-    _lib.check(rc, 'wl_dwt2d_analysis_fused_strided')
-    _mark_prepared(ent)
+    _lib.check(rc, 'wl_dwt2d_analysis_fused_ex')
     return yl, yh
 
 
@@ -512,21 +518,20 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
     key = ('sfb', yl.device, yl.dtype, N * C, kh, kw, tuple(tuple(t.shape[3:]) for t in yh), L, mode, strips, lattice)
     if key in _FUSED_DECLINED or yl.data_ptr() % 4 or any(t.data_ptr() % 4 for t in yh):
         return None
-    ent = _hinted_taps((g_w_lo, g_w_hi, g_h_lo, g_h_hi), yl, L, True) if lattice else [tuple(_taps(g, yl) for g in (g_w_lo, g_w_hi, g_h_lo, g_h_hi)), None, 0]
-    (gwl, gwh, ghl, ghh), scratch, prepared = ent
-    hint_bits = (4 if same else 0) | (8 if qmf else 0) | (16 if prepared else 0)
+    ent = _hinted_taps((g_w_lo, g_w_hi, g_h_lo, g_h_hi), yl, L, True) if lattice else _plain_taps((g_w_lo, g_w_hi, g_h_lo, g_h_hi), yl)
+    (gwl, gwh, ghl, ghh), scratch, tstate = ent
+    hint_bits = (4 if same else 0) | (8 if qmf else 0)
     y = torch.empty((N, C, sh, sw), dtype=yl.dtype, device=yl.device)
     ptrs = (ctypes.c_void_p * nlev)(*[t.data_ptr() for t in yh])
     khs = (ctypes.c_int * nlev)(*[t.shape[3] for t in yh])
     kws = (ctypes.c_int * nlev)(*[t.shape[4] for t in yh])
-    rc = _call('wl_dwt2d_synthesis_fused', yl, yl.data_ptr(), yl_ps, yl_rs, kh, kw, ptrs, khs, kws,
+    rc = _call('wl_dwt2d_synthesis_fused_ex', yl, yl.data_ptr(), yl_ps, yl_rs, kh, kw, ptrs, khs, kws,
                y.data_ptr(), _DTYPES[yl.dtype], N * C, nlev, gwl.data_ptr(), gwh.data_ptr(), ghl.data_ptr(),
-               ghh.data_ptr(), L, mode, strips | hint_bits, None if scratch is None else scratch.data_ptr(), _stream(yl))
+               ghh.data_ptr(), L, mode, strips | hint_bits, None if scratch is None else scratch.data_ptr(), ctypes.byref(tstate), _stream(yl))
     if rc == -3:
         _remember_decline(key)
         return None
-    _lib.check(rc, 'wl_dwt2d_synthesis_fused')
-    _mark_prepared(ent)
+    _lib.check(rc, 'wl_dwt2d_synthesis_fused_ex')
     return y
 
 
@@ -571,8 +576,8 @@ def afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=False, pad_ll=Fa
     key = ('afbs', x.device, x.dtype, N * C, H, W, x_ps, x_rs, L, mode, bool(force), qmf, bool(pad_ll))
     if key in _FUSED_DECLINED:
         return None
-    ent = _hinted_taps((h_w_lo, h_w_hi, h_h_lo, h_h_hi), x, L, False) if qmf else [tuple(_taps(h, x) for h in (h_w_lo, h_w_hi, h_h_lo, h_h_hi)), None, 0]
-    (hwl, hwh, hhl, hhh), scratch, prepared = ent
+    ent = _hinted_taps((h_w_lo, h_w_hi, h_h_lo, h_h_hi), x, L, False) if qmf else _plain_taps((h_w_lo, h_w_hi, h_h_lo, h_h_hi), x)
+    (hwl, hwh, hhl, hhh), scratch, tstate = ent
     Kh, Kw = coeff_len(H, L, mode), coeff_len(W, L, mode)
     q = 16 // es
     Kp = (Kw + q - 1) // q * q if pad_ll else Kw
@@ -580,14 +585,13 @@ def afb2d_stream(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, force=False, pad_ll=Fa
     if Kp != Kw:
         ll = ll[..., :Kw]
     highs = torch.empty((N, C, 3, Kh, Kw), dtype=x.dtype, device=x.device)
-    rc = _call('wl_dwt2d_analysis_stream', x, x.data_ptr(), x_ps, x_rs, ll.data_ptr(), Kh * Kp, Kp, highs.data_ptr(),
+    rc = _call('wl_dwt2d_analysis_stream_ex', x, x.data_ptr(), x_ps, x_rs, ll.data_ptr(), Kh * Kp, Kp, highs.data_ptr(),
                _DTYPES[x.dtype], N * C, H, W, hwl.data_ptr(), hwh.data_ptr(), hhl.data_ptr(), hhh.data_ptr(), L, mode,
-               (1 if force else 0) | (2 if qmf else 0) | prepared, None if scratch is None else scratch.data_ptr(), _stream(x))
+               (1 if force else 0) | (2 if qmf else 0), None if scratch is None else scratch.data_ptr(), ctypes.byref(tstate), _stream(x))
     if rc == -3:
         _remember_decline(key)
         return None
-    _lib.check(rc, 'wl_dwt2d_analysis_stream')
-    _mark_prepared(ent)
+    _lib.check(rc, 'wl_dwt2d_analysis_stream_ex')
     return ll, highs
 
 
@@ -618,17 +622,16 @@ def sfb2d_stream(ll, highs, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, out_hw=None, f
     key = ('sfbs', ll.device, ll.dtype, N * C, Kh, Kw, ll_ps, ll_rs, OH, OW, L, mode, bool(force), qmf)
     if key in _FUSED_DECLINED:
         return None
-    ent = _hinted_taps((g_w_lo, g_w_hi, g_h_lo, g_h_hi), ll, L, True) if qmf else [tuple(_taps(g, ll) for g in (g_w_lo, g_w_hi, g_h_lo, g_h_hi)), None, 0]
-    (gwl, gwh, ghl, ghh), scratch, prepared = ent
+    ent = _hinted_taps((g_w_lo, g_w_hi, g_h_lo, g_h_hi), ll, L, True) if qmf else _plain_taps((g_w_lo, g_w_hi, g_h_lo, g_h_hi), ll)
+    (gwl, gwh, ghl, ghh), scratch, tstate = ent
     y = torch.empty((N, C, OH, OW), dtype=ll.dtype, device=ll.device)
-    rc = _call('wl_dwt2d_synthesis_stream', ll, ll.data_ptr(), ll_ps, ll_rs, highs.data_ptr(), y.data_ptr(), _DTYPES[ll.dtype],
+    rc = _call('wl_dwt2d_synthesis_stream_ex', ll, ll.data_ptr(), ll_ps, ll_rs, highs.data_ptr(), y.data_ptr(), _DTYPES[ll.dtype],
                N * C, Kh, Kw, OH, OW, gwl.data_ptr(), gwh.data_ptr(), ghl.data_ptr(), ghh.data_ptr(), L, mode,
-               (1 if force else 0) | (2 if qmf else 0) | prepared, None if scratch is None else scratch.data_ptr(), _stream(ll))
+               (1 if force else 0) | (2 if qmf else 0), None if scratch is None else scratch.data_ptr(), ctypes.byref(tstate), _stream(ll))
     if rc == -3:
         _remember_decline(key)
         return None
-    _lib.check(rc, 'wl_dwt2d_synthesis_stream')
-    _mark_prepared(ent)
+    _lib.check(rc, 'wl_dwt2d_synthesis_stream_ex')
     return y
 
 

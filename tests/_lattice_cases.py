@@ -414,3 +414,87 @@ def check_irows_lattice_rejections(dev, dtype=torch.float32, shape=(2, 2, 96, 25
             run(ifm, yl, yh, wave + ': g1_col.data.mul_')
     finally:
         ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS = prev
+
+
+# ---- a scratch block is trusted only after the LIBRARY examined it (tap_state of the *_ex entry points) -------------------------
+def _poisoned_scratch(device):
+    """What a recycled allocator block may hold: the OK verdict and lattice of ANOTHER bank (here: nonsense coefficients)."""
+    import struct
+    ok = struct.unpack('f', struct.pack('I', 0x4c415431))[0]       # WL_LAT_OK of csrc/wl_lattice.h
+    return torch.tensor([ok, 3.0] + [0.7 * (-1) ** k * (k + 1) for k in range(14)], dtype=torch.float32, device=device)
+
+
+def check_unexamined_scratch_is_never_trusted(dev, shape=(1, 2, 64, 1024)):
+    """a strip level that makes NO use of the device scratch (8 / 10 taps) must not make the fused lattice
+    launch of the next levels skip its examination.  DWTForward(J = 3) / DWTInverse of 8- and 10-tap wavelets on a 1024-wide plane
+    (level 1 on the strip kernel, the rest fused in lattice form) with every scratch block handed out POISONED (the verdict word
+    of an accepted factorisation + nonsense coefficients): WlTapPrep must run in front of the lattice kernel, and the result is the
+    oracle's."""
+    from pytorch_wavelets_amd import ops
+    from pytorch_wavelets_amd.dwt import lowlevel as _ll
+    rng = np.random.RandomState(61)
+    prev = ops.STREAM_FORCE, ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS, ops.LATTICE_MIN_ELEMS_ML, ops._new_tap_scratch, _ll.WIDE_ONE_LEVEL
+    ops.STREAM_FORCE, ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS, ops.LATTICE_MIN_ELEMS_ML = True, 1, 0, 0
+    ops._new_tap_scratch = _poisoned_scratch
+    _ll.WIDE_ONE_LEVEL = 256
+    try:
+        for wave in ('db5', 'db4', 'db6'):
+            x = torch.tensor(rng.randn(*shape), dtype=torch.float32, device=dev)
+            xfm = pw.DWTForward(J=3, wave=wave, mode='symmetric').to(dev)
+            ifm = pw.DWTInverse(wave=wave, mode='symmetric').to(dev)
+            c0 = pw.launch_count()
+            yl, yh = xfm(x)
+            ks = pw.kernels_since(c0)
+            lat = [i for i, k in enumerate(ks) if _is_lattice_rows(k) or _is_lattice(k)]
+            for i in lat:    # every lattice launch of the call sits behind an examination made in THIS call
+                assert any(k.startswith('WlTapPrep') for k in ks[:i]), (wave, ks)
+            oyl, oyh = wo.dwt_forward(x.cpu().double().numpy(), 3, _flat(xfm.h0_col), _flat(xfm.h1_col), _flat(xfm.h0_row), _flat(xfm.h1_row), 'symmetric')
+            e = max([_rel(yl, oyl)] + [_rel(a, b) for a, b in zip(yh, oyh)])
+            assert e <= 1e-5, (wave, 'forward', e, ks)
+            c0 = pw.launch_count()
+            r = ifm((yl, yh))
+            ks = pw.kernels_since(c0)
+            lat = [i for i, k in enumerate(ks) if _is_lattice_irows(k) or _is_lattice_syn(k)]
+            for i in lat:
+                assert any(k.startswith('WlTapPrep') for k in ks[:i]), (wave, ks)
+            want = wo.dwt_inverse(oyl, oyh, _flat(ifm.g0_col), _flat(ifm.g1_col), _flat(ifm.g0_row), _flat(ifm.g1_row), 'symmetric')
+            e = _rel(r, want)
+            assert e <= 1e-5, (wave, 'inverse', e, ks)
+    finally:
+        ops.STREAM_FORCE, ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS, ops.LATTICE_MIN_ELEMS_ML, ops._new_tap_scratch, _ll.WIDE_ONE_LEVEL = prev
+
+
+def check_tap_state_contract(dev):
+    """The C ABI directly: wl_dwt2d_analysis_stream_ex with a poisoned scratch.  10 taps (no use for the scratch): *tap_state stays 0.
+    12 taps with the hint: the library examines (bit 0 set), a second call with that state skips the examination, and a state the
+    CALLER forged (bit 0 on a poisoned block) is the caller's contract to keep - the library documents it, the Python layer never does it."""
+    import ctypes
+    from pytorch_wavelets_amd import ops
+    rng = np.random.RandomState(5)
+    x = torch.tensor(rng.randn(1, 2, 32, 288), dtype=torch.float32, device=dev)
+    for wave, uses in (('db5', False), ('db6', True)):
+        h0, h1 = (np.asarray(v, dtype=np.float64) for v in F.dwt_analysis_taps(wave))
+        L = len(h0)
+        taps = [torch.tensor(v, dtype=torch.float32, device=dev) for v in (h0, h1, h0, h1)]    # (stored order: what the modules' buffers hold)
+        scratch = _poisoned_scratch(dev)
+        st = ctypes.c_int(0)
+        Kh, Kw = ops.coeff_len(32, L, 1), ops.coeff_len(288, L, 1)
+        ll = torch.empty(1, 2, Kh, Kw, dtype=torch.float32, device=dev)
+        hs = torch.empty(1, 2, 3, Kh, Kw, dtype=torch.float32, device=dev)
+
+        def call():
+            c0 = pw.launch_count()
+            rc = ops._call('wl_dwt2d_analysis_stream_ex', x, x.data_ptr(), 32 * 288, 288, ll.data_ptr(), Kh * Kw, Kw, hs.data_ptr(), 0, 2, 32, 288,
+                           taps[0].data_ptr(), taps[1].data_ptr(), taps[2].data_ptr(), taps[3].data_ptr(), L, 1, 1 | 2, scratch.data_ptr(),
+                           ctypes.byref(st), ops._stream(x))
+            assert rc == 0, rc
+            return pw.kernels_since(c0)
+        ks = call()
+        assert st.value == (1 if uses else 0), (wave, st.value, ks)
+        assert any(k.startswith('WlTapPrep') for k in ks) == uses, (wave, ks)
+        oyl, oyh = wo.dwt_forward(x.cpu().double().numpy(), 1, taps[0].cpu().double().numpy(), taps[1].cpu().double().numpy(),
+                                  taps[2].cpu().double().numpy(), taps[3].cpu().double().numpy(), 'symmetric')
+        assert max(_rel(ll, oyl), _rel(hs, oyh[0])) <= 1e-5, (wave, _rel(ll, oyl), _rel(hs, oyh[0]), ks)
+        ks = call()
+        assert not any(k.startswith('WlTapPrep') for k in ks), (wave, ks)          # examined once (or never needed)
+        assert max(_rel(ll, oyl), _rel(hs, oyh[0])) <= 1e-5, wave

@@ -71,7 +71,7 @@ def check_packed(dev, wave, mode, dtype, H, W, planes, packed=True):
         ops.STREAM_FORCE, _ll.FUSED_LEVELS, ops.LATTICE_MIN_ELEMS = prev
 
 
-# ---- the fused multi-level analysis on a ROW-PADDED input (wl_dwt2d_analysis_fused_strided) ------------------------------------
+# ---- the fused multi-level analysis on a ROW-PADDED input (wl_dwt2d_analysis_fused_ex) ------------------------------------
 PADDED_FUSED_CASES = [
     # (wave, mode, H, W, nlev): W * 4 no multiple of 16 - the row ends inside its last 16-byte piece
     ('db4', 'symmetric', 75, 515, 2),      # the ll below a 1024-wide image: three 1 KiB pieces per row

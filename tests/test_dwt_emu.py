@@ -906,6 +906,13 @@ def test_lattice_levels_share_one_examination():
         LC.check_lattice_levels_share_one_examination('cpu', shape=(1, 1, 96, 1024))
 
 
+def test_unexamined_scratch_is_never_trusted():
+    import _lattice_cases as LC
+    with emu_backend.emulated():
+        LC.check_unexamined_scratch_is_never_trusted('cpu')
+        LC.check_tap_state_contract('cpu')
+
+
 @pytest.mark.parametrize('wave', ['db7', 'db9', 'sym7'])
 def test_tile_kernels_for_14_and_18_taps(wave):
     import _lattice_cases as LC
@@ -1000,7 +1007,7 @@ def test_wide_single_synthesis_level_prefers_the_strip_kernel():
 
 @pytest.mark.parametrize('wave,mode,H,W,nlev', __import__('_packed_cases').PADDED_FUSED_CASES)
 def test_fused_analysis_on_a_row_padded_input(wave, mode, H, W, nlev):
-    """wl_dwt2d_analysis_fused_strided: rows that end inside their last 16-byte piece (the odd-width ll of a strip-kernel level), the
+    """wl_dwt2d_analysis_fused_ex: rows that end inside their last 16-byte piece (the odd-width ll of a strip-kernel level), the
     padding behind them NaN - against the oracle, every mode of the multi-level kernel."""
     import _packed_cases as PC
     with emu_backend.emulated():

@@ -867,6 +867,13 @@ def test_lattice_levels_share_one_examination():
 
 
 @pytest.mark.gpu
+def test_unexamined_scratch_is_never_trusted():
+    import _lattice_cases as LC
+    LC.check_unexamined_scratch_is_never_trusted(DEV, shape=(2, 3, 128, 1024))
+    LC.check_tap_state_contract(DEV)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('wave', ['db7', 'db9', 'sym7', 'sym9'])
 def test_tile_kernels_for_14_and_18_taps(wave):
     import _lattice_cases as LC
@@ -915,7 +922,7 @@ def test_strip_kernels_take_several_planes_per_workgroup_on_narrow_levels(wave, 
 @pytest.mark.gpu
 @pytest.mark.parametrize('wave,mode,H,W,nlev', __import__('_packed_cases').PADDED_FUSED_CASES)
 def test_fused_analysis_on_a_row_padded_input(wave, mode, H, W, nlev):
-    """wl_dwt2d_analysis_fused_strided: rows that end inside their last 16-byte piece, NaN behind them - against the oracle."""
+    """wl_dwt2d_analysis_fused_ex: rows that end inside their last 16-byte piece, NaN behind them - against the oracle."""
     import _packed_cases as PC
     PC.check_padded_fused('cuda:0', wave, mode, H, W, nlev, planes=300)
 
