@@ -147,6 +147,10 @@ struct WlRowsArgs {
 struct WlRowsSched {
     int fed[WL_ROWS_MAXLEV];
     WL_HD void init(const WlRowsSeg& sg) { for (int j = 0; j < WL_ROWS_MAXLEV; ++j) fed[j] = sg.f0[j]; }
+    // the LL row of the level above that extended row e of a level >= 2 reads.  Periodization: row e itself - the level above
+    // COMPUTES the rows above / below its plane (rows -hl .. -1 are rows Hs - hl .. Hs - 1 of its periodic output, produced a
+    // second time at the start of the segment: its feeds start at a negative number, WlRowsSeg::f0)
+    static WL_HD int src_row(int e, int Hs, int ext) { return ext == WL_EXT_PER ? e : wl_ext1(e, Hs, ext); }
     // rows [sg.f0[j], avail(j)) of level j are complete
     WL_HD int avail(const WlRowsSeg& sg, int j, int LT) const {
         const int warm = (LT - 2) / 2;
@@ -159,8 +163,8 @@ struct WlRowsSched {
         const int av = avail(sg, j - 1, LT);
         const int Hs = a.g[j].Hs;
         const int e = a.base + 2 * fed[j];
-        const bool ok0 = left > 0 && wl_ext1(e, Hs, a.ext) < av && wl_ext1(e + 1, Hs, a.ext) < av;
-        const bool ok1 = left > 1 && wl_ext1(e + 2, Hs, a.ext) < av && wl_ext1(e + 3, Hs, a.ext) < av;
+        const bool ok0 = left > 0 && src_row(e, Hs, a.ext) < av && src_row(e + 1, Hs, a.ext) < av;
+        const bool ok1 = left > 1 && src_row(e + 2, Hs, a.ext) < av && src_row(e + 3, Hs, a.ext) < av;
         return ok0 ? (ok1 ? 2 : 1) : 0;
     }
 };
@@ -176,10 +180,15 @@ struct WlRowsSched {
 // row where the direct form needs 2L FMAs and an L-row window that is moved along every feed.  The kernel is bound by the
 // instructions its waves issue: 12 taps shed a third of them, and 14-20 taps - which the direct form cannot hold in 80
 // registers - get a fused multi-level kernel at all.
-template <typename T, int LT, int PPR, int D = WL_ROWS_DEPTH, int SAME = 0, int LAT = 0>
+// ODD = 1 (round 6): `base` is odd - periodization with L % 4 == 0, base = 1 - L/2 (db2, db4, db6, db8, db10) - so a lane's L row-filter
+// samples start on an ODD cell of the ring row.  The lane then reads L/2 + 1 aligned (even, odd) pairs from one cell earlier and
+// meets tap t with the OTHER half of a pair (even taps the .y of pair t/2, odd taps the .x of pair (t+1)/2): the same L packed
+// FMAs, one more 8-byte LDS read per row, no unaligned access.  The unused first and last cells are halo cells like the others.
+template <typename T, int LT, int PPR, int D = WL_ROWS_DEPTH, int SAME = 0, int LAT = 0, int ODD = 0>
 struct WlAfbRows {
     typedef WlRowsArgs<T> Args;
     static_assert(!LAT || SAME, "the lattice variant holds one bank");
+    static const int NP = LT / 2 + ODD;    // (even, odd) sample pairs a lane reads per ring row
     static const int KL = LT / 2;          // rotations of the lattice
     static const int kThreads = 64 * WL_ROWS_WAVES;
     static const int kMinWaves = 6;        // two workgroups per CU: 24 waves on 4 SIMDs
@@ -281,12 +290,12 @@ struct WlAfbRows {
     };
 
     // the L samples of this lane in two ring rows (LDS byte offsets row0/row1, wave-uniform), as (even, odd) pairs
-    static WL_DEV void load_rows(const Lane& L, const char* smem, int row0, int row1, wl_v2 (&s0)[LT / 2], wl_v2 (&s1)[LT / 2]) {
+    static WL_DEV void load_rows(const Lane& L, const char* smem, int row0, int row1, wl_v2 (&s0)[NP], wl_v2 (&s1)[NP]) {
         const char* p0 = smem + (row0 + L.off);
         const char* p1 = smem + (row1 + L.off);
         if (SZ == 4) {
 #pragma unroll
-            for (int u = 0; u < LT / 2; ++u) {
+            for (int u = 0; u < NP; ++u) {
                 const wl_f2 t0 = *reinterpret_cast<const wl_f2*>(p0 + 8 * u);
                 const wl_f2 t1 = *reinterpret_cast<const wl_f2*>(p1 + 8 * u);
                 s0[u] = wl_v2{t0.x, t0.y}; s1[u] = wl_v2{t1.x, t1.y};
@@ -294,7 +303,7 @@ struct WlAfbRows {
         } else {
             typedef T Pair2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int u = 0; u < LT / 2; ++u) {
+            for (int u = 0; u < NP; ++u) {
                 const Pair2 t0 = *reinterpret_cast<const Pair2*>(p0 + 2 * SZ * u);
                 const Pair2 t1 = *reinterpret_cast<const Pair2*>(p1 + 2 * SZ * u);
                 s0[u] = wl_v2{(float)t0.x, (float)t0.y}; s1[u] = wl_v2{(float)t1.x, (float)t1.y};
@@ -303,7 +312,34 @@ struct WlAfbRows {
     }
     // row filter of two rows: four independent chains (even / odd taps of either row; dependent v_pk_fma_f32 need a
     // wait state in between)
-    static WL_DEV void row_pass(const Role& R, const wl_v2 (&s0)[LT / 2], const wl_v2 (&s1)[LT / 2], wl_v2& a0, wl_v2& a1) {
+    static WL_DEV void row_pass(const Role& R, const wl_v2 (&s0)[NP], const wl_v2 (&s1)[NP], wl_v2& a0, wl_v2& a1) {
+        if constexpr (ODD != 0) {    // sample of tap t = the OTHER half: even taps pair t/2 .y, odd taps pair (t+1)/2 .x
+            wl_v2 b0, b1;
+            if constexpr (LAT != 0) {
+                a0 = wl_qmf_mul<LT>(R.tw, 0, 1, s0[0]); a1 = wl_qmf_mul<LT>(R.tw, 0, 1, s1[0]);
+                b0 = wl_qmf_mul<LT>(R.tw, 1, 0, s0[1]); b1 = wl_qmf_mul<LT>(R.tw, 1, 0, s1[1]);
+#pragma unroll
+                for (int u = 1; u < LT / 2; ++u) {
+                    wl_qmf_fma<LT>(a0, R.tw, 2 * u, 1, s0[u]);
+                    wl_qmf_fma<LT>(a1, R.tw, 2 * u, 1, s1[u]);
+                    wl_qmf_fma<LT>(b0, R.tw, 2 * u + 1, 0, s0[u + 1]);
+                    wl_qmf_fma<LT>(b1, R.tw, 2 * u + 1, 0, s1[u + 1]);
+                }
+            } else {
+                a0 = wl_pk_mul_y(R.tw[0], s0[0]); a1 = wl_pk_mul_y(R.tw[0], s1[0]);
+                b0 = wl_pk_mul_x(R.tw[1], s0[1]); b1 = wl_pk_mul_x(R.tw[1], s1[1]);
+#pragma unroll
+                for (int u = 1; u < LT / 2; ++u) {
+                    wl_pk_fma_y(a0, R.tw[2 * u], s0[u]);
+                    wl_pk_fma_y(a1, R.tw[2 * u], s1[u]);
+                    wl_pk_fma_x(b0, R.tw[2 * u + 1], s0[u + 1]);
+                    wl_pk_fma_x(b1, R.tw[2 * u + 1], s1[u + 1]);
+                }
+            }
+            a0 += b0;
+            a1 += b1;
+            return;
+        }
         if constexpr (LAT != 0) {
             a0 = wl_qmf_mul<LT>(R.tw, 0, 0, s0[0]); a1 = wl_qmf_mul<LT>(R.tw, 0, 0, s1[0]);
             wl_v2 b0 = wl_qmf_mul<LT>(R.tw, 1, 1, s0[0]), b1 = wl_qmf_mul<LT>(R.tw, 1, 1, s1[0]);
@@ -390,7 +426,7 @@ struct WlAfbRows {
     // one feed: row-filter the two new source rows into the window and - once the window is full - emit one output row
     template <bool LAST, bool HALO>
     static WL_DEV void feed1(Lane& L, const Role& R, char* smem, int row0, int row1, bool emit, int orow, bool keep) {
-        wl_v2 s0[LT / 2], s1[LT / 2], a0, a1;
+        wl_v2 s0[NP], s1[NP], a0, a1;
         load_rows(L, smem, row0, row1, s0, s1);
         row_pass(R, s0, s1, a0, a1);
         if constexpr (LAT != 0) {   // (every feed: the lattice's state; the first K - 1 outputs of a segment are the warm-up)
@@ -410,7 +446,7 @@ struct WlAfbRows {
     template <bool LAST, bool HALO>
     static WL_DEV void feed2(Lane& L, const Role& R, char* smem, int row0, int row1, int row2, int row3, int orow,
                              bool keep0, bool keep1) {
-        wl_v2 s0[LT / 2], s1[LT / 2], s2[LT / 2], s3[LT / 2];
+        wl_v2 s0[NP], s1[NP], s2[NP], s3[NP];
         load_rows(L, smem, row0, row1, s0, s1);
         load_rows(L, smem, row2, row3, s2, s3);
         if constexpr (LAT != 0) {
@@ -468,7 +504,7 @@ struct WlAfbRows {
 #pragma unroll
         for (int t = 0; t < (LAT ? (KL > 1 ? KL - 1 : 1) : LT); ++t) L.win[t] = wl_v2{0.f, 0.f};
         L.ob = (unsigned)sg.f0[j] * R.rowb + (unsigned)k * SZ;   // the first row this segment produces is row f0
-        L.off = g.pad + (2 * (active ? k : 0) + a.base) * SZ;   // halo cells included: always >= 0
+        L.off = g.pad + (2 * (active ? k : 0) + a.base - ODD) * SZ;   // halo cells included: always >= 0 (ODD: one cell earlier, an aligned pair)
         // the halo cells of the NEXT level's ring rows whose source column is k - at most one on either side
         L.ndst = gn.pad + k * SZ; L.hx0 = L.hx1 = -1;
         if (!R.last && active && a.ext != WL_EXT_ZERO) {
@@ -492,7 +528,7 @@ struct WlAfbRows {
         const WlRowsLevel& g = a.g[j];
         char* const smem = ctx.smem;
         const int rmask = R.rmask, zrow = a.zero_off, ring = g.ring_off, pitch = g.ring_pitch, Hs = g.Hs;
-        const bool zmode = a.ext == WL_EXT_ZERO;
+        const bool zmode = a.ext == WL_EXT_ZERO, per = a.ext == WL_EXT_PER;
         // LDS byte offsets (wave-uniform) of the two source rows of feed f = (2f+base, 2f+base+1); i = its index in
         // the half-batch hb
         auto rows_of = [&](int f, int hb, int i, int& r0, int& r1) {
@@ -505,10 +541,12 @@ struct WlAfbRows {
                     if ((unsigned)(e + 1) >= (unsigned)Hs) r1 = zrow;
                 }
             } else {
+                // periodization: the rows above / below the plane are COMPUTED (the level above produces rows -hl .. Hs + hr of its
+                // periodic output, the wrapped ones twice): the ring is addressed by the unfolded row number, negative ones included
                 int s0 = e, s1 = e + 1;
-                if (e < 0 || e + 1 >= Hs) { s0 = wl_ext1(e, Hs, a.ext); s1 = wl_ext1(e + 1, Hs, a.ext); }   // top / bottom rows only
-                r0 = s0 < 0 ? zrow : ring + (s0 & rmask) * pitch;
-                r1 = s1 < 0 ? zrow : ring + (s1 & rmask) * pitch;
+                if (!per && (e < 0 || e + 1 >= Hs)) { s0 = wl_ext1(e, Hs, a.ext); s1 = wl_ext1(e + 1, Hs, a.ext); }   // top / bottom rows only
+                r0 = zmode && s0 < 0 ? zrow : ring + (s0 & rmask) * pitch;
+                r1 = zmode && s1 < 0 ? zrow : ring + (s1 & rmask) * pitch;
             }
             r0 = wl_uniform(r0); r1 = wl_uniform(r1);
         };

@@ -361,10 +361,11 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None, whol
     # (csrc/wl_lattice.h): the only fused form of 14, 16 and 20 taps.
     same = bool(getattr(_HINTS, 'same', False))
     qmf = bool(getattr(_HINTS, 'qmf', False))
+    # (periodization with 12 taps: its odd-cell instantiations are the lattice variant and the two-bank direct form, which spills)
     lattice = (same and qmf and ROWS_LATTICE and L in (8, 10, 12, 14, 16, 20) and L >= ROWS_LATTICE_MIN
-               and (L > 12 or x.numel() >= LATTICE_MIN_ELEMS))
+               and (L > 12 or x.numel() >= LATTICE_MIN_ELEMS or (mode == 2 and L == 12)))
     if (x.dtype == torch.float64 or nlev < 1 or nlev > 3 or h_h_lo.numel() != L or L % 2 or (L > 12 and not lattice)
-            or (nlev > 1 and mode not in (0, 1, 4)) or x.numel() == 0
+            or (nlev > 1 and mode not in (0, 1, 2, 4)) or x.numel() == 0
             or (strips == 0 and 8 * N * C < 3 * _num_cus(x.device)) or strips > 2):
         return None
     # rows as whole 16-byte pieces: a dense x whose width is one, or a row-padded view (the ll that afb2d_stream(pad_ll=True) /

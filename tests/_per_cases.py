@@ -1,0 +1,106 @@
+"""Round 6: several PERIODIZATION levels in one launch of the fused streaming analysis kernel (csrc/wl_dwt_rows.h: the rows above /
+below a level's plane are computed by the level above - WlRowsSched::src_row - and tap counts with L % 4 == 0, whose samples sit
+on odd cells, run the ODD instantiations).  Every case against the ORACLE (reference dwt/lowlevel.py:134-150 through
+oracle/wavelet_oracle.py).  Shared by the emulator tests (device 'cpu' under emu_backend.emulated()) and the -m gpu tests."""
+import numpy as np
+import torch
+
+import pytorch_wavelets_amd as pw
+from oracle import wavelet_oracle as wo
+
+
+def _flat(b):
+    return b.detach().cpu().double().numpy().ravel()
+
+
+def _rel(a, b):
+    a = a.detach().cpu().double().numpy()
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+# (wave, H, W, J, dtype, strips): strips 1 = whole planes, 2 = every plane cut in two, 0 = the launcher's own policy
+FUSED_PER_CASES = [
+    ('haar', 64, 64, 3, torch.float32, 1),
+    ('db2', 96, 128, 3, torch.float32, 2),          # L % 4 == 0: the odd-cell instantiations
+    ('db3', 64, 96, 2, torch.float32, 1),
+    ('db4', 128, 256, 3, torch.float32, 1),
+    ('db4', 128, 256, 3, torch.float32, 2),
+    ('db4', 80, 272, 2, torch.float32, 0),          # two 1 KiB pieces per row
+    ('db4', 72, 520, 2, torch.float32, 1),          # three pieces per row
+    ('db5', 96, 128, 3, torch.float32, 2),
+    ('db6', 96, 128, 3, torch.float32, 1),          # 12 taps, odd cells: lattice variant
+    ('db7', 128, 128, 2, torch.float32, 2),
+    ('db8', 128, 256, 3, torch.float32, 1),
+    ('db8', 128, 512, 3, torch.float16, 1),         # config 5's levels 3-4 (+ one more): 2 KiB rows of float16
+    ('db8', 128, 256, 3, torch.float16, 2),
+    ('db10', 160, 160, 2, torch.float32, 1),
+    ('sym4', 64, 192, 3, torch.float16, 0),
+]
+
+
+def check_fused_periodization(dev, wave, H, W, J, dtype, strips, planes=(2, 2), require_fused=True):
+    from pytorch_wavelets_amd import ops
+    rng = np.random.RandomState(71)
+    prev = ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS
+    ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS = strips, 0
+    try:
+        x = torch.tensor(rng.randn(planes[0], planes[1], H, W), dtype=dtype, device=dev)
+        xfm = pw.DWTForward(J=J, wave=wave, mode='periodization').to(dev).to(dtype)
+        c0 = pw.launch_count()
+        yl, yh = xfm(x)
+        ks = [k for k in pw.kernels_since(c0) if not k.endswith(')')]
+        if require_fused:   # ONE launch that does the transform's work
+            assert len(ks) == 1 and ks[0].startswith('WlAfbRows<'), (wave, H, W, J, ks)
+        oyl, oyh = wo.dwt_forward(x.detach().cpu().double().numpy(), J, _flat(xfm.h0_col), _flat(xfm.h1_col), _flat(xfm.h0_row),
+                                  _flat(xfm.h1_row), 'periodization')
+        e = max([_rel(yl, oyl)] + [_rel(a, b) for a, b in zip(yh, oyh)])
+        assert e <= (1e-5 if dtype == torch.float32 else 4e-3), (wave, H, W, J, e, ks)
+        return e
+    finally:
+        ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS = prev
+
+
+def check_fused_periodization_corners(dev):
+    """What the fused kernel must DECLINE in periodization (the per-level kernels restate these corners): a level shorter than the
+    filter (the reference's wrap-add folds once: no periodic convolution), an odd number of rows or columns below level 1 (the
+    repeated last row / column) - and the module's answer is the oracle's either way."""
+    from pytorch_wavelets_amd import ops
+    rng = np.random.RandomState(73)
+    prev = ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS
+    ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS = 1, 0
+    try:
+        for wave, H, W, J in (('db10', 64, 64, 3), ('db4', 68, 64, 3), ('db8', 36, 260, 2), ('db6', 50, 50, 2), ('db4', 64, 132, 3)):
+            x = torch.tensor(rng.randn(1, 2, H, W), dtype=torch.float32, device=dev)
+            xfm = pw.DWTForward(J=J, wave=wave, mode='periodization').to(dev)
+            yl, yh = xfm(x)
+            oyl, oyh = wo.dwt_forward(x.detach().cpu().double().numpy(), J, _flat(xfm.h0_col), _flat(xfm.h1_col), _flat(xfm.h0_row),
+                                      _flat(xfm.h1_row), 'periodization')
+            e = max([_rel(yl, oyl)] + [_rel(a, b) for a, b in zip(yh, oyh)])
+            assert e <= 1e-5, (wave, H, W, J, e)
+    finally:
+        ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS = prev
+
+
+def check_periodization_gradient(dev, shape=(2, 2, 64, 128), wave='db4', J=3):
+    """The module's backward pass (an inverse transform with the analysis taps) next to the fused periodization forward: the
+    gradient of sum(w . coefficients) is the adjoint applied to w - compared with the oracle's forward by the inner-product test."""
+    from pytorch_wavelets_amd import ops
+    rng = np.random.RandomState(79)
+    prev = ops.FUSED_STRIPS
+    ops.FUSED_STRIPS = 1
+    try:
+        x = torch.tensor(rng.randn(*shape), dtype=torch.float32, device=dev, requires_grad=True)
+        xfm = pw.DWTForward(J=J, wave=wave, mode='periodization').to(dev)
+        yl, yh = xfm(x)
+        wl = torch.tensor(rng.randn(*yl.shape), dtype=torch.float32, device=dev)
+        wh = [torch.tensor(rng.randn(*h.shape), dtype=torch.float32, device=dev) for h in yh]
+        loss = (yl * wl).sum() + sum((h * w).sum() for h, w in zip(yh, wh))
+        g, = torch.autograd.grad(loss, x)
+        # <A x', w> == <x', A^T w> for a random x' (A from the oracle)
+        xp = rng.randn(*shape)
+        oyl, oyh = wo.dwt_forward(xp, J, _flat(xfm.h0_col), _flat(xfm.h1_col), _flat(xfm.h0_row), _flat(xfm.h1_row), 'periodization')
+        lhs = float((oyl * wl.cpu().double().numpy()).sum() + sum((a * w.cpu().double().numpy()).sum() for a, w in zip(oyh, wh)))
+        rhs = float((xp * g.detach().cpu().double().numpy()).sum())
+        assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0), (lhs, rhs)
+    finally:
+        ops.FUSED_STRIPS = prev

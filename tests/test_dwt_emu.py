@@ -1109,3 +1109,18 @@ def test_random_pyramids_on_chips_of_several_sizes(block):
         pairs = [(yl, oyl)] + list(zip(yh, oyh)) + [(rec, orec)]
         e = max(float(np.abs(a.double().numpy() - b).max() / max(np.abs(b).max(), 1e-30)) for a, b in pairs)
         assert e < 1e-5, (seed, wave, mode, cus, planes, H, W, J, e)
+
+
+# ---- round 6: several periodization levels in one launch of the fused analysis kernel -----------------------------------------
+@pytest.mark.parametrize('wave,H,W,J,dtype,strips', __import__('_per_cases').FUSED_PER_CASES)
+def test_fused_periodization_levels(wave, H, W, J, dtype, strips):
+    import _per_cases as PC
+    with emu_backend.emulated():
+        PC.check_fused_periodization('cpu', wave, H, W, J, dtype, strips)
+
+
+def test_fused_periodization_corners_and_gradient():
+    import _per_cases as PC
+    with emu_backend.emulated():
+        PC.check_fused_periodization_corners('cpu')
+        PC.check_periodization_gradient('cpu')

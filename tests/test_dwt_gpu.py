@@ -933,3 +933,28 @@ def test_wide_pyramid_is_a_strip_level_and_one_fused_launch():
     import _packed_cases as PC
     PC.check_wide_pyramid('cuda:0', shape=(32, 3, 256, 1024))
     PC.check_wide_pyramid('cuda:0', wave='db2', mode='zero', shape=(32, 3, 130, 1028))
+
+
+# ---- round 6: several periodization levels in one launch of the fused analysis kernel -----------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('wave,H,W,J,dtype,strips', __import__('_per_cases').FUSED_PER_CASES)
+def test_fused_periodization_levels(wave, H, W, J, dtype, strips):
+    import _per_cases as PC
+    PC.check_fused_periodization(DEV, wave, H, W, J, dtype, strips, planes=(5, 3))
+
+
+@pytest.mark.gpu
+def test_fused_periodization_at_full_size():
+    """The shapes the policy takes by itself: 128x3x512^2 db4 J = 3 / db8 J = 2 and 512-wide float16 planes (config 5's levels 3-4: a
+    1024-wide float16 level has more columns than the workgroup has compute waves for two levels) - against the oracle."""
+    import _per_cases as PC
+    PC.check_fused_periodization(DEV, 'db4', 512, 512, 3, torch.float32, 0, planes=(128, 3))
+    PC.check_fused_periodization(DEV, 'db8', 512, 512, 2, torch.float32, 0, planes=(128, 3))
+    PC.check_fused_periodization(DEV, 'db8', 512, 512, 3, torch.float16, 0, planes=(16, 16))
+
+
+@pytest.mark.gpu
+def test_fused_periodization_corners_and_gradient():
+    import _per_cases as PC
+    PC.check_fused_periodization_corners(DEV)
+    PC.check_periodization_gradient(DEV, shape=(16, 8, 256, 256))
