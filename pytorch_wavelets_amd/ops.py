@@ -365,7 +365,7 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None, whol
     lattice = (same and qmf and ROWS_LATTICE and L in (8, 10, 12, 14, 16, 20) and L >= ROWS_LATTICE_MIN
                and (L > 12 or x.numel() >= LATTICE_MIN_ELEMS or (mode == 2 and L == 12)))
     if (x.dtype == torch.float64 or nlev < 1 or nlev > 3 or h_h_lo.numel() != L or L % 2 or (L > 12 and not lattice)
-            or (nlev > 1 and mode not in (0, 1, 2, 4)) or x.numel() == 0
+            or (nlev > 1 and mode not in (0, 1, 2, 4)) or x.numel() == 0 or (mode == 2 and not ROWS_PER and (nlev > 1 or L % 4 == 0))
             or (strips == 0 and 8 * N * C < 3 * _num_cus(x.device)) or strips > 2):
         return None
     # rows as whole 16-byte pieces: a dense x whose width is one, or a row-padded view (the ll that afb2d_stream(pad_ll=True) /
@@ -374,7 +374,15 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None, whol
     # float32 rows of 2-3 KiB (three pieces per row, round 5): two and more levels per launch, or a one-level transform.  A single
     # level of a longer pyramid stays with the strip kernel (tools/gpu_r5v.py, same process: 128x3x768^2 J = 3 as strip + two fused levels
     # 0.438 ms, as fused + strip + fused 0.464; the last level of 64x3x1024^2 J = 2 on the padded ll 0.465 against 0.456 on the strip kernel)
-    if W * es > 2048 and (not ROWS_3KIB or (nlev < 2 and not whole)):
+    # periodization, float16, 12 / 16 / 20 taps (the odd-cell instantiations of the long filters): the strip kernels - tuned on config 5, two / four
+    # planes per workgroup - are ahead (tools/gpu_r6_per.py deep, same process: 512x1x512^2 db8 J = 2 0.188 ms on two strip launches, 0.216
+    # fused; J = 1 0.141 / 0.182; db6 0.176 / 0.186; config 5 2.45 / 2.49); float32 (db8 0.294 / 0.245) and 8 taps (0.165 / 0.168; three
+    # levels 0.166 / 0.136) stay here
+    if mode == 2 and es == 2 and L % 4 == 0 and L >= 12:
+        return None
+    # ... and rows of exactly 2 KiB (round 6: config 5's 1024-column float16 level, which has more columns than the workgroup has compute
+    # waves for two levels; tools/gpu_r6_per.py: the transform 2.51 ms with that level on the strip kernel, 2.68 on the fused one)
+    if (W * es > 2048 and not ROWS_3KIB) or (W * es >= 2048 and nlev < 2 and not whole):
         return None
     x, x_ps, x_rs = _planes(x)
     if (x_rs * es) % 16 or (x_ps * es) % 16 or x.data_ptr() % 16 or (W * es + 15) // 16 * 16 > x_rs * es:
@@ -554,6 +562,7 @@ LATTICE_MIN_ELEMS_ML = 16000000
 IROWS_LATTICE_MIN = 8     # WL_IROWS_LAT_MIN of csrc/wl_idwt_rows.h: the fused synthesis takes the lattice from 8 taps on (the metric's inverse: -6 %)
 
 
+ROWS_PER = True         # round 6: several periodization levels per fused analysis launch, and its odd-cell tap counts (L % 4 == 0) at all (False: A/B measurements)
 ROWS_3KIB = True        # float32 rows of 2-3 KiB on the fused analysis kernel (three 1 KiB pieces per row; False: A/B measurements)
 PAD_ODD_LL = True    # an inner-level ll of the strip kernel whose rows are no whole 16-byte pieces is written at a padded row pitch (A/B: False)
 

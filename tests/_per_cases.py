@@ -31,8 +31,8 @@ FUSED_PER_CASES = [
     ('db6', 96, 128, 3, torch.float32, 1),          # 12 taps, odd cells: lattice variant
     ('db7', 128, 128, 2, torch.float32, 2),
     ('db8', 128, 256, 3, torch.float32, 1),
-    ('db8', 128, 512, 3, torch.float16, 1),         # config 5's levels 3-4 (+ one more): 2 KiB rows of float16
-    ('db8', 128, 256, 3, torch.float16, 2),
+    ('db7', 128, 512, 3, torch.float16, 1),         # 2 KiB rows of float16 (12 / 16 / 20 taps in float16 periodization stay on the strip kernels: policy)
+    ('db5', 128, 256, 3, torch.float16, 2),
     ('db10', 160, 160, 2, torch.float32, 1),
     ('sym4', 64, 192, 3, torch.float16, 0),
 ]

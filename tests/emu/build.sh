@@ -7,6 +7,8 @@ cd "$(dirname "$0")"
 CXX=${CXX:-/opt/rocm/lib/llvm/bin/clang++}
 FLAGS="-O2 -g -std=c++17 -fno-strict-aliasing -fPIC -fopenmp -Wall -Wno-unused-function $WL_EMU_EXTRA"
 pids=()
+stamp=$(mktemp); touch $stamp    # objects get the time the build STARTED: a source edited meanwhile stays newer
+built=()
 for u in api rows strip dtinv; do
   stale=0
   if [ ! -f wl_emu_$u.o ] || [ ! -f wl_emu_$u.o.d ] || [ build.sh -nt wl_emu_$u.o ]; then stale=1; else
@@ -16,9 +18,11 @@ for u in api rows strip dtinv; do
     done
   fi
   if [ $stale = 1 ]; then
-    $CXX $FLAGS -MD -MF wl_emu_$u.o.d -c wl_emu_$u.cpp -o wl_emu_$u.o & pids+=($!)
+    $CXX $FLAGS -MD -MF wl_emu_$u.o.d -c wl_emu_$u.cpp -o wl_emu_$u.o & pids+=($!); built+=(wl_emu_$u.o)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
+for o in "${built[@]}"; do touch -r $stamp $o; done
 $CXX -shared -fopenmp wl_emu_api.o wl_emu_rows.o wl_emu_strip.o wl_emu_dtinv.o -o libwl_emu.so
+touch -r $stamp libwl_emu.so; rm -f $stamp
 echo built tests/emu/libwl_emu.so

@@ -940,7 +940,7 @@ def test_wide_pyramid_is_a_strip_level_and_one_fused_launch():
 @pytest.mark.parametrize('wave,H,W,J,dtype,strips', __import__('_per_cases').FUSED_PER_CASES)
 def test_fused_periodization_levels(wave, H, W, J, dtype, strips):
     import _per_cases as PC
-    PC.check_fused_periodization(DEV, wave, H, W, J, dtype, strips, planes=(5, 3))
+    PC.check_fused_periodization(DEV, wave, H, W, J, dtype, strips, planes=(5, 3), require_fused=strips != 0)   # (0: the policy declines 15 planes)
 
 
 @pytest.mark.gpu
@@ -950,7 +950,8 @@ def test_fused_periodization_at_full_size():
     import _per_cases as PC
     PC.check_fused_periodization(DEV, 'db4', 512, 512, 3, torch.float32, 0, planes=(128, 3))
     PC.check_fused_periodization(DEV, 'db8', 512, 512, 2, torch.float32, 0, planes=(128, 3))
-    PC.check_fused_periodization(DEV, 'db8', 512, 512, 3, torch.float16, 0, planes=(16, 16))
+    PC.check_fused_periodization(DEV, 'db4', 512, 512, 3, torch.float16, 0, planes=(16, 16))
+    PC.check_fused_periodization(DEV, 'db8', 512, 512, 3, torch.float16, 0, planes=(16, 16), require_fused=False)   # (policy: strip kernels)
 
 
 @pytest.mark.gpu
