@@ -180,12 +180,33 @@ class SFB2DMulti(Function):
         d = None
         if any(ctx.needs_input_grad[:1]) or any(ctx.needs_input_grad[6 + j] for j in range(J)):
             g0_row, g1_row, g0_col, g1_col = ctx.saved_tensors
-            d = dy
-            for j in range(J):
-                d, dhigh = ops.afb2d_best(d, g0_row, g1_row, g0_col, g1_col, ctx.mode)
-                if ctx.has_highs[j] and ctx.needs_input_grad[6 + j]:
-                    grads[j] = dhigh
-                full = ctx.ll_shapes[j]
+            d, j, L = dy, 0, g0_row.numel()
+            while j < J:
+                # Levels whose low-pass the forward handed on WHOLE (no 'unpad' between them: always so in periodization) are a plain
+                # multi-level analysis with the synthesis taps: up to three of them in ONE launch of the fused kernel (round 6);
+                # a level after which a dropped row / column gets its zero gradient back ends the group.
+                n, res = 0, None
+                h, w = d.shape[-2:]
+                while FUSED_LEVELS and n < 3 and j + n < J and g0_col.numel() == L:
+                    h, w = ops.coeff_len(h, L, ctx.mode), ops.coeff_len(w, L, ctx.mode)
+                    n += 1
+                    if (h, w) != tuple(ctx.ll_shapes[j + n - 1]):
+                        break
+                while n >= 2 and res is None:
+                    res = ops.afb2d_fused(d, g0_row, g1_row, g0_col, g1_col, ctx.mode, n, whole=False)
+                    if res is None:
+                        n -= 1
+                if res is None:
+                    n = 1
+                    d, dhigh = ops.afb2d_best(d, g0_row, g1_row, g0_col, g1_col, ctx.mode)
+                    dhighs = [dhigh]
+                else:
+                    d, dhighs = res
+                for i, dhigh in enumerate(dhighs):
+                    if ctx.has_highs[j + i] and ctx.needs_input_grad[6 + j + i]:
+                        grads[j + i] = dhigh
+                j += n
+                full = ctx.ll_shapes[j - 1]
                 if tuple(d.shape[-2:]) != full:      # the forward dropped a row / column of this low-pass
                     d = torch.nn.functional.pad(d, (0, full[1] - d.shape[-1], 0, full[0] - d.shape[-2]))
             if not ctx.needs_input_grad[0]:

@@ -104,3 +104,34 @@ def check_periodization_gradient(dev, shape=(2, 2, 64, 128), wave='db4', J=3):
         assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0), (lhs, rhs)
     finally:
         ops.FUSED_STRIPS = prev
+
+
+def check_inverse_backward_is_one_fused_analysis(dev, shape=(2, 2, 64, 128), wave='db4', J=3, mode='periodization'):
+    """DWTInverse.backward = J analysis levels with the synthesis taps (reference dwt/lowlevel.py:683-694 chained by autograd); where the
+    forward 'unpadded' nothing between levels - always in periodization - they run as ONE fused launch.  Adjoint test against the oracle's
+    inverse: <S c', w> == <c', S^T w>."""
+    from pytorch_wavelets_amd import ops
+    rng = np.random.RandomState(83)
+    prev = ops.FUSED_STRIPS
+    ops.FUSED_STRIPS = 1
+    try:
+        xfm = pw.DWTForward(J=J, wave=wave, mode=mode).to(dev)
+        ifm = pw.DWTInverse(wave=wave, mode=mode).to(dev)
+        with torch.no_grad():
+            yl, yh = xfm(torch.tensor(rng.randn(*shape), dtype=torch.float32, device=dev))
+        yl = yl.clone().requires_grad_(True)
+        yh = [h.clone().requires_grad_(True) for h in yh]
+        y = ifm((yl, yh))
+        w = torch.tensor(rng.randn(*y.shape), dtype=torch.float32, device=dev)
+        c0 = pw.launch_count()
+        grads = torch.autograd.grad((y * w).sum(), [yl] + yh)
+        ks = [k for k in pw.kernels_since(c0) if not k.endswith(')') and k.startswith('Wl')]
+        assert len(ks) == 1 and ks[0].startswith('WlAfbRows<'), ks
+        cl = rng.randn(*yl.shape)
+        ch = [rng.randn(*h.shape) for h in yh]
+        oy = wo.dwt_inverse(cl, ch, _flat(ifm.g0_col), _flat(ifm.g1_col), _flat(ifm.g0_row), _flat(ifm.g1_row), mode)
+        lhs = float((oy * w.cpu().double().numpy()).sum())
+        rhs = float((cl * grads[0].cpu().double().numpy()).sum() + sum((a * g.cpu().double().numpy()).sum() for a, g in zip(ch, grads[1:])))
+        assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0), (lhs, rhs)
+    finally:
+        ops.FUSED_STRIPS = prev

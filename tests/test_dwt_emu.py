@@ -1124,3 +1124,5 @@ def test_fused_periodization_corners_and_gradient():
     with emu_backend.emulated():
         PC.check_fused_periodization_corners('cpu')
         PC.check_periodization_gradient('cpu')
+        PC.check_inverse_backward_is_one_fused_analysis('cpu')
+        PC.check_inverse_backward_is_one_fused_analysis('cpu', shape=(1, 2, 64, 64), wave='db3', J=2)

@@ -959,3 +959,4 @@ def test_fused_periodization_corners_and_gradient():
     import _per_cases as PC
     PC.check_fused_periodization_corners(DEV)
     PC.check_periodization_gradient(DEV, shape=(16, 8, 256, 256))
+    PC.check_inverse_backward_is_one_fused_analysis(DEV, shape=(16, 8, 256, 256))
