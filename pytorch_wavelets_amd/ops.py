@@ -364,6 +364,11 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None, whol
     # (periodization with 12 taps: its odd-cell instantiations are the lattice variant and the two-bank direct form, which spills)
     lattice = (same and qmf and ROWS_LATTICE and L in (8, 10, 12, 14, 16, 20) and L >= ROWS_LATTICE_MIN
                and (L > 12 or x.numel() >= LATTICE_MIN_ELEMS or (mode == 2 and L == 12)))
+    # (float16-ROUNDED 20-tap banks - the buffers of a `.half()` module - are no orthogonal pair to within the lattice's tolerance (residue 9e-4,
+    # csrc/wl_lattice.h): the examination rejects them and the armed two-bank 20-tap kernel, which spills, would do the work - 0.70 ms against
+    # 0.32 on the strip kernels for 512x1x512^2 J = 2, tools/gpu_r6_per.py deep)
+    if L == 20 and h_w_lo.dtype == torch.float16 and strips == 0:      # (the engine's policy; a forced launch is taken)
+        return None
     if (x.dtype == torch.float64 or nlev < 1 or nlev > 3 or h_h_lo.numel() != L or L % 2 or (L > 12 and not lattice)
             or (nlev > 1 and mode not in (0, 1, 2, 4)) or x.numel() == 0 or (mode == 2 and not ROWS_PER and (nlev > 1 or L % 4 == 0))
             or (strips == 0 and 8 * N * C < 3 * _num_cus(x.device)) or strips > 2):
@@ -500,6 +505,8 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
     lattice = (same and qmf and ROWS_LATTICE and L in (8, 10, 12, 14, 16, 20) and L >= IROWS_LATTICE_MIN
                and (L > 12 or (nlev >= 1 and yh[0] is not None and yh[0].dim() == 5
                                and 4 * yh[0].shape[3] * yh[0].shape[4] * N * C >= (LATTICE_MIN_ELEMS if nlev == 1 else min(LATTICE_MIN_ELEMS, LATTICE_MIN_ELEMS_ML)))))
+    if L == 20 and g_w_lo.dtype == torch.float16 and strips == 0:      # (as in afb2d_fused: float16-rounded 20-tap banks fail the lattice's examination)
+        return None
     if (yl.dtype == torch.float64 or nlev < 1 or nlev > 3 or g_h_lo.numel() != L or L % 2 or (L > 12 and not lattice) or mode == 2
             or yl.numel() == 0 or (strips == 0 and 8 * N * C < 3 * _num_cus(yl.device)) or strips > 2
             or any(t is None or t.dim() != 5 or t.dtype != yl.dtype or t.shape[:3] != (N, C, 3) or t.numel() == 0
