@@ -692,16 +692,19 @@ def other_configs(pw, dev, sync):
         other['scatlayer_1024x3x128x128_fp32'] = {'fwd_ms': round(tsm, 4), 'frac_of_hbm_peak_at_11B_per_px': frac(11 * xm.numel(), tsm),
                                                   'fwd_kernels': names(lambda: slm(xm))}
         del xm
-        # outside the fused streaming envelope of round 2: wider images, longer filters
-        for tag, shape, wave, L in (('dwt_j3_db4_16x3x1024x1024_fp32', (16, 3, 1024, 1024), 'db4', 8),
-                                    ('dwt_j3_db4_64x3x1024x1024_fp32', (64, 3, 1024, 1024), 'db4', 8),
-                                    ('dwt_j3_db8_128x3x512x512_fp32', (128, 3, 512, 512), 'db8', 16)):
+        # outside the fused streaming envelope of round 2: wider images, longer filters; round 6: periodization at the metric's shape
+        # (all levels in one launch of the fused analysis kernel; the inverse still one strip / tile launch per level)
+        for tag, shape, wave, L, mode in (('dwt_j3_db4_16x3x1024x1024_fp32', (16, 3, 1024, 1024), 'db4', 8, 'symmetric'),
+                                          ('dwt_j3_db4_64x3x1024x1024_fp32', (64, 3, 1024, 1024), 'db4', 8, 'symmetric'),
+                                          ('dwt_j3_db8_128x3x512x512_fp32', (128, 3, 512, 512), 'db8', 16, 'symmetric'),
+                                          ('dwt_j3_db4_periodization_128x3x512x512_fp32', (128, 3, 512, 512), 'db4', 8, 'periodization'),
+                                          ('dwt_j3_db9_128x3x512x512_fp32', (128, 3, 512, 512), 'db9', 18, 'symmetric')):
             xl = torch.randn(*shape, device=dev)
-            fx, fi = pw.DWTForward(J=3, wave=wave, mode='symmetric').to(dev), pw.DWTInverse(wave=wave, mode='symmetric').to(dev)
+            fx, fi = pw.DWTForward(J=3, wave=wave, mode=mode).to(dev), pw.DWTInverse(wave=wave, mode=mode).to(dev)
             c = fx(xl)
             tf = time_seq_fn(lambda: fx(xl), 30, sync)
             ti = time_seq_fn(lambda: fi(c), 30, sync)
-            b = algorithmic_bytes_fwd(shape[0], shape[1], shape[2], shape[3], 3, L, 4)
+            b = algorithmic_bytes_fwd(shape[0], shape[1], shape[2], shape[3], 3, L, 4, periodization=mode == 'periodization')
             other[tag] = {'fwd_ms': round(tf, 4), 'inv_ms': round(ti, 4), 'fwd_frac': frac(b, tf), 'inv_frac': frac(b, ti),
                           'fwd_kernels': names(lambda: fx(xl)), 'inv_kernels': names(lambda: fi(c))}
             del xl, c

@@ -106,7 +106,7 @@ int wl_dwt2d_synthesis(const void* ll, int64_t ll_plane_stride, int ll_row_strid
  * (dwt/transform2d.py:63-74): x (planes,H,W) dense -> yh[j] (planes,3,H_j,W_j) for j < nlev and the last
  * level's low-pass yl; one workgroup streams one plane top to bottom, the intermediate LL_j stay in LDS rings and
  * HBM traffic is the algorithmic minimum.  `yh` is a HOST array of nlev device pointers.  Same taps (even length
- * L <= 12; 14, 16, 20 in the lattice form, see `strips`) on both axes of every level, F32/F16 data, float taps; rows of 16-byte multiples of up to
+ * L <= 12; 14 - 20 in the lattice form, see `strips`) on both axes of every level, F32/F16 data, float taps; rows of 16-byte multiples of up to
  * 2 KiB (F32: 3 KiB) and ~630 outputs;
  * zero / symmetric / reflect for nlev > 1, any mode for nlev == 1.  `strips`: 0 = let the engine decide (it declines
  * below about 3/8 as many planes as compute units, where the tile kernels win; with fewer planes than compute units it
@@ -115,7 +115,7 @@ int wl_dwt2d_synthesis(const void* ll, int64_t ll_plane_stride, int ll_row_strid
  * 10- and 12-tap kernels then run their one-bank variant (one set of tap pairs in scalar registers), which compares the two
  * banks on the device first, with the two-bank variant queued behind it for the case that they differ (identical POINTERS for
  * both axes need no hint and no check); + 8 (bit 3) = a HINT that each highpass bank is the quadrature mirror of its lowpass bank.
- * The LATTICE variant of 10 - 20 taps (the only fused multi-level form of 14, 16 and 20 taps) needs device scratch: see
+ * The LATTICE variant of 10 - 20 taps (the only fused multi-level form of 14 - 20 taps) needs device scratch: see
  * wl_dwt2d_analysis_fused_ex; here those lengths return WL_ERR_UNSUPPORTED.  Returns WL_ERR_UNSUPPORTED outside the
  * kernel's envelope: the caller then uses wl_dwt2d_analysis level by level. */
 int wl_dwt2d_analysis_fused(const void* x, void* yl, void* const* yh, int dtype, int64_t planes, int H,
@@ -128,7 +128,7 @@ int wl_dwt2d_analysis_fused(const void* x, void* yl, void* const* yh, int dtype,
  * elements behind the row; the kernel overwrites what it loaded from there before any lane reads it);
  * and (b) device scratch for the LATTICE variant (csrc/wl_lattice.h): with BOTH hints (strips | 4 | 8) and tap_scratch =
  * WL_TAP_SCRATCH_BYTES of device memory that stay valid until the launches of this call have run (stream order), the 10- to
- * 20-tap kernels (10, 12, 14, 16, 20) run their lattice variant behind a one-thread examination of the banks (WlTapPrep), the
+ * 20-tap kernels (10 - 20) run their lattice variant behind a one-thread examination of the banks (WlTapPrep), the
  * two-bank variant armed behind it.  tap_state: NULL, or a HOST int the caller keeps next to the scratch block - 0 when the
  * block is fresh, when any of the four tap pointers, their contents, L, the data type or the direction (analysis / synthesis)
  * changed; the library sets bit 0 when it has run the examination of exactly these banks into the block, bit 1 when that
@@ -157,7 +157,7 @@ int wl_dwt2d_synthesis_fused(const void* yl, int64_t yl_plane_stride, int yl_row
                              int64_t planes, int nlev, const void* g_w_lo, const void* g_w_hi,
                              const void* g_h_lo, const void* g_h_hi, int L, int mode, int strips, void* stream);
 /* The same with tap_scratch / tap_state as for wl_dwt2d_analysis_fused_ex: with both hints and the scratch the 8-20 tap kernels
- * run their lattice variant (the transposed recurrence of csrc/wl_lattice.h) - the only fused form of 14, 16 and 20 taps. */
+ * run their lattice variant (the transposed recurrence of csrc/wl_lattice.h) - the only fused form of 14 - 20 taps. */
 int wl_dwt2d_synthesis_fused_ex(const void* yl, int64_t yl_plane_stride, int yl_row_stride, int yl_h, int yl_w,
                                 const void* const* yh, const int* Kh, const int* Kw, void* y, int dtype,
                                 int64_t planes, int nlev, const void* g_w_lo, const void* g_w_hi,

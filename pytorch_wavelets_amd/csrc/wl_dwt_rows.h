@@ -90,6 +90,9 @@ struct WlRowsLevel {
     int pad;            // byte offset of sample 0 inside a ring row (multiple of 16)
     int hl, hr;         // halo cells left / right of the samples (boundary extension along W)
     int nwaves;         // 64-column chunks of this level (each chunk is one compute wave)
+    int ring_rows;      // levels >= 2: rows of this level's SOURCE ring (power of two, row r in r & (ring_rows - 1)); round 6: per level -
+                        // the smallest the level's own schedule does not overrun (one size for all rings put 16-tap symmetric pyramids of
+                        // three levels over the 80 KiB of two workgroups per CU)
 };
 
 // One SEGMENT of a plane: the feeds [f0, fend) of every level and the output rows [own_lo, own_hi) it stores.  A plane
@@ -122,7 +125,6 @@ struct WlRowsArgs {
     int x_rs, ll_rs;
     int nlev, ext, base;
     int nwhole;         // workgroups [0, nwhole) take whole planes; pairs of the remaining ones the two halves of a plane
-    int ring_rows;      // rows of the LL rings (power of two)
     int zero_off;       // LDS byte offset of an all-zero row (zero padding above / below the plane)
     int lds_bytes;
     // role of every wave: level (0..nlev-1) and first column of its 64-column chunk; -1 = loader (col0 = its index), -2 = spare.  Waves w
@@ -497,9 +499,9 @@ struct WlAfbRows {
         R.hp2 = R.hp1 + (size_t)bplane * SZ;
         R.llp = reinterpret_cast<char*>(a.ll + (size_t)plane * a.ll_ps);
         R.rowb = (unsigned)g.Kw * SZ; R.llrowb = (unsigned)a.ll_rs * SZ; R.kb = (unsigned)k * SZ;
-        R.rmask = a.ring_rows - 1;
         const WlRowsLevel& gn = a.g[j + 1 < WL_ROWS_MAXLEV ? j + 1 : j];
         R.nring = gn.ring_off; R.npitch = gn.ring_pitch;
+        R.rmask = gn.ring_rows - 1;                       // (the ring this level WRITES: the next level's source ring)
         Lane L;
 #pragma unroll
         for (int t = 0; t < (LAT ? (KL > 1 ? KL - 1 : 1) : LT); ++t) L.win[t] = wl_v2{0.f, 0.f};
@@ -527,7 +529,7 @@ struct WlAfbRows {
                                  bool active, int k) {
         const WlRowsLevel& g = a.g[j];
         char* const smem = ctx.smem;
-        const int rmask = R.rmask, zrow = a.zero_off, ring = g.ring_off, pitch = g.ring_pitch, Hs = g.Hs;
+        const int rmask = g.ring_rows - 1, zrow = a.zero_off, ring = g.ring_off, pitch = g.ring_pitch, Hs = g.Hs;   // (the ring this level READS)
         const bool zmode = a.ext == WL_EXT_ZERO, per = a.ext == WL_EXT_PER;
         // LDS byte offsets (wave-uniform) of the two source rows of feed f = (2f+base, 2f+base+1); i = its index in
         // the half-batch hb

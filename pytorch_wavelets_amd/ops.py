@@ -362,7 +362,7 @@ def afb2d_fused(x, h_w_lo, h_w_hi, h_h_lo, h_h_hi, mode, nlev, strips=None, whol
     same = bool(getattr(_HINTS, 'same', False))
     qmf = bool(getattr(_HINTS, 'qmf', False))
     # (periodization with 12 taps: its odd-cell instantiations are the lattice variant and the two-bank direct form, which spills)
-    lattice = (same and qmf and ROWS_LATTICE and L in (8, 10, 12, 14, 16, 20) and L >= ROWS_LATTICE_MIN
+    lattice = (same and qmf and ROWS_LATTICE and L in (8, 10, 12, 14, 16, 18, 20) and L >= ROWS_LATTICE_MIN
                and (L > 12 or x.numel() >= LATTICE_MIN_ELEMS or (mode == 2 and L == 12)))
     # (float16-ROUNDED 20-tap banks - the buffers of a `.half()` module - are no orthogonal pair to within the lattice's tolerance (residue 9e-4,
     # csrc/wl_lattice.h): the examination rejects them and the armed two-bank 20-tap kernel, which spills, would do the work - 0.70 ms against
@@ -502,7 +502,7 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
     # (hints as in afb2d_fused: with "same banks" and "quadrature-mirror highpass" 10-20 taps run the lattice variant of the kernel)
     same = bool(getattr(_HINTS, 'same', False))
     qmf = bool(getattr(_HINTS, 'qmf', False))
-    lattice = (same and qmf and ROWS_LATTICE and L in (8, 10, 12, 14, 16, 20) and L >= IROWS_LATTICE_MIN
+    lattice = (same and qmf and ROWS_LATTICE and L in (8, 10, 12, 14, 16, 18, 20) and L >= IROWS_LATTICE_MIN
                and (L > 12 or (nlev >= 1 and yh[0] is not None and yh[0].dim() == 5
                                and 4 * yh[0].shape[3] * yh[0].shape[4] * N * C >= (LATTICE_MIN_ELEMS if nlev == 1 else min(LATTICE_MIN_ELEMS, LATTICE_MIN_ELEMS_ML)))))
     if L == 20 and g_w_lo.dtype == torch.float16 and strips == 0:      # (as in afb2d_fused: float16-rounded 20-tap banks fail the lattice's examination)

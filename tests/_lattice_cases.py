@@ -267,11 +267,14 @@ def _tile_14_18_modes(dev, wave, shape, rng, h0, h1, g0, g1, L):
 
 
 ROWS_LATTICE_CASES = [('db5', 'symmetric', 3), ('db6', 'zero', 3), ('sym7', 'reflect', 2), ('db8', 'symmetric', 3), ('sym8', 'zero', 2),
-                      ('db10', 'symmetric', 2), ('coif2', 'reflect', 3), ('db7', 'symmetric', 3)]
+                      ('db10', 'symmetric', 2), ('coif2', 'reflect', 3), ('db7', 'symmetric', 3), ('db9', 'symmetric', 2), ('coif3', 'zero', 3)]
 
 
 def _is_lattice_rows(name):
-    return 'WlAfbRows<' in name and name.endswith(', 3, 1, 1>')
+    if 'WlAfbRows<' not in name or not name.rstrip().endswith('>'):
+        return False
+    args = [a.strip() for a in name[name.index('<') + 1:name.rindex('>')].split(',')]   # <T, L, PPR, D, SAME, LAT[, ODD]>
+    return len(args) >= 6 and args[4] == '1' and args[5] == '1'
 
 
 def check_rows_lattice_vs_oracle(dev, wave, mode, J, shape=(2, 3, 128, 256), dtype=torch.float32):
