@@ -505,7 +505,10 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
     lattice = (same and qmf and ROWS_LATTICE and L in (8, 10, 12, 14, 16, 18, 20) and L >= IROWS_LATTICE_MIN
                and (L > 12 or (nlev >= 1 and yh[0] is not None and yh[0].dim() == 5
                                and 4 * yh[0].shape[3] * yh[0].shape[4] * N * C >= (LATTICE_MIN_ELEMS if nlev == 1 else min(LATTICE_MIN_ELEMS, LATTICE_MIN_ELEMS_ML)))))
-    if L == 20 and g_w_lo.dtype == torch.float16 and strips == 0:      # (as in afb2d_fused: float16-rounded 20-tap banks fail the lattice's examination)
+    # float16 data, 10 taps and more: the fused synthesis reads its coefficients one 2-byte element at a time and converts each - the per-level strip /
+    # tile ladder is ahead (tools/gpu_r6_grid.py, 128x3x512^2 J = 3, fractions of the HBM roofline: db5 0.17 fused / 0.27 per level, db6 0.18 / 0.23,
+    # db7 0.15 / 0.23, db9 0.14 / 0.23, bior4.4 0.15 / 0.27; up to 8 taps the two are level: haar 0.45 / 0.34, db2 0.28 / 0.27, db4 0.25 / 0.26)
+    if es == 2 and L > IROWS_F16_MAXL and strips == 0:
         return None
     if (yl.dtype == torch.float64 or nlev < 1 or nlev > 3 or g_h_lo.numel() != L or L % 2 or (L > 12 and not lattice) or mode == 2
             or yl.numel() == 0 or (strips == 0 and 8 * N * C < 3 * _num_cus(yl.device)) or strips > 2
@@ -569,6 +572,7 @@ LATTICE_MIN_ELEMS_ML = 16000000
 IROWS_LATTICE_MIN = 8     # WL_IROWS_LAT_MIN of csrc/wl_idwt_rows.h: the fused synthesis takes the lattice from 8 taps on (the metric's inverse: -6 %)
 
 
+IROWS_F16_MAXL = 8      # longest filter the fused synthesis takes on float16 data under the engine's policy (99: A/B measurements)
 ROWS_PER = True         # round 6: several periodization levels per fused analysis launch, and its odd-cell tap counts (L % 4 == 0) at all (False: A/B measurements)
 ROWS_3KIB = True        # float32 rows of 2-3 KiB on the fused analysis kernel (three 1 KiB pieces per row; False: A/B measurements)
 PAD_ODD_LL = True    # an inner-level ll of the strip kernel whose rows are no whole 16-byte pieces is written at a padded row pitch (A/B: False)
