@@ -45,7 +45,10 @@ def test_batch_sharding_world2():
     emu_backend.handle()   # build the emulator once, before forking workers
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:      # a port nobody holds (consecutive runs from one pytest process must not meet the previous run's socket)
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -70,7 +73,10 @@ def _run_bench_emulated(extra):
     import json
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:      # a port nobody holds (consecutive runs from one pytest process must not meet the previous run's socket)
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
            '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2',
            '--warmup', '1', '--emulate'] + extra
