@@ -51,12 +51,21 @@ struct WlIRowsLevel {
     int dma_shift;      // log2(dma_rows)
     int cpr;            // chunks per revolution of the ring = ceil(dma_rows * rbytes / 1024)
     int nwaves;         // compute waves: 64 column pairs each
+    // periodization (PER = 1, round 6): the DMA rings are ROWS of `rbytes` (a pitch, 16-byte multiple) - [.. | WARM halo cells | Kw coefficients],
+    // the coefficients at byte per_d0 (16-byte aligned), in front of them copies of the row's LAST WARM coefficients (the wrap of the
+    // reference's periodized synthesis, dwt/lowlevel.py:252-261) - row k of the level's feed numbering at (k & (dma_rows - 1)) * rbytes;
+    // an LDS-fed low-pass ring row holds the level above's output in the order it was produced (z order: x column m = z column m + WARM),
+    // WARM copies of its first cells behind it, and head_off = WARM more rows: copies of the ring's first WARM rows, which the last WARM feeds read
+    int per_d0, head_off;
 };
 
 struct WlIRowsSeg {
     int nhb;
     int f0[WL_IROWS_MAXLEV], fend[WL_IROWS_MAXLEV];   // feeds [f0, fend) of each level
-    int own_lo, own_hi;                               // rows of x this segment stores
+    int rho[WL_IROWS_MAXLEV];                         // PER: the segment's frame is the periodic plane ROTATED by rho[j] coefficient rows of level j
+                                                      // (feed i of level j reads coefficient row (i - WARM + rho[j]) mod Kh): both halves of a cut
+                                                      // plane are a segment that starts at feed 0 and never meets its own wrap
+    int own_lo, own_hi;                               // rows of x this segment stores (PER: z rows of the rotated frame)
     unsigned sched[WL_IROWS_MAXHB / 4];               // per half-batch: bits 2j+1:2j = feeds of level j
 };
 
@@ -81,6 +90,7 @@ struct WlIRowsArgs {
     int pp, lds_plane;
     WlIRowsLevel g[WL_IROWS_MAXLEV];
     WlIRowsSeg seg[3];             // 0: whole plane, 1: top half, 2: bottom half
+    int per;                       // periodization (the PER instantiations)
     int guard;                     // tap-relation guard (wl_common.h) of the lattice variant (1) and its armed four-bank fallback (2); 0 = no check
     const float* lat;              // WlTapPrep's verdict (+ the column lattice for LAT = 1) in device scratch (wl_lattice.h)
 };
@@ -100,7 +110,8 @@ struct WlIRowsSched {
         while (n < 2 && fed[j] + n < sg.fend[j]) {
             const int k = fed[j] + n;
             // its LL row must exist (the coarsest level's arrives by DMA like the bands) ...
-            if (j + 1 < a.nlev && k >= made(sg, j + 1, LT)) break;
+            // (periodization: feeds Kh .. Kh + WARM - 1 read the head copies of the ring's first rows, made long ago)
+            if (j + 1 < a.nlev && k >= made(sg, j + 1, LT) && !(a.per && k >= a.g[j].Kh)) break;
             // ... and its two output rows must fit into the ring of the level below without evicting an unread row
             if (j > 0 && k - sg.f0[j] >= warm && 2 * (k - warm) + 1 - a.g[j - 1].ll_rows >= fed[j - 1]) break;
             ++n;
@@ -118,7 +129,12 @@ struct WlIRowsSched {
                                 // A/B of the inverse 0.1887-0.1899 -> 0.1768-0.1782 ms (-6 %) WITH the examination kernel and the armed
                                 // fallback in the figure (the analysis kernel at 8 taps measured +2 %: its lattice starts at 10)
 #endif
-template <typename T, int LT, int LAT = 0>
+// PER = 1 (round 6): periodization.  y[n] = sum_k c[k mod N] g[n - 2k] (the reference's transposed convolution + ONE wrap-add, for a level of
+// at least L/2 coefficients) and x[m] = y[(m + L/2 - 1) mod 2N] (its roll): the polyphase arithmetic of the other modes on coefficient rows /
+// columns that carry L/2 - 1 wrapped coefficients in front, all 2N outputs kept, stored L/2 - 1 places earlier (address arithmetic).  The roll
+// makes the order in which a level PRODUCES its rows the order in which the level below CONSUMES them - the rows it needs first are the
+// producer's first - so nothing is recomputed: the low-pass rings keep a copy of their first L/2 - 1 rows and cells (WlIRowsLevel).
+template <typename T, int LT, int LAT = 0, int PER = 0>
 struct WlSfbRows {
     typedef WlIRowsArgs<T> Args;
     static const int kThreads = 64 * WL_IROWS_WAVES;
@@ -207,6 +223,73 @@ struct WlSfbRows {
         }
     }
 
+    // ---- loader wave, periodization: one coefficient ROW of every source per step, into ring rows with the wrapped cells in front ------
+    static WL_DEV void loader_per(const Args& a, const WlIRowsSeg& sg, const WlCtx& ctx, int64_t plane, int lane, int j, int s0, int ns, int soff) {
+        const WlIRowsLevel& g = a.g[j];
+        const int P = g.rbytes, R = g.dma_rows, Kh = g.Kh, rowb = g.Kw * SZ;
+        const int rowb16 = rowb & ~15, tail = (rowb & 15) / 4;
+        const int nseg = (rowb16 + WL_IROWS_CHUNK - 1) / WL_IROWS_CHUNK;      // dwordx4 instructions per row and source
+        const int per_row = ns * (nseg + (tail ? 1 : 0));                        // DMA instructions of one step
+        const int f0 = sg.f0[j], fend = sg.fend[j], rho = sg.rho[j];
+        const char* src[4];
+        int dst[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int s = s0 + (i < ns ? i : 0);
+            src[i] = s == 0 ? reinterpret_cast<const char*>(a.yl + (size_t)plane * a.ll_ps)
+                            : reinterpret_cast<const char*>(a.yh[j] + ((size_t)plane * 3 + (s - 1)) * ((size_t)g.Kh * g.Kw));
+            dst[i] = g.src_off[s] + soff;
+        }
+        const int max_rows = WL_IROWS_MAX_VM / per_row - 1;   // rows in flight at once
+        int next = f0, landed = f0;                           // next row to issue / rows [f0, landed) known to have landed
+        int fed = f0;
+        auto try_issue = [&]() {
+            if (next >= fend || next - landed >= max_rows) return false;
+            if (next - R >= fed - 2) return false;            // the ring row it overwrites: consumed, and not in the half-batch that is running now
+            int sr = next - WARM + rho;                       // the coefficient row of feed `next`, wrapped into the plane
+            sr = sr < 0 ? sr + Kh : sr;
+            sr = sr >= Kh ? sr - Kh : sr;
+            const unsigned gro = (unsigned)sr * (unsigned)rowb;
+            const unsigned slot = (unsigned)((next & (R - 1)) * P + g.per_d0);
+            if (!(WL_IROWS_ABLATE & 2)) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i >= ns) break;
+                    for (int q = 0; q < nseg; ++q) {
+                        const int byte = (q * 64 + lane) * 16;
+                        wl_dma16_s(ctx, (unsigned)dst[i] + slot + (unsigned)(q * WL_IROWS_CHUNK), src[i], gro + (unsigned)byte, byte + 16 <= rowb);
+                    }
+                    if (tail) wl_dma4_s(ctx, (unsigned)dst[i] + slot + (unsigned)rowb16, src[i], gro + (unsigned)(rowb16 + lane * 4), lane < tail);
+                }
+            }
+            ++next;
+            return true;
+        };
+        while (try_issue()) {}
+        unsigned word = sg.sched[0];
+        for (int hb = 0; hb < sg.nhb; ++hb) {
+            const int n = (int)(word >> (8 * (hb & 3) + 2 * j)) & 3;
+            if ((hb & 3) == 3) word = sg.sched[(hb >> 2) + 1 < WL_IROWS_MAXHB / 4 ? (hb >> 2) + 1 : 0];
+            if (n) {   // rows fed .. fed+n-1 have landed; their wrapped cells: copies of the row's last WARM coefficients
+                const int nd = fed + n;
+                if (next < nd) wl_fail();   // the launcher's geometry checks rule this out
+                if (!(WL_IROWS_ABLATE & 2)) wl_wait_vm_dyn((next - nd) * per_row);
+                landed = nd;
+                if (WARM > 0) {
+                    for (int it = lane; it < n * ns * WARM; it += 64) {
+                        const int h = it % WARM, rs = it / WARM, i = rs % ns, rr = rs / ns;
+                        char* row = ctx.smem + (dst[i < 4 ? i : 0] + ((fed + rr) & (R - 1)) * P + g.per_d0);
+                        *reinterpret_cast<T*>(row + (h - WARM) * SZ) = *reinterpret_cast<const T*>(row + (g.Kw - WARM + h) * SZ);
+                    }
+                }
+            }
+            ctx.sync();
+            fed += n;
+            while (try_issue()) {}
+        }
+        wl_wait_vm<0>();   // nothing may land after the workgroup has released its LDS
+    }
+
     // ---- compute waves of level j -------------------------------------------------------------------------------------
     struct __attribute__((packed, aligned(sizeof(T)), may_alias)) WlPairT { T a, b; };
     static const int NP = (HL + 1) / 2;        // coefficient pairs a lane reads per band row
@@ -215,6 +298,11 @@ struct WlSfbRows {
         wl_v2 gw0[HL], gw1[LAT ? 1 : HL], gh0[LAT ? 1 : HL], gh1[LAT ? 1 : HL];   // (g[2t], g[2t+1]) tap pairs, wave-uniform (LAT: gw0 g only)
         wl_v2 lt[LAT ? HL : 1];                // LAT: (T_k, -T_k) of the column lattice
         int coff;                              // byte offset of this lane's first coefficient in a ring row
+        int coff_ll;                           // PER: the same in the low-pass source's row (an LDS-fed ring starts at its cell 0, a DMA ring at its halo)
+        int ycol1;                             // PER, level 0: byte offset of this lane's SECOND output column in a row of x (the roll may wrap between the two)
+        int hcol0, hcol1;                      // PER, levels > 0: the wrapped cells behind the ring row this lane is the source of (or -1)
+        int rot2, xoh;                         // PER, level 0: 2 rho - WARM and OH: x row of z row m = (m + rot2) mod OH
+        int lhead;                             // PER, levels > 0: LDS offset of the head rows of the ring this level writes
         int llmask;                            // row mask of this level's low-pass source ring
         bool two;                              // the second column of the pair exists (odd widths: not for the last pair)
         bool odd_wave;                         // wave-uniform: some lane of this wave has !two
@@ -234,10 +322,11 @@ struct WlSfbRows {
     // intermediate), b = (lh, hh) (the H-high one); tap pair t meets coefficient c + HL-1 - t
     static WL_DEV void row_syn(const WlIRowsLevel& g, const Wave& R, const char* smem, int k, wl_v2& na, wl_v2& nb) {
         // (all scalar already: no readfirstlane here - it would drag the producers of its operand into vector registers)
-        const int rll = g.src_off[0] + (k & R.llmask) * g.ll_pitch;
+        int rll = g.src_off[0] + (k & R.llmask) * g.ll_pitch;
+        if (PER && g.head_off >= 0 && k >= g.Kh) rll = g.head_off + (k - g.Kh) * g.ll_pitch;   // (wave-uniform: the last WARM feeds of a whole plane)
         const int rb = (k & (g.dma_rows - 1)) * g.rbytes;
         wl_v2 vll[NP], vlh[NP], vhl[NP], vhh[NP];
-        load_coeffs(smem + (rll + R.coff), vll);
+        load_coeffs(smem + (rll + (PER ? R.coff_ll : R.coff)), vll);
         load_coeffs(smem + (g.src_off[1] + rb + R.coff), vlh);
         load_coeffs(smem + (g.src_off[2] + rb + R.coff), vhl);
         load_coeffs(smem + (g.src_off[3] + rb + R.coff), vhh);
@@ -304,9 +393,51 @@ struct WlSfbRows {
             wl_pk_fma_y(y1, R.gh1[LAT ? 0 : t], eb[OFF + HL - 1 - t]);
         }
     }
+    // periodization: z rows m, m+1 (y0 = the two rows of z column 2q, y1 of column 2q+1) - level 0: to x, L/2 - 1 rows / columns earlier
+    // (mod the plane, and by the segment's rotation); other levels: into the ring of the level below in z order, with the copies it wraps to
+    template <int j>
+    static WL_DEV void emit_per(const Wave& R, char* smem, int m, wl_v2 y0, wl_v2 y1) {
+        if (j == 0) {
+            if ((WL_IROWS_ABLATE & 1) && y0.x + y0.y + y1.x + y1.y != 1.2345e30f) return;
+            int r0 = m + R.rot2;
+            r0 = r0 < 0 ? r0 + R.xoh : r0;
+            r0 = r0 >= R.xoh ? r0 - R.xoh : r0;
+            int r1 = r0 + 1;
+            r1 = r1 >= R.xoh ? r1 - R.xoh : r1;
+            char* p0 = R.yp + (unsigned)r0 * R.yrowb;
+            char* p1 = R.yp + (unsigned)r1 * R.yrowb;
+            if (!R.odd_wave) {
+                T v[2] = {(T)y0.x, (T)y1.x}, w[2] = {(T)y0.y, (T)y1.y};
+                *reinterpret_cast<WlPairT*>(p0 + R.ycol) = *reinterpret_cast<WlPairT*>(v);
+                *reinterpret_cast<WlPairT*>(p1 + R.ycol) = *reinterpret_cast<WlPairT*>(w);
+            } else {   // the wave that holds the pair the roll splits between the row's last and first column
+                *reinterpret_cast<T*>(p0 + R.ycol) = (T)y0.x; *reinterpret_cast<T*>(p0 + R.ycol1) = (T)y1.x;
+                *reinterpret_cast<T*>(p1 + R.ycol) = (T)y0.y; *reinterpret_cast<T*>(p1 + R.ycol1) = (T)y1.y;
+            }
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int row = m + rr;
+                if (row >= R.lrows) continue;
+                const T va = (T)(rr ? y0.y : y0.x), vb = (T)(rr ? y1.y : y1.x);
+                char* d = smem + (R.lring + (row & R.lmask) * R.lpitch);
+                T v[2] = {va, vb};
+                *reinterpret_cast<WlPairT*>(d + R.lcol) = *reinterpret_cast<WlPairT*>(v);
+                if (R.hcol0 >= 0) *reinterpret_cast<T*>(d + R.hcol0) = va;
+                if (R.hcol1 >= 0) *reinterpret_cast<T*>(d + R.hcol1) = vb;
+                if (row < WARM) {   // (wave-uniform) the ring's first rows, kept for the feeds that wrap around the plane's bottom
+                    char* h = smem + (R.lhead + row * R.lpitch);
+                    *reinterpret_cast<WlPairT*>(h + R.lcol) = *reinterpret_cast<WlPairT*>(v);
+                    if (R.hcol0 >= 0) *reinterpret_cast<T*>(h + R.hcol0) = va;
+                    if (R.hcol1 >= 0) *reinterpret_cast<T*>(h + R.hcol1) = vb;
+                }
+            }
+        }
+    }
     // output rows m, m+1: to x (8 contiguous bytes per lane and row), or into the low-pass ring of the level below
     template <int j>
     static WL_DEV void emit(const Wave& R, char* smem, int m, wl_v2 y0, wl_v2 y1) {
+        if constexpr (PER != 0) { emit_per<j>(R, smem, m, y0, y1); return; }
         if (j == 0) {
             // every row a level-0 feed produces is one this segment owns: its feeds start at own_lo / 2 and end with the
             // feed that makes row own_hi - 1
@@ -375,6 +506,27 @@ struct WlSfbRows {
         R.lpitch = j > 0 ? a.g[j > 0 ? j - 1 : 0].ll_pitch : 0;
         R.lrows = j > 0 ? a.g[j > 0 ? j - 1 : 0].Kh : 0;   // rows the level below reads ('unpad': it may drop the last one)
         R.lcol = 2 * c * SZ;
+        R.coff_ll = R.coff; R.ycol1 = 0; R.hcol0 = R.hcol1 = -1; R.rot2 = 0; R.xoh = g.OH; R.lhead = 0;
+        if constexpr (PER != 0) {
+            const int q = active ? c : 0;
+            R.coff = g.per_d0 - WARM * SZ + q * SZ;
+            R.coff_ll = j + 1 < a.nlev ? q * SZ : R.coff;
+            if (j == 0) {
+                int x0 = 2 * q - WARM;
+                x0 = x0 < 0 ? x0 + g.OW : x0;
+                int x1 = x0 + 1;
+                x1 = x1 >= g.OW ? x1 - g.OW : x1;
+                R.ycol = (unsigned)x0 * SZ; R.ycol1 = x1 * SZ;
+                const int qs = (WARM - 1) / 2;               // the pair (2 qs, 2 qs + 1) lands on columns (OW - 1, 0) when WARM is odd
+                R.odd_wave = (WARM & 1) && c0 <= qs && qs < c0 + 64;
+                R.rot2 = 2 * sg.rho[0] - WARM;
+            } else {
+                const WlIRowsLevel& gl = a.g[j > 0 ? j - 1 : 0];
+                R.lhead = gl.head_off;
+                R.hcol0 = active && 2 * q < WARM ? (gl.Kw + 2 * q) * SZ : -1;
+                R.hcol1 = active && 2 * q + 1 < WARM ? (gl.Kw + 2 * q + 1) * SZ : -1;
+            }
+        }
         // window: the row-synthesised (a, b) of the previous HL-1 coefficient rows as (col n, col n+1) pairs, oldest first
         wl_v2 wa[NW], wb[NW];
 #pragma unroll
@@ -451,7 +603,8 @@ struct WlSfbRows {
 #if defined(__HIPCC__)
             __builtin_amdgcn_s_setprio(3);   // its few instructions go first: every other wave waits for it at the barrier
 #endif
-            loader(a, sg, ctx, plane, lane, arg >> 4, (arg >> 2) & 3, (arg & 3) + 1, soff);
+            if constexpr (PER != 0) loader_per(a, sg, ctx, plane, lane, arg >> 4, (arg >> 2) & 3, (arg & 3) + 1, soff);
+            else loader(a, sg, ctx, plane, lane, arg >> 4, (arg >> 2) & 3, (arg & 3) + 1, soff);
         }
         else if (lev == 0) compute<0>(a, sg, ctx, plane, arg, lane, soff);
         else if (lev == 1) compute<1>(a, sg, ctx, plane, arg, lane, soff);

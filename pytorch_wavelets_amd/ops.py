@@ -510,7 +510,10 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
     # db7 0.15 / 0.23, db9 0.14 / 0.23, bior4.4 0.15 / 0.27; up to 8 taps the two are level: haar 0.45 / 0.34, db2 0.28 / 0.27, db4 0.25 / 0.26)
     if es == 2 and L > IROWS_F16_MAXL and strips == 0:
         return None
-    if (yl.dtype == torch.float64 or nlev < 1 or nlev > 3 or g_h_lo.numel() != L or L % 2 or (L > 12 and not lattice) or mode == 2
+    per = mode == 2          # periodization (round 6): every level exactly twice the level above, all 2K outputs kept (the PER instantiations)
+    if per and not IROWS_PER:
+        return None
+    if (yl.dtype == torch.float64 or nlev < 1 or nlev > 3 or g_h_lo.numel() != L or L % 2 or (L > 12 and not lattice)
             or yl.numel() == 0 or (strips == 0 and 8 * N * C < 3 * _num_cus(yl.device)) or strips > 2
             or any(t is None or t.dim() != 5 or t.dtype != yl.dtype or t.shape[:3] != (N, C, 3) or t.numel() == 0
                    or (t.shape[4] * es) % 4 or (t.shape[3] * t.shape[4] * es) % 4 for t in yh)):
@@ -519,9 +522,9 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
     sh, sw = h, w
     for t in reversed(yh):
         kh, kw = t.shape[3], t.shape[4]
-        if not (kh <= sh <= kh + 1 and kw <= sw <= kw + 1) or kh < L // 2 or kw < L // 2:
+        if not (kh <= sh <= kh + 1 and kw <= sw <= kw + 1) or kh < L // 2 or kw < L // 2 or (per and (sh, sw) != (kh, kw)):
             return None
-        sh, sw = 2 * kh - L + 2, 2 * kw - L + 2
+        sh, sw = (2 * kh, 2 * kw) if per else (2 * kh - L + 2, 2 * kw - L + 2)
     # the kernel copies the coarsest low-pass like a band plane: dense rows of the coarsest high-pass width
     kh, kw = yh[-1].shape[3], yh[-1].shape[4]
     if (h, w) != (kh, kw):
@@ -573,6 +576,7 @@ IROWS_LATTICE_MIN = 8     # WL_IROWS_LAT_MIN of csrc/wl_idwt_rows.h: the fused s
 
 
 IROWS_F16_MAXL = 8      # longest filter the fused synthesis takes on float16 data under the engine's policy (99: A/B measurements)
+IROWS_PER = True        # round 6: periodization on the fused synthesis kernel (False: A/B measurements)
 ROWS_PER = True         # round 6: several periodization levels per fused analysis launch, and its odd-cell tap counts (L % 4 == 0) at all (False: A/B measurements)
 ROWS_3KIB = True        # float32 rows of 2-3 KiB on the fused analysis kernel (three 1 KiB pieces per row; False: A/B measurements)
 PAD_ODD_LL = True    # an inner-level ll of the strip kernel whose rows are no whole 16-byte pieces is written at a padded row pitch (A/B: False)

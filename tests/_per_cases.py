@@ -135,3 +135,82 @@ def check_inverse_backward_is_one_fused_analysis(dev, shape=(2, 2, 64, 128), wav
         assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0), (lhs, rhs)
     finally:
         ops.FUSED_STRIPS = prev
+
+
+# ---- round 6: the fused SYNTHESIS in periodization (csrc/wl_idwt_rows.h, PER = 1) ----------------------------------------------------------
+# (wave, H, W, J, dtype, strips)
+FUSED_IPER_CASES = [
+    ('haar', 64, 64, 3, torch.float32, 1),
+    ('db2', 96, 128, 3, torch.float32, 2),           # odd L/2 - 1: the roll splits one output pair between a row's last and first column
+    ('db3', 64, 96, 2, torch.float32, 1),
+    ('db4', 128, 256, 3, torch.float32, 1),
+    ('db4', 128, 256, 3, torch.float32, 2),          # both halves of a cut plane: rotated frames
+    ('db4', 80, 272, 2, torch.float32, 0),
+    ('db4', 72, 520, 1, torch.float32, 1),           # rows of more than one 1 KiB DMA piece + an 8-byte tail
+    ('db5', 96, 128, 3, torch.float32, 2),
+    ('db6', 96, 128, 3, torch.float32, 1),
+    ('db8', 128, 256, 3, torch.float32, 1),          # lattice variant
+    ('db9', 160, 160, 2, torch.float32, 2),
+    ('db10', 160, 160, 2, torch.float32, 1),
+    ('bior2.2', 64, 128, 3, torch.float32, 1),       # biorthogonal: the four-bank direct form
+    ('db4', 128, 256, 3, torch.float16, 2),
+    ('db8', 128, 512, 3, torch.float16, 1),
+]
+
+
+def check_fused_periodization_inverse(dev, wave, H, W, J, dtype, strips, planes=(2, 2), require_fused=True):
+    """DWTInverse in periodization on the fused synthesis kernel (all levels in ONE launch) against the oracle
+    (reference dwt/lowlevel.py:252-261 through oracle/wavelet_oracle.py) on random coefficients."""
+    from pytorch_wavelets_amd import ops
+    rng = np.random.RandomState(89)
+    prev = ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS, ops.LATTICE_MIN_ELEMS_ML, ops.IROWS_F16_MAXL
+    ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS, ops.LATTICE_MIN_ELEMS_ML, ops.IROWS_F16_MAXL = strips, 0, 0, 99
+    try:
+        ifm = pw.DWTInverse(wave=wave, mode='periodization').to(dev).to(dtype)
+        h, w, shp = H, W, []
+        for _ in range(J):
+            h, w = h // 2, w // 2
+            shp.append((h, w))
+        yl = torch.tensor(rng.randn(planes[0], planes[1], h, w), dtype=dtype, device=dev)
+        yh = [torch.tensor(rng.randn(planes[0], planes[1], 3, a, b), dtype=dtype, device=dev) for a, b in shp]
+        c0 = pw.launch_count()
+        y = ifm((yl, yh))
+        ks = [k for k in pw.kernels_since(c0) if not k.endswith(')')]
+        if require_fused:
+            assert len(ks) == 1 and ks[0].startswith('WlSfbRows<'), (wave, H, W, J, ks)
+        oy = wo.dwt_inverse(yl.detach().cpu().double().numpy(), [t.detach().cpu().double().numpy() for t in yh], _flat(ifm.g0_col), _flat(ifm.g1_col),
+                            _flat(ifm.g0_row), _flat(ifm.g1_row), 'periodization')
+        e = _rel(y, oy)
+        assert tuple(y.shape[-2:]) == (H, W) and e <= (1e-5 if dtype == torch.float32 else 4e-3), (wave, H, W, J, e, ks)
+        return e
+    finally:
+        ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS, ops.LATTICE_MIN_ELEMS_ML, ops.IROWS_F16_MAXL = prev
+
+
+def check_fused_periodization_inverse_corners(dev):
+    """Shapes the fused periodized synthesis must decline (the per-level kernels restate them) - an odd level (the module's 'unpad'), a level
+    shorter than the filter, None for a band - and the round trip x -> DWTForward -> DWTInverse -> x through both fused kernels."""
+    from pytorch_wavelets_amd import ops
+    rng = np.random.RandomState(97)
+    prev = ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS, ops.LATTICE_MIN_ELEMS_ML
+    ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS, ops.LATTICE_MIN_ELEMS_ML = 1, 0, 0
+    try:
+        for wave, H, W, J in (('db4', 70, 66, 3), ('db10', 64, 64, 3), ('db2', 36, 52, 2), ('db6', 96, 160, 3), ('db8', 128, 128, 2)):
+            x = torch.tensor(rng.randn(2, 2, H, W), dtype=torch.float32, device=dev)
+            xfm = pw.DWTForward(J=J, wave=wave, mode='periodization').to(dev)
+            ifm = pw.DWTInverse(wave=wave, mode='periodization').to(dev)
+            yl, yh = xfm(x)
+            y = ifm((yl, yh))
+            oy = wo.dwt_inverse(yl.cpu().double().numpy(), [t.cpu().double().numpy() for t in yh], _flat(ifm.g0_col), _flat(ifm.g1_col),
+                                _flat(ifm.g0_row), _flat(ifm.g1_row), 'periodization')
+            assert _rel(y, oy) <= 1e-5, (wave, H, W, J, _rel(y, oy))
+            if min(H, W) >> (J - 1) >= ifm.g0_col.numel():   # (a level shorter than the filter is no perfect-reconstruction pair in the reference either)
+                assert float((y[..., :H, :W] - x).abs().max()) <= 2e-5 * float(x.abs().max()), (wave, H, W, J)
+            yh2 = list(yh)
+            yh2[0] = None                      # a band the caller left out: zeros (dwt/transform2d.py:137-139)
+            y2 = ifm((yl, yh2))
+            oy2 = wo.dwt_inverse(yl.cpu().double().numpy(), [None if t is None else t.cpu().double().numpy() for t in yh2], _flat(ifm.g0_col),
+                                 _flat(ifm.g1_col), _flat(ifm.g0_row), _flat(ifm.g1_row), 'periodization')
+            assert _rel(y2, oy2) <= 1e-5, (wave, 'None band')
+    finally:
+        ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS, ops.LATTICE_MIN_ELEMS_ML = prev

@@ -1126,3 +1126,16 @@ def test_fused_periodization_corners_and_gradient():
         PC.check_periodization_gradient('cpu')
         PC.check_inverse_backward_is_one_fused_analysis('cpu')
         PC.check_inverse_backward_is_one_fused_analysis('cpu', shape=(1, 2, 64, 64), wave='db3', J=2)
+
+
+@pytest.mark.parametrize('wave,H,W,J,dtype,strips', __import__('_per_cases').FUSED_IPER_CASES)
+def test_fused_periodization_inverse(wave, H, W, J, dtype, strips):
+    import _per_cases as PC
+    with emu_backend.emulated():
+        PC.check_fused_periodization_inverse('cpu', wave, H, W, J, dtype, strips)
+
+
+def test_fused_periodization_inverse_corners():
+    import _per_cases as PC
+    with emu_backend.emulated():
+        PC.check_fused_periodization_inverse_corners('cpu')

@@ -960,3 +960,26 @@ def test_fused_periodization_corners_and_gradient():
     PC.check_fused_periodization_corners(DEV)
     PC.check_periodization_gradient(DEV, shape=(16, 8, 256, 256))
     PC.check_inverse_backward_is_one_fused_analysis(DEV, shape=(16, 8, 256, 256))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('wave,H,W,J,dtype,strips', __import__('_per_cases').FUSED_IPER_CASES)
+def test_fused_periodization_inverse(wave, H, W, J, dtype, strips):
+    import _per_cases as PC
+    PC.check_fused_periodization_inverse(DEV, wave, H, W, J, dtype, strips, planes=(5, 3), require_fused=strips != 0)
+
+
+@pytest.mark.gpu
+def test_fused_periodization_inverse_at_full_size():
+    """The shapes the policy takes by itself: 128x3x512^2 db4 J = 3 (whole planes + halves), db8 J = 2 (lattice), float16 db4."""
+    import _per_cases as PC
+    PC.check_fused_periodization_inverse(DEV, 'db4', 512, 512, 3, torch.float32, 0, planes=(128, 3))
+    PC.check_fused_periodization_inverse(DEV, 'db8', 512, 512, 2, torch.float32, 0, planes=(128, 3))
+    PC.check_fused_periodization_inverse(DEV, 'db4', 512, 512, 3, torch.float16, 0, planes=(64, 3))
+    PC.check_fused_periodization_inverse(DEV, 'db3', 256, 256, 3, torch.float32, 0, planes=(256, 3))
+
+
+@pytest.mark.gpu
+def test_fused_periodization_inverse_corners():
+    import _per_cases as PC
+    PC.check_fused_periodization_inverse_corners(DEV)
