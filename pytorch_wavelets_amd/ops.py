@@ -513,6 +513,15 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
     per = mode == 2          # periodization (round 6): every level exactly twice the level above, all 2K outputs kept (the PER instantiations)
     if per and not IROWS_PER:
         return None
+    if per and strips == 0 and nlev >= 1 and yh[0] is not None and yh[0].dim() == 5:
+        # The periodized loader brings the coefficients in ROW by row (rows that carry their wrapped cells), one LDS-DMA instruction per KiB or part
+        # of one: it pays where the finest level's rows fill those instructions and the planes fill the chip.  Same-process A/B against the per-level
+        # ladder (tools/gpu_r6_iper.py, profiles/r06g_*): 128x3x512^2 J=3 db4 0.230 -> 0.175 ms, db2 0.226 -> 0.164, 448^2 0.191 -> 0.143, 384^2 0.136 -> 0.118,
+        # 512x3x512^2 0.848 -> 0.700; behind it: 256-column planes (+20-31 %), 144 planes (+23 %), 16-20 taps (0 to +6 %), float16 from 6 taps on (db4 +52 %)
+        ow0 = 2 * yh[0].shape[4]
+        if (L > 12 or N * C < _num_cus(yl.device) or (es == 4 and ow0 < 320)
+                or (es == 2 and (L > 4 or not 384 <= ow0 <= 512))):
+            return None
     if (yl.dtype == torch.float64 or nlev < 1 or nlev > 3 or g_h_lo.numel() != L or L % 2 or (L > 12 and not lattice)
             or yl.numel() == 0 or (strips == 0 and 8 * N * C < 3 * _num_cus(yl.device)) or strips > 2
             or any(t is None or t.dim() != 5 or t.dtype != yl.dtype or t.shape[:3] != (N, C, 3) or t.numel() == 0

@@ -145,7 +145,7 @@ FUSED_IPER_CASES = [
     ('db3', 64, 96, 2, torch.float32, 1),
     ('db4', 128, 256, 3, torch.float32, 1),
     ('db4', 128, 256, 3, torch.float32, 2),          # both halves of a cut plane: rotated frames
-    ('db4', 80, 272, 2, torch.float32, 0),
+    ('db4', 80, 336, 2, torch.float32, 0),           # (the policy takes planes of 320 columns and more)
     ('db4', 72, 520, 1, torch.float32, 1),           # rows of more than one 1 KiB DMA piece + an 8-byte tail
     ('db5', 96, 128, 3, torch.float32, 2),
     ('db6', 96, 128, 3, torch.float32, 1),

@@ -975,8 +975,9 @@ def test_fused_periodization_inverse_at_full_size():
     import _per_cases as PC
     PC.check_fused_periodization_inverse(DEV, 'db4', 512, 512, 3, torch.float32, 0, planes=(128, 3))
     PC.check_fused_periodization_inverse(DEV, 'db8', 512, 512, 2, torch.float32, 0, planes=(128, 3))
-    PC.check_fused_periodization_inverse(DEV, 'db4', 512, 512, 3, torch.float16, 0, planes=(64, 3))
-    PC.check_fused_periodization_inverse(DEV, 'db3', 256, 256, 3, torch.float32, 0, planes=(256, 3))
+    PC.check_fused_periodization_inverse(DEV, 'db2', 512, 512, 3, torch.float16, 0, planes=(128, 3))
+    PC.check_fused_periodization_inverse(DEV, 'db4', 512, 512, 3, torch.float16, 0, planes=(128, 3), require_fused=False)   # (policy: per level)
+    PC.check_fused_periodization_inverse(DEV, 'db3', 384, 384, 3, torch.float32, 0, planes=(128, 3))
 
 
 @pytest.mark.gpu
