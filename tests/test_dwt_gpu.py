@@ -971,10 +971,11 @@ def test_fused_periodization_inverse(wave, H, W, J, dtype, strips):
 
 @pytest.mark.gpu
 def test_fused_periodization_inverse_at_full_size():
-    """The shapes the policy takes by itself: 128x3x512^2 db4 J = 3 (whole planes + halves), db8 J = 2 (lattice), float16 db4."""
+    """The shapes the policy takes by itself: 128x3x512^2 db4 J = 3 (whole planes + halves), db6 J = 2 (lattice), float16 db2, 384^2 - and two it leaves to the ladder."""
     import _per_cases as PC
     PC.check_fused_periodization_inverse(DEV, 'db4', 512, 512, 3, torch.float32, 0, planes=(128, 3))
-    PC.check_fused_periodization_inverse(DEV, 'db8', 512, 512, 2, torch.float32, 0, planes=(128, 3))
+    PC.check_fused_periodization_inverse(DEV, 'db6', 512, 512, 2, torch.float32, 0, planes=(128, 3))
+    PC.check_fused_periodization_inverse(DEV, 'db8', 512, 512, 2, torch.float32, 0, planes=(128, 3), require_fused=False)   # (policy: 16 taps per level)
     PC.check_fused_periodization_inverse(DEV, 'db2', 512, 512, 3, torch.float16, 0, planes=(128, 3))
     PC.check_fused_periodization_inverse(DEV, 'db4', 512, 512, 3, torch.float16, 0, planes=(128, 3), require_fused=False)   # (policy: per level)
     PC.check_fused_periodization_inverse(DEV, 'db3', 384, 384, 3, torch.float32, 0, planes=(128, 3))
