@@ -693,7 +693,7 @@ def other_configs(pw, dev, sync):
                                                   'fwd_kernels': names(lambda: slm(xm))}
         del xm
         # outside the fused streaming envelope of round 2: wider images, longer filters; round 6: periodization at the metric's shape
-        # (all levels in one launch of the fused analysis kernel; the inverse still one strip / tile launch per level)
+        # (all levels in one launch of the fused analysis / synthesis kernels)
         for tag, shape, wave, L, mode in (('dwt_j3_db4_16x3x1024x1024_fp32', (16, 3, 1024, 1024), 'db4', 8, 'symmetric'),
                                           ('dwt_j3_db4_64x3x1024x1024_fp32', (64, 3, 1024, 1024), 'db4', 8, 'symmetric'),
                                           ('dwt_j3_db8_128x3x512x512_fp32', (128, 3, 512, 512), 'db8', 16, 'symmetric'),

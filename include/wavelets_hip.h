@@ -108,7 +108,8 @@ int wl_dwt2d_synthesis(const void* ll, int64_t ll_plane_stride, int ll_row_strid
  * HBM traffic is the algorithmic minimum.  `yh` is a HOST array of nlev device pointers.  Same taps (even length
  * L <= 12; 14 - 20 in the lattice form, see `strips`) on both axes of every level, F32/F16 data, float taps; rows of 16-byte multiples of up to
  * 2 KiB (F32: 3 KiB) and ~630 outputs;
- * zero / symmetric / reflect for nlev > 1, any mode for nlev == 1.  `strips`: 0 = let the engine decide (it declines
+ * zero / symmetric / reflect and (library version 210) periodization for nlev > 1 - even sizes below level 1, every level at least as long
+ * as the filter -, any mode for nlev == 1.  `strips`: 0 = let the engine decide (it declines
  * below about 3/8 as many planes as compute units, where the tile kernels win; with fewer planes than compute units it
  * cuts planes in two so that every workgroup has a compute unit of its own), 1 = force this kernel, whole planes,
  * 2 = force, every plane cut in two; + 4 (bit 2) = a HINT that (h_h_lo, h_h_hi) hold the same taps as (h_w_lo, h_w_hi): the
@@ -149,7 +150,8 @@ int wl_dwt2d_analysis_fused_ex(const void* x, int64_t x_plane_stride, int x_row_
  * exactly as the reference does.  One workgroup streams one plane (or half of one) coarsest level first; the
  * intermediate low-passes stay in LDS rings, every coefficient is read from HBM once (LDS-DMA in whole 1024-byte
  * chunks of the contiguous band planes) and x is written once.  Same even tap count L <= 12 on both axes of every
- * level, F32/F16 data, float taps; zero / symmetric / reflect / periodic (not periodization); row bytes and plane
+ * level, F32/F16 data, float taps; zero / symmetric / reflect / periodic, and (library version 210) periodization - there y is (planes, 2*Kh[0], 2*Kw[0]), every level exactly
+ * twice the level above, yl the size of yh[nlev-1], at least L/2 coefficients per row and column (csrc/wl_idwt_rows.h, PER); row bytes and plane
  * bytes multiples of four.  `strips` (incl. the hint bits 2-3) as for wl_dwt2d_analysis_fused.  Returns WL_ERR_UNSUPPORTED
  * outside the kernel's envelope: the caller then uses wl_dwt2d_synthesis level by level. */
 int wl_dwt2d_synthesis_fused(const void* yl, int64_t yl_plane_stride, int yl_row_stride, int yl_h, int yl_w,
