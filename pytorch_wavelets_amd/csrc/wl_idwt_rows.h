@@ -57,6 +57,7 @@ struct WlIRowsLevel {
     // an LDS-fed low-pass ring row holds the level above's output in the order it was produced (z order: x column m = z column m + WARM),
     // WARM copies of its first cells behind it, and head_off = WARM more rows: copies of the ring's first WARM rows, which the last WARM feeds read
     int per_d0, head_off;
+    int per_grp;        // G: ring rows one DMA instruction fills (a power of two; G * rbytes <= 1024 - short rows, several to an instruction; 1: row by row)
 };
 
 struct WlIRowsSeg {
@@ -240,12 +241,37 @@ struct WlSfbRows {
                             : reinterpret_cast<const char*>(a.yh[j] + ((size_t)plane * 3 + (s - 1)) * ((size_t)g.Kh * g.Kw));
             dst[i] = g.src_off[s] + soff;
         }
-        const int max_rows = WL_IROWS_MAX_VM / per_row - 1;   // rows in flight at once
+        // Short rows: G ring rows per DMA instruction (an instruction costs the CU the same ~64 cycles whatever it moves: row by row, a 224-column
+        // plane issued three times the instructions of the flat images of the other modes).  The instruction covers the LDS bytes of G consecutive
+        // ring rows; a lane's 16 bytes lie in ring row lrg at data byte lo - or in a row's halo cells / pitch padding: that lane is off.
+        const int G = g.per_grp;
+        const int per_step = G > 1 ? ns : per_row;            // DMA instructions of one step (G rows of every source)
+        const int lrg = (16 * lane) / P, lo = 16 * lane - lrg * P - g.per_d0;
+        const bool lon = lrg < G && lo >= 0 && lo + 16 <= rowb;
+        const int fend_g = (fend + G - 1) & ~(G - 1);         // (the last group may reach past the segment's feeds: rows nobody reads)
+        const int max_rows = (WL_IROWS_MAX_VM / per_step - 1) * G;   // rows in flight at once
         int next = f0, landed = f0;                           // next row to issue / rows [f0, landed) known to have landed
         int fed = f0;
         auto try_issue = [&]() {
-            if (next >= fend || next - landed >= max_rows) return false;
-            if (next - R >= fed - 2) return false;            // the ring row it overwrites: consumed, and not in the half-batch that is running now
+            if (next >= fend_g || next - landed >= max_rows) return false;
+            if (next + G - 1 - R >= fed - 2) return false;    // the ring rows it overwrites: consumed, and not in the half-batch that is running now
+            if (G > 1) {
+                int sr = next + lrg - WARM + rho;             // this lane's coefficient row, wrapped into the plane
+                sr = sr < 0 ? sr + Kh : sr;
+                sr = sr >= Kh ? sr - Kh : sr;
+                sr = sr >= Kh ? sr - Kh : sr;
+                const unsigned gro = (unsigned)sr * (unsigned)rowb + (unsigned)lo;
+                const unsigned slot = (unsigned)((next & (R - 1)) * P);
+                if (!(WL_IROWS_ABLATE & 2)) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (i >= ns) break;
+                        wl_dma16_s(ctx, (unsigned)dst[i] + slot, src[i], gro, lon);
+                    }
+                }
+                next += G;
+                return true;
+            }
             int sr = next - WARM + rho;                       // the coefficient row of feed `next`, wrapped into the plane
             sr = sr < 0 ? sr + Kh : sr;
             sr = sr >= Kh ? sr - Kh : sr;
@@ -271,9 +297,9 @@ struct WlSfbRows {
             const int n = (int)(word >> (8 * (hb & 3) + 2 * j)) & 3;
             if ((hb & 3) == 3) word = sg.sched[(hb >> 2) + 1 < WL_IROWS_MAXHB / 4 ? (hb >> 2) + 1 : 0];
             if (n) {   // rows fed .. fed+n-1 have landed; their wrapped cells: copies of the row's last WARM coefficients
-                const int nd = fed + n;
+                const int nd = (fed + n + G - 1) & ~(G - 1);   // (whole groups)
                 if (next < nd) wl_fail();   // the launcher's geometry checks rule this out
-                if (!(WL_IROWS_ABLATE & 2)) wl_wait_vm_dyn((next - nd) * per_row);
+                if (!(WL_IROWS_ABLATE & 2)) wl_wait_vm_dyn(G > 1 ? ((next - nd) / G) * per_step : (next - nd) * per_step);
                 landed = nd;
                 if (WARM > 0) {
                     for (int it = lane; it < n * ns * WARM; it += 64) {

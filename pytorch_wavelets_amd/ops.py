@@ -513,7 +513,7 @@ def sfb2d_fused(yl, yh, g_w_lo, g_w_hi, g_h_lo, g_h_hi, mode, strips=None):
     per = mode == 2          # periodization (round 6): every level exactly twice the level above, all 2K outputs kept (the PER instantiations)
     if per and not IROWS_PER:
         return None
-    if per and strips == 0 and nlev >= 1 and yh[0] is not None and yh[0].dim() == 5:
+    if per and strips == 0 and IROWS_PER_POLICY and nlev >= 1 and yh[0] is not None and yh[0].dim() == 5:
         # The periodized loader brings the coefficients in ROW by row (rows that carry their wrapped cells), one LDS-DMA instruction per KiB or part
         # of one: it pays where the finest level's rows fill those instructions and the planes fill the chip.  Same-process A/B against the per-level
         # ladder (tools/gpu_r6_iper.py, profiles/r06g_*): 128x3x512^2 J=3 db4 0.230 -> 0.175 ms, db2 0.226 -> 0.164, 448^2 0.191 -> 0.143, 384^2 0.136 -> 0.118,
@@ -585,6 +585,7 @@ IROWS_LATTICE_MIN = 8     # WL_IROWS_LAT_MIN of csrc/wl_idwt_rows.h: the fused s
 
 
 IROWS_F16_MAXL = 8      # longest filter the fused synthesis takes on float16 data under the engine's policy (99: A/B measurements)
+IROWS_PER_POLICY = True # (False: A/B measurements - the fused periodized synthesis whatever the shape)
 IROWS_PER = True        # round 6: periodization on the fused synthesis kernel (False: A/B measurements)
 ROWS_PER = True         # round 6: several periodization levels per fused analysis launch, and its odd-cell tap counts (L % 4 == 0) at all (False: A/B measurements)
 ROWS_3KIB = True        # float32 rows of 2-3 KiB on the fused analysis kernel (three 1 KiB pieces per row; False: A/B measurements)

@@ -16,6 +16,10 @@ CASES = [((128, 3, 512, 512), 'db4', 3, torch.float32), ((128, 3, 512, 512), 'db
          ((128, 3, 512, 512), 'db4', 3, torch.float16), ((128, 3, 512, 512), 'haar', 3, torch.float16), ((128, 3, 512, 512), 'db2', 3, torch.float16),
          ((256, 3, 256, 256), 'db4', 3, torch.float32), ((128, 3, 224, 224), 'db4', 3, torch.float32), ((512, 3, 128, 128), 'db4', 2, torch.float32),
          ((128, 3, 640, 640), 'db4', 3, torch.float32), ((64, 3, 1024, 1024), 'db4', 3, torch.float32), ((32, 16, 2048, 2048), 'db8', 4, torch.float16)]
+if len(sys.argv) > 1 and sys.argv[1] == 'narrow':
+    ops_policy_off = True
+    CASES = [((n, 3, w, w), wv, J, torch.float32) for (n, w) in ((128, 224), (256, 224), (128, 256), (256, 256), (512, 128), (1024, 112), (128, 320), (128, 288), (512, 64)) for wv, J in (('db4', 3), ('db2', 2), ('haar', 1), ('db4', 1))]
+    CASES += [((48, 3, 512, 512), 'db4', 3, torch.float32), ((64, 3, 512, 512), 'db4', 3, torch.float32), ((96, 3, 384, 384), 'db4', 3, torch.float32)]
 if len(sys.argv) > 1 and sys.argv[1] == 'widths':
     CASES = [((128, 3, w, w), wv, J, dt) for w in (256, 320, 384, 448, 576, 768) for wv, J, dt in (('db4', 3, torch.float32), ('db2', 2, torch.float32), ('haar', 3, torch.float16), ('db2', 3, torch.float16))]
     CASES += [((128, 3, 512, 512), 'db7', 3, torch.float32), ((128, 3, 512, 512), 'db3', 3, torch.float16), ((48, 3, 512, 512), 'db4', 3, torch.float32), ((512, 3, 512, 512), 'db4', 3, torch.float32)]
@@ -30,6 +34,7 @@ for shape, wave, J, dt in CASES:
         c = f(x)
     for flag in (False, True):
         ops.IROWS_PER = flag
+        ops.IROWS_PER_POLICY = not (len(sys.argv) > 1 and sys.argv[1] == 'narrow')
         ops._FUSED_DECLINED.clear()
         with torch.no_grad():
             i(c)
