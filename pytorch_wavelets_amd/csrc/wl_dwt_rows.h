@@ -90,6 +90,7 @@ struct WlRowsLevel {
     int pad;            // byte offset of sample 0 inside a ring row (multiple of 16)
     int hl, hr;         // halo cells left / right of the samples (boundary extension along W)
     int nwaves;         // 64-column chunks of this level (each chunk is one compute wave)
+    unsigned ring_magic;  // NP2 instantiations: floor(2^32 / ring_rows) - row r sits in slot r mod ring_rows, any ring_rows (wl_ring_slot)
     int ring_rows;      // levels >= 2: rows of this level's SOURCE ring (power of two, row r in r & (ring_rows - 1)); round 6: per level -
                         // the smallest the level's own schedule does not overrun (one size for all rings put 16-tap symmetric pyramids of
                         // three levels over the 80 KiB of two workgroups per CU)
@@ -186,7 +187,16 @@ struct WlRowsSched {
 // samples start on an ODD cell of the ring row.  The lane then reads L/2 + 1 aligned (even, odd) pairs from one cell earlier and
 // meets tap t with the OTHER half of a pair (even taps the .y of pair t/2, odd taps the .x of pair (t+1)/2): the same L packed
 // FMAs, one more 8-byte LDS read per row, no unaligned access.  The unused first and last cells are halo cells like the others.
-template <typename T, int LT, int PPR, int D = WL_ROWS_DEPTH, int SAME = 0, int LAT = 0, int ODD = 0>
+// NP2 = 1 (round 6): the LL rings have EXACTLY the rows the simulated schedule needs, not the next power of two - a symmetric / reflect pyramid
+// needs L - 1 resident rows per ring for the mirrored rows above the plane plus what the producer runs ahead: 18-24 rows where the power of two is
+// 32, and three levels of a 12- to 16-tap filter on 512 columns are 83-97 KiB with 32-row rings (two workgroups per CU: 80).  The slot of a row is
+// r mod rows by a multiply-high (two scalar instructions more per row than the mask): instantiated for the long filters only.
+WL_HD int wl_ring_slot(int r, int rows, unsigned magic) {
+    const unsigned q = (unsigned)(((unsigned long long)(unsigned)r * magic) >> 32);     // floor(r / rows) or one less
+    const int sl = r - (int)q * rows;
+    return sl >= rows ? sl - rows : sl;
+}
+template <typename T, int LT, int PPR, int D = WL_ROWS_DEPTH, int SAME = 0, int LAT = 0, int ODD = 0, int NP2 = 0>
 struct WlAfbRows {
     typedef WlRowsArgs<T> Args;
     static_assert(!LAT || SAME, "the lattice variant holds one bank");
@@ -288,6 +298,7 @@ struct WlAfbRows {
         char* hp0; char* hp1; char* hp2; char* llp;   // band planes of this (plane, level); LL plane of the last level
         unsigned rowb, llrowb, kb;
         int nring, npitch, rmask;
+        unsigned nmagic;                   // NP2: rmask holds the ROWS of the ring this level writes, nmagic its magic
         bool last, halo;
     };
 
@@ -416,7 +427,7 @@ struct WlAfbRows {
         if (LAST) {
             if (st) *reinterpret_cast<T*>(R.llp + ((unsigned)orow * R.llrowb + R.kb)) = (T)cl.x;
         } else {
-            char* nrow = smem + (R.nring + (orow & R.rmask) * R.npitch);
+            char* nrow = smem + (R.nring + (NP2 ? wl_uniform(wl_ring_slot(orow, R.rmask, R.nmagic)) : (orow & R.rmask)) * R.npitch);
             *reinterpret_cast<T*>(nrow + L.ndst) = (T)cl.x;
             if (HALO) {   // only waves that own a boundary column of the next level
                 if (L.hx0 >= 0) *reinterpret_cast<T*>(nrow + L.hx0) = (T)cl.x;
@@ -501,7 +512,8 @@ struct WlAfbRows {
         R.rowb = (unsigned)g.Kw * SZ; R.llrowb = (unsigned)a.ll_rs * SZ; R.kb = (unsigned)k * SZ;
         const WlRowsLevel& gn = a.g[j + 1 < WL_ROWS_MAXLEV ? j + 1 : j];
         R.nring = gn.ring_off; R.npitch = gn.ring_pitch;
-        R.rmask = gn.ring_rows - 1;                       // (the ring this level WRITES: the next level's source ring)
+        R.rmask = NP2 ? gn.ring_rows : gn.ring_rows - 1;  // (the ring this level WRITES: the next level's source ring)
+        R.nmagic = gn.ring_magic;
         Lane L;
 #pragma unroll
         for (int t = 0; t < (LAT ? (KL > 1 ? KL - 1 : 1) : LT); ++t) L.win[t] = wl_v2{0.f, 0.f};
@@ -529,7 +541,7 @@ struct WlAfbRows {
                                  bool active, int k) {
         const WlRowsLevel& g = a.g[j];
         char* const smem = ctx.smem;
-        const int rmask = g.ring_rows - 1, zrow = a.zero_off, ring = g.ring_off, pitch = g.ring_pitch, Hs = g.Hs;   // (the ring this level READS)
+        const int rmask = NP2 ? g.ring_rows : g.ring_rows - 1, zrow = a.zero_off, ring = g.ring_off, pitch = g.ring_pitch, Hs = g.Hs;   // (the ring this level READS)
         const bool zmode = a.ext == WL_EXT_ZERO, per = a.ext == WL_EXT_PER;
         // LDS byte offsets (wave-uniform) of the two source rows of feed f = (2f+base, 2f+base+1); i = its index in
         // the half-batch hb
@@ -547,8 +559,8 @@ struct WlAfbRows {
                 // periodic output, the wrapped ones twice): the ring is addressed by the unfolded row number, negative ones included
                 int s0 = e, s1 = e + 1;
                 if (!per && (e < 0 || e + 1 >= Hs)) { s0 = wl_ext1(e, Hs, a.ext); s1 = wl_ext1(e + 1, Hs, a.ext); }   // top / bottom rows only
-                r0 = zmode && s0 < 0 ? zrow : ring + (s0 & rmask) * pitch;
-                r1 = zmode && s1 < 0 ? zrow : ring + (s1 & rmask) * pitch;
+                r0 = zmode && s0 < 0 ? zrow : ring + (NP2 ? wl_ring_slot(s0, rmask, g.ring_magic) : (s0 & rmask)) * pitch;
+                r1 = zmode && s1 < 0 ? zrow : ring + (NP2 ? wl_ring_slot(s1, rmask, g.ring_magic) : (s1 & rmask)) * pitch;
             }
             r0 = wl_uniform(r0); r1 = wl_uniform(r1);
         };

@@ -501,3 +501,31 @@ def check_tap_state_contract(dev):
         ks = call()
         assert not any(k.startswith('WlTapPrep') for k in ks), (wave, ks)          # examined once (or never needed)
         assert max(_rel(ll, oyl), _rel(hs, oyh[0])) <= 1e-5, wave
+
+
+# ---- round 6: LL rings sized exactly (WlAfbRows<.., NP2 = 1>): three levels of a long filter on 512 columns in symmetric / reflect mode ---------
+NP2_CASES = [('db8', 'symmetric'), ('db7', 'reflect'), ('db6', 'symmetric'), ('sym8', 'reflect'), ('db10', 'zero')]
+
+
+def check_rows_exact_rings(dev, wave, mode, shape=(1, 2, 200, 512), dtype=torch.float32, planes_cut=False, require_np2=True):
+    """DWTForward J = 3 of a 12- to 20-tap orthogonal wavelet on 512-column planes: with power-of-two LL rings the three levels do not fit the
+    80 KiB of two workgroups per CU and the launcher takes the instantiation whose rings have exactly the rows the simulated schedule needs
+    (slot = row mod rows).  ONE launch does the work; against the oracle."""
+    from pytorch_wavelets_amd import ops
+    rng = np.random.RandomState(101)
+    prev = ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS
+    ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS = (2 if planes_cut else 1), 0
+    try:
+        x = torch.tensor(rng.randn(*shape), device=dev).to(dtype)
+        xfm = pw.DWTForward(J=3, wave=wave, mode=mode).to(dev).to(dtype)
+        c0 = pw.launch_count()
+        yl, yh = xfm(x)
+        prim = [k for k in pw.kernels_since(c0) if not k.endswith(')')]
+        args = [a.strip() for a in prim[0][prim[0].index('<') + 1:prim[0].rindex('>')].split(',')] if prim else []
+        assert len(prim) == 1 and prim[0].startswith('WlAfbRows<') and (not require_np2 or (len(args) == 8 and args[7] == '1')), prim   # <T, L, PPR, D, SAME, LAT, ODD, NP2>
+        oyl, oyh = wo.dwt_forward(x.detach().cpu().double().numpy(), 3, _flat(xfm.h0_col), _flat(xfm.h1_col), _flat(xfm.h0_row), _flat(xfm.h1_row), mode)
+        e = max([_rel(yl, oyl)] + [_rel(a, b) for a, b in zip(yh, oyh)])
+        assert e <= (1e-5 if dtype == torch.float32 else 4e-3), (wave, mode, e)
+        return e
+    finally:
+        ops.FUSED_STRIPS, ops.LATTICE_MIN_ELEMS = prev

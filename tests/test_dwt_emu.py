@@ -1140,3 +1140,11 @@ def test_fused_periodization_inverse_corners():
     import _per_cases as PC
     with emu_backend.emulated():
         PC.check_fused_periodization_inverse_corners('cpu')
+
+
+@pytest.mark.parametrize('wave,mode', __import__('_lattice_cases').NP2_CASES)
+def test_fused_analysis_with_exactly_sized_rings(wave, mode):
+    import _lattice_cases as LC
+    with emu_backend.emulated():
+        LC.check_rows_exact_rings('cpu', wave, mode)
+        LC.check_rows_exact_rings('cpu', wave, mode, shape=(1, 1, 264, 512), planes_cut=True)
