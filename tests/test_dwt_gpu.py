@@ -993,4 +993,4 @@ def test_fused_analysis_with_exactly_sized_rings(wave, mode):
     import _lattice_cases as LC
     LC.check_rows_exact_rings(DEV, wave, mode, shape=(4, 3, 512, 512))
     LC.check_rows_exact_rings(DEV, wave, mode, shape=(4, 3, 512, 512), planes_cut=True)
-    LC.check_rows_exact_rings(DEV, wave, mode, shape=(2, 3, 300, 1024), dtype=torch.float16, require_np2=False)   # (float16 rows of 2 KiB: whichever ring form fits)
+    LC.check_rows_exact_rings(DEV, wave, mode, shape=(2, 3, 300, 512), dtype=torch.float16, require_np2=False)   # (float16 rows of 1 KiB: the power-of-two rings fit)
