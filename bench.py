@@ -20,6 +20,10 @@ import subprocess
 import sys
 import time
 
+# multi-process GPU work on this pool needs dmabuf IPC (the host driver supports nothing else: without it RCCL's rendezvous fails with
+# hipIpcGetMemHandle: invalid argument); already exported on the pool's boxes, kept for any environment that launches this file
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
