@@ -45,12 +45,21 @@ struct WlIdwt1dFused {
     // (n is even and dst 8-byte aligned: two samples per lane and load - element-aligned 8-byte loads - while both exist)
     typedef T Pair2 __attribute__((ext_vector_type(2), aligned(sizeof(T)), may_alias));
     static WL_DEV void load_range(float* dst, const T* src, int base, int n, int len, int tid) {
-        for (int i = 2 * tid; i < n; i += 2 * kThreads) {
+        // (round 6: four samples per lane and load - element-aligned 16-byte loads, 16-byte LDS writes - while all four exist; the
+        // buffers are 16-byte aligned and padded to whole 16-byte groups by the launcher)
+        typedef T Quad4 __attribute__((ext_vector_type(4), aligned(sizeof(T)), may_alias));
+        for (int i = 4 * tid; i < n; i += 4 * kThreads) {
             const int k = base + i;
-            wl_f2 v; v.x = v.y = 0.f;
-            if (src && k + 1 < len) { const Pair2 t = *reinterpret_cast<const Pair2*>(src + k); v.x = (float)t.x; v.y = (float)t.y; }
-            else if (src && k < len) v.x = (float)src[k];
-            *reinterpret_cast<wl_f2*>(dst + i) = v;
+            wl_vf4 v; v.x = v.y = v.z = v.w = 0.f;
+            if (src && k + 3 < len) {
+                const Quad4 t = *reinterpret_cast<const Quad4*>(src + k);
+                v.x = (float)t.x; v.y = (float)t.y; v.z = (float)t.z; v.w = (float)t.w;
+            } else if (src) {
+                if (k < len) v.x = (float)src[k];
+                if (k + 1 < len) v.y = (float)src[k + 1];
+                if (k + 2 < len) v.z = (float)src[k + 2];
+            }
+            *reinterpret_cast<wl_vf4*>(dst + i) = v;
         }
     }
     static WL_DEV void run(const Args& a, const WlCtx& ctx) {
@@ -85,6 +94,34 @@ struct WlIdwt1dFused {
             float* nxt = j > 0 ? reinterpret_cast<float*>(ctx.smem + a.lo_off[j - 1]) : nullptr;
             const int lim = j > 0 ? a.n_hi[j - 1] : a.out_len;   // outputs from here on are dropped ('unpad' / crop)
             T* const yp = a.y + (size_t)row * a.out_len;
+            if (!nxt) {
+                // level 1 -> y: TWO output pairs per lane, one element-aligned 16-byte store (round 6: half the store instructions)
+                typedef T Quad4 __attribute__((ext_vector_type(4), aligned(sizeof(T)), may_alias));
+                for (int q = 2 * tid; q < npairs; q += 2 * kThreads) {
+                    wl_v2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, b0 = {0.f, 0.f}, b1 = {0.f, 0.f};
+                    float sl = lb[q], sh = hb[q];
+#pragma unroll
+                    for (int i = 0; i < HL; ++i) {
+                        const float nl = lb[q + i + 1], nh = hb[q + i + 1];   // (one group of padding behind every buffer: readable)
+                        wl_pk_fma_x(a0, p0[i], wl_v2{sl, 0.f}); wl_pk_fma_x(a1, p1[i], wl_v2{sh, 0.f});
+                        wl_pk_fma_x(b0, p0[i], wl_v2{nl, 0.f}); wl_pk_fma_x(b1, p1[i], wl_v2{nh, 0.f});
+                        sl = nl; sh = nh;
+                    }
+                    const float v0 = a0.x + a1.x, v1 = a0.y + a1.y, v2 = b0.x + b1.x, v3 = b0.y + b1.y;
+                    const int p = obase + 2 * q;
+                    if (q + 1 < npairs && p + 3 < lim) {
+                        Quad4 t; t.x = (T)v0; t.y = (T)v1; t.z = (T)v2; t.w = (T)v3;
+                        *reinterpret_cast<Quad4*>(yp + p) = t;
+                    } else {
+                        if (p < lim) yp[p] = (T)v0;
+                        if (p + 1 < lim) yp[p + 1] = (T)v1;
+                        if (q + 1 < npairs && p + 2 < lim) yp[p + 2] = (T)v2;
+                        if (q + 1 < npairs && p + 3 < lim) yp[p + 3] = (T)v3;
+                    }
+                }
+                ctx.sync();
+                continue;
+            }
             for (int q = tid; q < npairs; q += kThreads) {
                 wl_v2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
 #pragma unroll
