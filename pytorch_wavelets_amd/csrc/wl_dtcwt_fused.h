@@ -103,9 +103,13 @@ struct WlDtFwd12Strip {
     // (MODE 3, the training forward, keeps 19 output streams' addresses and values live: at the 80 registers of six waves per
     // SIMD it spilled 88 bytes per lane and ran 0.354 ms at config 4's shape; at 128 registers (four waves, two workgroups per
     // CU) nothing spills: 0.235 ms.  The inference kernel fits 78 registers and is faster at six.)
-    static const int kMinWaves = MODE == 3 ? 4 : (kScat ? WL_DT12_MINW1 : (SW == 2 && MODE == 2 ? 5 : 6));
     static const int SZ = (int)sizeof(T);
     static const int M0 = L0 / 2, M1 = L1 / 2, M = kL2 ? 0 : (M0 > M1 ? M0 : M1);   // (MODE 4: no level-1 filters)
+    // (the 13 / 19-tap pair of near_sym_b: two windows of 20 rows are 80 registers - room for 128, two workgroups of 8 waves per
+    // CU - and a lane reads a row's samples when it filters it, not the four rows of a half-batch up front)
+    static const bool kLong = M > 4;
+    static const int kMinWaves = kLong ? 2 : (MODE == 3 ? 4 : (kScat ? WL_DT12_MINW1 : (SW == 2 && MODE == 2 ? 5 : 6)));
+    static const bool kRowLoads = WL_DT12_ROWLOADS || kLong;
     static const int LW = (2 * M + 1 + 3) / 4 * 4;
     static const int PERIOD = LW / 4;
     static const int NS = 2 + 2 * M;
@@ -267,8 +271,8 @@ struct WlDtFwd12Strip {
     }
     struct Taps1 {
         wl_v2 tr[2 * M + 1];               // row-filter tap pairs (h0[t], h1[t]), both centred in 2M+1 slots (zeros outside)
-        wl_v2 c0[(L0 + 1) / 2];            // column taps, two to a pair: (h0[2u], h0[2u+1])
-        wl_v2 c1[(L1 + 1) / 2];
+        wl_v2 c0[kLong ? 1 : (L0 + 1) / 2];   // column taps, two to a pair: (h0[2u], h0[2u+1])
+        wl_v2 c1[kLong ? 1 : (L1 + 1) / 2];   // (kLong: 36 pairs overflow the scalar file - the column filters read the halves of tr)
     };
     // row filter pair of column COL of the quad: samples COL .. COL + 2M of the lane's NS -> (lo, hi)
     template <int COL> static WL_DEV wl_v2 row_filter(const Taps1& R, const wl_v2 (&s)[NC2]) {
@@ -284,6 +288,13 @@ struct WlDtFwd12Strip {
     // column filters of the row whose window is centred on slot `c`: aL = (ll, hl), aH = (lh, hh)
     static WL_DEV void col_filter(const Taps1& R, const wl_v2 (&w)[LW], int c, wl_v2& aL, wl_v2& aH) {
         aL = wl_v2{0.f, 0.f}; aH = wl_v2{0.f, 0.f};
+        if (kLong) {
+#pragma unroll
+            for (int t = 0; t < L0; ++t) fma_cc<0>(aL, w[(c + LW - M0 + t) % LW], R.tr[M - M0 + t]);
+#pragma unroll
+            for (int t = 0; t < L1; ++t) fma_cc<1>(aH, w[(c + LW - M1 + t) % LW], R.tr[M - M1 + t]);
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < L0; ++t) {
             if (t & 1) fma_cc<1>(aL, w[(c + LW - M0 + t) % LW], R.c0[t / 2]); else fma_cc<0>(aL, w[(c + LW - M0 + t) % LW], R.c0[t / 2]);
@@ -297,6 +308,11 @@ struct WlDtFwd12Strip {
     // the (ll, hl) column filter of an LL1 row above / below the plane (MODE 2; see the header): the window read backwards
     static WL_DEV void col_filter_rev(const Taps1& R, const wl_v2 (&w)[LW], int c, wl_v2& aL) {
         aL = wl_v2{0.f, 0.f};
+        if (kLong) {
+#pragma unroll
+            for (int t = 0; t < L0; ++t) fma_cc<0>(aL, w[(c + LW + M0 - t) % LW], R.tr[M - M0 + t]);
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < L0; ++t) {
             if (t & 1) fma_cc<1>(aL, w[(c + LW + M0 - t) % LW], R.c0[t / 2]); else fma_cc<0>(aL, w[(c + LW + M0 - t) % LW], R.c0[t / 2]);
@@ -325,9 +341,9 @@ struct WlDtFwd12Strip {
             R.tr[t] = wl_uniform_v2(wl_v2{v0, v1});
         }
 #pragma unroll
-        for (int u = 0; u < (L0 + 1) / 2; ++u) R.c0[u] = wl_uniform_v2(wl_v2{(float)f.h0[2 * u], 2 * u + 1 < L0 ? (float)f.h0[2 * u + 1 < L0 ? 2 * u + 1 : 0] : 0.f});
+        for (int u = 0; u < (kLong ? 0 : (L0 + 1) / 2); ++u) R.c0[u] = wl_uniform_v2(wl_v2{(float)f.h0[2 * u], 2 * u + 1 < L0 ? (float)f.h0[2 * u + 1 < L0 ? 2 * u + 1 : 0] : 0.f});
 #pragma unroll
-        for (int u = 0; u < (L1 + 1) / 2; ++u) R.c1[u] = wl_uniform_v2(wl_v2{(float)f.h1[2 * u], 2 * u + 1 < L1 ? (float)f.h1[2 * u + 1 < L1 ? 2 * u + 1 : 0] : 0.f});
+        for (int u = 0; u < (kLong ? 0 : (L1 + 1) / 2); ++u) R.c1[u] = wl_uniform_v2(wl_v2{(float)f.h1[2 * u], 2 * u + 1 < L1 ? (float)f.h1[2 * u + 1 < L1 ? 2 * u + 1 : 0] : 0.f});
         const int soff = 16 + 8 * (active ? q - s.qa : 0) + (PP > 1 ? sub * (a.st_pitch / PP) : 0);
         // LL1 ring: cell 0 = pixel column 2 q0 - HQ.  At the plane's edges the mirrored copies go out with the pixel pair.
         const int Q = f.W / 2;
@@ -366,35 +382,31 @@ struct WlDtFwd12Strip {
                 if (!active || hb >= s.nhb1 || (WL_DT12_ABLATE & 8)) continue;
                 const char* slot = smem + a.st_off + (hb & 1) * 4 * a.st_pitch + soff;
                 char* l1slot = smem + a.l1_off + (hb & 1) * 4 * a.l1_pitch;
-#if !WL_DT12_ROWLOADS
-                wl_v2 sr[4][NC2];
+                wl_v2 sr[kRowLoads ? 1 : 4][NC2];
+                if (!kRowLoads) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < (kRowLoads ? 0 : 4); ++i)
 #pragma unroll
-                    for (int u = 0; u < NC2; ++u) {
-                        const wl_f2 t = *reinterpret_cast<const wl_f2*>(slot + i * a.st_pitch + 8 * u);
-                        sr[i][u] = wl_v2{t.x, t.y};
-                    }
-#endif
+                        for (int u = 0; u < NC2; ++u) {
+                            const wl_f2 t = *reinterpret_cast<const wl_f2*>(slot + i * a.st_pitch + 8 * u);
+                            sr[i][u] = wl_v2{t.x, t.y};
+                        }
+                }
                 const int o0 = s.o_base + 4 * hb;              // LL1 rows o0 .. o0 + 3 are completed in this half-batch
                 const bool outp = MODE == 2 && (o0 < 0 || o0 >= f.H);   // all four above / below the plane (o0, H: multiples of 4)
                 wl_v2 pL[2], pH[2];                            // the quad's upper row: (ll, hl), (lh, hh) of its two columns
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int w = (4 * ph + i) % LW;           // slot of the new input row e = o + M
-#if WL_DT12_ROWLOADS
-                    wl_v2 sri[NC2];
+                    if (kRowLoads) {
 #pragma unroll
-                    for (int u = 0; u < NC2; ++u) {
-                        const wl_f2 t = *reinterpret_cast<const wl_f2*>(slot + i * a.st_pitch + 8 * u);
-                        sri[u] = wl_v2{t.x, t.y};
+                        for (int u = 0; u < NC2; ++u) {
+                            const wl_f2 t = *reinterpret_cast<const wl_f2*>(slot + i * a.st_pitch + 8 * u);
+                            sr[0][u] = wl_v2{t.x, t.y};
+                        }
                     }
-                    wa[w] = row_filter<0>(R, sri);
-                    wb[w] = row_filter<1>(R, sri);
-#else
-                    wa[w] = row_filter<0>(R, sr[i]);
-                    wb[w] = row_filter<1>(R, sr[i]);
-#endif
+                    wa[w] = row_filter<0>(R, sr[kRowLoads ? 0 : i]);
+                    wb[w] = row_filter<1>(R, sr[kRowLoads ? 0 : i]);
                     wl_v2 aL, aH, bL, bH;
                     if (outp) {                                // (wave-uniform; such rows own no band-pass output)
                         col_filter_rev(R, wa, (w + LW - M) % LW, aL);

@@ -306,9 +306,9 @@ struct WlDtInv1Strip {
     static const int CW = 4;                           // compute waves: up to 256 quad columns per strip
     static const int kWaves = CW + 4;
     static const int kThreads = 64 * kWaves;
-    static const int kMinWaves = 4;
     static const int SZ = (int)sizeof(T);
     static const int M0 = L0 / 2, M1 = L1 / 2, M = M0 > M1 ? M0 : M1, ME = (M + 1) & ~1;
+    static const int kMinWaves = M > 4 ? 2 : 4;        // (13 / 19 taps: 127 registers when the allocator is given room, 6 spilled at a bound of 128 - two workgroups per CU either way)
     static const int LW = 2 * M + 2;                   // window slots (even): rotation by the 2 rows of a half-batch
     static const int PERIOD = LW / 2;
 #ifndef WL_DTI1_PF
@@ -468,14 +468,58 @@ struct WlDtInv1Strip {
         }
     }
 
+    // The 13 / 19-tap pair (near_sym_b): 51 duplicated tap pairs do not fit the scalar file (129 spilled scalars, a v_readlane
+    // per tap).  Its row filter reads the column filter's pairs instead: the packed FMA takes the pair's low / high half for
+    // both of its lanes (op_sel) - 19 pairs in all, the same products in the same order.
+    static const bool PAIRS = M > 4;
     struct Wave {
-        wl_v2 r0[L0], r1[L1];      // row-filter taps, duplicated: (g0[t], g0[t]) meets (ll, lh), (g1[t], g1[t]) meets (hl, hh)
+        wl_v2 r0[PAIRS ? 1 : L0], r1[PAIRS ? 1 : L1];   // row-filter taps, duplicated: (g0[t], g0[t]) meets (ll, lh), (g1[t], g1[t]) meets (hl, hh)
         wl_v2 cc[2 * M + 1];       // column-filter tap pairs (g0[t], g1[t]), both centred in 2M+1 slots
     };
+    // acc (+)= w * (c, c), c = the low / high half of a scalar tap pair
+    template <int HI> static WL_DEV void fma_half(wl_v2& acc, wl_v2 w, wl_v2 pair) {
+#if defined(__HIPCC__)
+        if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "s"(pair));
+        else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w), "s"(pair));
+#else
+        const float c = HI ? pair.y : pair.x;
+        acc.x = __builtin_fmaf(w.x, c, acc.x); acc.y = __builtin_fmaf(w.y, c, acc.y);
+#endif
+    }
+    template <int HI> static WL_DEV wl_v2 mul_half(wl_v2 w, wl_v2 pair) {
+#if defined(__HIPCC__)
+        wl_v2 r;
+        if (HI) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(w), "s"(pair));
+        else asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(w), "s"(pair));
+        return r;
+#else
+        const float c = HI ? pair.y : pair.x;
+        return wl_v2{w.x * c, w.y * c};
+#endif
+    }
     // (A, B) of both output columns of the quad from the lane's pixels px[0..NPX): (x, y) = (ll, lh), (z, w) = (hl, hh).
     // Four accumulator chains, interleaved: on gfx950 a packed FMA that reads the result of one of the two instructions
     // before it costs a wait state (the compiler pads with s_nop, which takes an issue slot like any instruction).
     static WL_DEV void row_filter2(const Wave& R, const wl_vf4 (&px)[NPX], wl_v2& ra, wl_v2& rb) {
+        if (PAIRS) {
+            wl_v2 a0 = mul_half<0>(wl_v2{px[M - M0].x, px[M - M0].y}, R.cc[M - M0]);
+            wl_v2 b0 = mul_half<0>(wl_v2{px[1 + M - M0].x, px[1 + M - M0].y}, R.cc[M - M0]);
+            wl_v2 a1 = mul_half<1>(wl_v2{px[M - M1].z, px[M - M1].w}, R.cc[M - M1]);
+            wl_v2 b1 = mul_half<1>(wl_v2{px[1 + M - M1].z, px[1 + M - M1].w}, R.cc[M - M1]);
+#pragma unroll
+            for (int t = 1; t < (L0 > L1 ? L0 : L1); ++t) {
+                if (t < L0) {
+                    fma_half<0>(a0, wl_v2{px[M - M0 + t].x, px[M - M0 + t].y}, R.cc[M - M0 + (t < L0 ? t : 0)]);
+                    fma_half<0>(b0, wl_v2{px[1 + M - M0 + t].x, px[1 + M - M0 + t].y}, R.cc[M - M0 + (t < L0 ? t : 0)]);
+                }
+                if (t < L1) {
+                    fma_half<1>(a1, wl_v2{px[M - M1 + t].z, px[M - M1 + t].w}, R.cc[M - M1 + (t < L1 ? t : 0)]);
+                    fma_half<1>(b1, wl_v2{px[1 + M - M1 + t].z, px[1 + M - M1 + t].w}, R.cc[M - M1 + (t < L1 ? t : 0)]);
+                }
+            }
+            ra = a0 + a1; rb = b0 + b1;
+            return;
+        }
         wl_v2 a0 = wl_pk_mul_vs(wl_v2{px[M - M0].x, px[M - M0].y}, R.r0[0]);
         wl_v2 b0 = wl_pk_mul_vs(wl_v2{px[1 + M - M0].x, px[1 + M - M0].y}, R.r0[0]);
         wl_v2 a1 = wl_pk_mul_vs(wl_v2{px[M - M1].z, px[M - M1].w}, R.r1[0]);
@@ -515,9 +559,9 @@ struct WlDtInv1Strip {
         const bool active = q < s.q1 && plane < f.NC;
         Wave R;
 #pragma unroll
-        for (int t = 0; t < L0; ++t) R.r0[t] = wl_uniform_v2(wl_v2{(float)f.g0[t], (float)f.g0[t]});
+        for (int t = 0; t < (PAIRS ? 0 : L0); ++t) R.r0[t] = wl_uniform_v2(wl_v2{(float)f.g0[t], (float)f.g0[t]});
 #pragma unroll
-        for (int t = 0; t < L1; ++t) R.r1[t] = wl_uniform_v2(wl_v2{(float)f.g1[t], (float)f.g1[t]});
+        for (int t = 0; t < (PAIRS ? 0 : L1); ++t) R.r1[t] = wl_uniform_v2(wl_v2{(float)f.g1[t], (float)f.g1[t]});
 #pragma unroll
         for (int t = 0; t < 2 * M + 1; ++t) {
             const int t0 = t - (M - M0), t1 = t - (M - M1);

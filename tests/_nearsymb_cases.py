@@ -1,0 +1,114 @@
+"""The 13 / 19-tap level-1 pair (`near_sym_b`) on the streaming level-1 kernels - the lean forward `WlDtFwd12Strip<T, 13, 19, ..>`
+(MODE 0 / 1 / 3) and the streaming inverse `WlDtInv1Strip<T, 19, 13>` (and `<T, 13, 19>` as the forward's backward, `SCAT = 1` as
+ScatLayer's) - against the ORACLE (reference dtcwt/transform2d.py:87-147, 193-254; scatternet/lowlevel.py:71-137).  Run by the
+emulator (CPU) and the GPU test modules."""
+import numpy as np
+import torch
+
+import pytorch_wavelets_amd as pw
+from oracle import wavelet_oracle as wo
+from pytorch_wavelets_amd import filters as F
+
+
+def _args(k):
+    return [a.strip() for a in k[k.index('<') + 1:k.rindex('>')].split(',')]
+
+
+def _has(ks, name, *taps):
+    return any((name + '<') in k and _args(k)[1:1 + len(taps)] == [str(t) for t in taps] for k in ks)
+
+
+def _npy(t):
+    return t.detach().cpu().double().numpy()
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max()) / float(np.abs(b).max())
+
+
+def check_dtcwt_near_sym_b(dev, shape, dtype, J=1, qshift='qshift_b', tol=1e-5, expect_stream=True):
+    """DTCWTForward / DTCWTInverse / the forward's gradient with `near_sym_b`: the kernels named, every output against the oracle."""
+    rng = np.random.RandomState(7)
+    x = rng.randn(*shape)
+    if dtype == torch.float16:
+        x = np.float16(x).astype(np.float64)
+    fw = F.dtcwt_forward_taps('near_sym_b', qshift)
+    iv = F.dtcwt_inverse_taps('near_sym_b', qshift)
+    assert len(fw[0]) == 13 and len(fw[1]) == 19 and len(iv[0]) == 19 and len(iv[1]) == 13
+    want_l, want_h = wo.dtcwt_forward(x, J, *fw)
+    xfm = pw.DTCWTForward(J=J, biort='near_sym_b', qshift=qshift).to(dev).to(dtype)
+    ifm = pw.DTCWTInverse(biort='near_sym_b', qshift=qshift).to(dev).to(dtype)
+    xt = torch.tensor(x, dtype=dtype, device=dev).requires_grad_(dtype != torch.float16)
+    c0 = pw.launch_count()
+    yl, yh = xfm(xt)
+    kf = pw.kernels_since(c0)
+    t = 4e-3 if dtype == torch.float16 else tol
+    assert _rel(_npy(yl), want_l) <= t, (shape, kf)
+    for a, b in zip(yh, want_h):
+        assert a.shape == b.shape and _rel(_npy(a), b) <= t, (shape, kf)
+    # inverse of perturbed coefficients (not a round trip: the bands carry independent data)
+    cl = want_l + 0.1 * rng.randn(*want_l.shape)
+    ch = [h + 0.1 * rng.randn(*h.shape) for h in want_h]
+    if dtype == torch.float16:
+        cl, ch = np.float16(cl).astype(np.float64), [np.float16(h).astype(np.float64) for h in ch]
+    want_y = wo.dtcwt_inverse(cl, ch, *iv)
+    c0 = pw.launch_count()
+    y = ifm((torch.tensor(cl, dtype=dtype, device=dev), [torch.tensor(h, dtype=dtype, device=dev) for h in ch]))
+    ki = pw.kernels_since(c0)
+    assert y.shape == want_y.shape and _rel(_npy(y), want_y) <= (1e-2 if dtype == torch.float16 else tol), (shape, ki)
+    kb = []
+    if dtype != torch.float16:
+        # the gradient is the adjoint: <dx, v> = <cotangent, forward(v)> for any v (the oracle's forward, float64)
+        cot_l = rng.randn(*want_l.shape)
+        cot_h = [rng.randn(*h.shape) for h in want_h]
+        c0 = pw.launch_count()
+        dx, = torch.autograd.grad((yl * torch.tensor(cot_l, dtype=dtype, device=dev)).sum()
+                                  + sum((a * torch.tensor(b, dtype=dtype, device=dev)).sum() for a, b in zip(yh, cot_h)), xt)
+        kb = pw.kernels_since(c0)
+        dxn = _npy(dx)
+        for _ in range(3):
+            v = rng.randn(*shape)
+            vl, vh = wo.dtcwt_forward(v, J, *fw)
+            rhs = float((cot_l * vl).sum() + sum((a * b).sum() for a, b in zip(cot_h, vh)))
+            lhs = float((dxn * v).sum())
+            scale = float(np.sqrt((dxn ** 2).sum() * (v ** 2).sum()))
+            assert abs(lhs - rhs) <= 2e-5 * scale, (shape, lhs, rhs, kb)
+    if expect_stream:
+        assert _has(kf, 'WlDtFwd12Strip', 13, 19), kf
+        assert _has(ki, 'WlDtInv1Strip', 19, 13), ki
+        if kb:
+            assert _has(kb, 'WlDtInv1Strip', 13, 19), kb
+    return kf, ki, kb, dxn if dtype != torch.float16 else None
+
+
+def check_scat_near_sym_b(dev, shape, dtype, tol=1e-5, expect_stream=True):
+    """ScatLayer(biort='near_sym_b'): inference and training forward, and the backward, against the oracle."""
+    rng = np.random.RandomState(11)
+    x = rng.randn(*shape)
+    if dtype == torch.float16:
+        x = np.float16(x).astype(np.float64)
+    h0o, h1o = F.dtcwt_forward_taps('near_sym_b', 'qshift_a')[:2]
+    Z, saved = wo.scat_layer_forward(x, h0o, h1o, return_saved=True)
+    dZ = rng.randn(*Z.shape)
+    want = wo.scat_layer_backward(dZ, saved, h0o, h1o)
+    sl = pw.ScatLayer(biort='near_sym_b').to(dev).to(dtype)
+    t = 1e-2 if dtype == torch.float16 else tol
+    with torch.no_grad():
+        c0 = pw.launch_count()
+        z0 = sl(torch.tensor(x, dtype=dtype, device=dev))
+        k0 = pw.kernels_since(c0)
+    assert _rel(_npy(z0), Z) <= t, (shape, k0)
+    xg = torch.tensor(x, dtype=dtype, device=dev).requires_grad_(True)
+    c0 = pw.launch_count()
+    z = sl(xg)
+    k1 = pw.kernels_since(c0)
+    assert _rel(_npy(z), Z) <= t, (shape, k1)
+    c0 = pw.launch_count()
+    g, = torch.autograd.grad(z, xg, torch.tensor(dZ, dtype=dtype, device=dev))
+    kb = pw.kernels_since(c0)
+    assert g.shape == want.shape and _rel(_npy(g), want) <= t, (shape, kb)
+    if expect_stream:
+        assert any('WlDtFwd12Strip<' in k and _args(k)[1:3] == ['13', '19'] and _args(k)[4] == '1' for k in k0), k0
+        assert any('WlDtFwd12Strip<' in k and _args(k)[1:3] == ['13', '19'] and _args(k)[4] == '3' for k in k1), k1
+        assert any('WlDtInv1Strip<' in k and _args(k)[1:4] == ['13', '19', '1'] for k in kb), kb
+    return k0, k1, kb

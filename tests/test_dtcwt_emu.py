@@ -608,3 +608,37 @@ def test_random_dtcwt_on_chips_of_several_sizes(block):
             return float(np.abs(a.double().numpy() - b).max() / max(np.abs(b).max(), 1e-30))
         es = [rel(yl, oyl), rel(rec, orec)] + [rel(a, np.stack([b.real, b.imag], -1) if np.iscomplexobj(b) else b) for a, b in zip(yh, oyh)]
         assert max(es) < 1e-5, (seed, biort, qshift, cus, planes, H, W, J, max(es))
+
+
+@pytest.mark.parametrize('shape,dtype,J,qshift', [((1, 2, 40, 256), torch.float32, 1, 'qshift_b'),     # two planes per workgroup
+                                                  ((1, 2, 44, 512), torch.float32, 1, 'qshift_b'),     # one wide strip
+                                                  ((1, 1, 72, 1024), torch.float32, 1, 'qshift_b'),    # two strips, mirrored edges in different strips
+                                                  ((2, 2, 64, 128), torch.float32, 1, 'qshift_b'),     # narrow planes (forward: pairs; inverse: four)
+                                                  ((1, 3, 132, 264), torch.float32, 1, 'qshift_b'),    # rows: several segments on the 2-CU chip
+                                                  ((1, 2, 64, 256), torch.float32, 3, 'qshift_b'),     # a pyramid: 14-tap levels below
+                                                  ((1, 2, 40, 512), torch.float16, 1, 'qshift_b')])
+def test_near_sym_b_on_the_streaming_level1_kernels(shape, dtype, J, qshift):
+    """Round 6: the 13 / 19-tap pair on the lean level-1 forward and the streaming level-1 inverse (tap pairs shared between the
+    row and the column filters by op_sel, windows of 20 rows) against the oracle; and elementwise against the tile kernels."""
+    import _nearsymb_cases as NB
+    from pytorch_wavelets_amd import ops
+    with emu_backend.emulated():
+        kf, ki, kb, dx = NB.check_dtcwt_near_sym_b('cpu', shape, dtype, J=J, qshift=qshift)
+        if dx is not None:
+            try:
+                ops.set_option('no_stream', 1)
+                _, _, kb2, dx2 = NB.check_dtcwt_near_sym_b('cpu', shape, dtype, J=J, qshift=qshift, expect_stream=False)
+            finally:
+                ops.set_option('no_stream', 0)
+            assert not any('Strip' in k for k in kb2), kb2
+            assert float(np.abs(dx - dx2).max()) <= 3e-6 * float(np.abs(dx2).max())
+
+
+@pytest.mark.parametrize('shape,dtype', [((2, 3, 40, 256), torch.float32), ((1, 2, 44, 512), torch.float32), ((1, 2, 64, 1024), torch.float32),
+                                         ((2, 2, 40, 128), torch.float32), ((1, 2, 40, 512), torch.float16)])
+def test_near_sym_b_scatlayer_on_the_streaming_kernels(shape, dtype):
+    """ScatLayer(biort='near_sym_b'): inference (MODE 1) and training forward (MODE 3) on the lean kernel, the backward on the
+    streaming inverse with the scattering prologue - against the oracle."""
+    import _nearsymb_cases as NB
+    with emu_backend.emulated():
+        NB.check_scat_near_sym_b('cpu', shape, dtype)

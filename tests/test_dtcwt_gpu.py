@@ -515,3 +515,20 @@ def test_streaming_kernels_on_narrow_and_half_precision_planes_equal_the_tile_ke
     for u, v in zip(out[0], out[1]):
         assert u.shape == v.shape
         assert float((u.float() - v.float()).abs().max()) <= tol * float(v.float().abs().max())
+
+
+@pytest.mark.parametrize('shape,dtype,J', [((12, 3, 512, 512), torch.float32, 1), ((12, 3, 512, 512), torch.float32, 3), ((6, 3, 1024, 1024), torch.float32, 2),
+                                           ((22, 3, 256, 256), torch.float32, 2), ((43, 3, 128, 128), torch.float32, 1), ((32, 3, 200, 328), torch.float32, 1),
+                                           ((12, 3, 512, 512), torch.float16, 2)])
+def test_near_sym_b_on_the_streaming_level1_kernels(shape, dtype, J):
+    """Round 6: DTCWT with `near_sym_b / qshift_b` (13 / 19 and 14 taps) - the level-1 pair on the lean forward kernel and the
+    streaming inverse - forward, inverse and the forward's gradient against the oracle at the shapes of the benchmarks."""
+    import _nearsymb_cases as NB
+    NB.check_dtcwt_near_sym_b(DEV, shape, dtype, J=J)
+
+
+@pytest.mark.parametrize('shape,dtype', [((22, 3, 256, 256), torch.float32), ((12, 3, 512, 512), torch.float32), ((6, 3, 1024, 1024), torch.float32),
+                                         ((12, 3, 512, 512), torch.float16)])
+def test_near_sym_b_scatlayer_on_the_streaming_kernels(shape, dtype):
+    import _nearsymb_cases as NB
+    NB.check_scat_near_sym_b(DEV, shape, dtype)
