@@ -372,11 +372,13 @@ def test_scatlayerj2_in_place_equals_the_chain(shape, dtype, expect):
 
 
 @pytest.mark.parametrize('shape,qshift,dtype', [((2, 1, 64, 256), 'qshift_a', torch.float32), ((1, 2, 72, 1024), 'qshift_a', torch.float32),
-                                                ((2, 1, 64, 256), 'qshift_b', torch.float32), ((2, 2, 64, 512), 'qshift_a', torch.float16)])
+                                                ((2, 1, 64, 256), 'qshift_b', torch.float32), ((2, 2, 64, 512), 'qshift_a', torch.float16),
+                                                ((2, 1, 64, 256), 'qshift_d', torch.float32), ((1, 2, 72, 1024), 'qshift_d', torch.float32),
+                                                ((2, 2, 64, 512), 'qshift_d', torch.float16)])
 def test_streaming_level2_inverse_equals_tile_kernel(shape, qshift, dtype):
     """The streaming level-2 inverse over column strips (wl_dtcwt_fused.h WlDtInv2Strip: one input quad per stager lane, row
     interpolation from 32-byte cells, column interpolation from register windows) against the tile kernel: flipped quad rows
-    at the top / bottom, mirrored quad columns, several strips and segments, 10 and 14 taps, float16; and as the backward of
+    at the top / bottom, mirrored quad columns, several strips and segments, 10, 14 and 18 taps, float16; and as the backward of
     the level-2 forward."""
     torch.manual_seed(0)
     x = torch.randn(*shape, dtype=dtype)
@@ -409,7 +411,7 @@ def test_streaming_level2_inverse_equals_tile_kernel(shape, qshift, dtype):
         assert float((u.float() - v.float()).abs().max()) <= tol * float(v.float().abs().max())
 
 
-@pytest.mark.parametrize('qshift,taps', [('qshift_a', 10), ('qshift_b', 14)])
+@pytest.mark.parametrize('qshift,taps', [('qshift_a', 10), ('qshift_b', 14), ('qshift_d', 18)])
 @pytest.mark.parametrize('shape,dtype', [((2, 1, 64, 256), torch.float32), ((1, 2, 72, 1024), torch.float32), ((2, 1, 32, 520), torch.float32),
                                          ((2, 2, 64, 512), torch.float16)])
 def test_streaming_level2_forward_equals_tile_kernel(shape, dtype, qshift, taps):
@@ -616,6 +618,8 @@ def test_random_dtcwt_on_chips_of_several_sizes(block):
                                                   ((2, 2, 64, 128), torch.float32, 1, 'qshift_b'),     # narrow planes (forward: pairs; inverse: four)
                                                   ((1, 3, 132, 264), torch.float32, 1, 'qshift_b'),    # rows: several segments on the 2-CU chip
                                                   ((1, 2, 64, 256), torch.float32, 3, 'qshift_b'),     # a pyramid: 14-tap levels below
+                                                  ((1, 2, 64, 256), torch.float32, 3, 'qshift_d'),     # 18-tap levels below
+                                                  ((1, 2, 96, 512), torch.float32, 2, 'qshift_d'),
                                                   ((1, 2, 40, 512), torch.float16, 1, 'qshift_b')])
 def test_near_sym_b_on_the_streaming_level1_kernels(shape, dtype, J, qshift):
     """Round 6: the 13 / 19-tap pair on the lean level-1 forward and the streaming level-1 inverse (tap pairs shared between the

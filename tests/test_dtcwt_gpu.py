@@ -274,7 +274,9 @@ def test_lean_scatlayer_kernel(shape, dtype, grad):
 
 
 @pytest.mark.parametrize('shape,qshift,dtype', [((64, 3, 512, 512), 'qshift_a', torch.float32), ((20, 3, 264, 1024), 'qshift_a', torch.float32),
-                                                ((128, 1, 256, 256), 'qshift_b', torch.float32), ((160, 1, 128, 512), 'qshift_a', torch.float16)])
+                                                ((128, 1, 256, 256), 'qshift_b', torch.float32), ((160, 1, 128, 512), 'qshift_a', torch.float16),
+                                                ((64, 3, 512, 512), 'qshift_d', torch.float32), ((128, 1, 256, 256), 'qshift_d', torch.float32),
+                                                ((20, 3, 264, 1024), 'qshift_d', torch.float32), ((160, 1, 128, 512), 'qshift_d', torch.float16)])
 def test_streaming_level2_inverse(shape, qshift, dtype):
     """The streaming level-2 inverse over column strips (WlDtInv2Strip) against the tile kernel (wl_set_option no_stream)
     on every plane, the whole inverse against the oracle on sampled planes, and as the backward of the level-2 forward."""
@@ -532,3 +534,14 @@ def test_near_sym_b_on_the_streaming_level1_kernels(shape, dtype, J):
 def test_near_sym_b_scatlayer_on_the_streaming_kernels(shape, dtype):
     import _nearsymb_cases as NB
     NB.check_scat_near_sym_b(DEV, shape, dtype)
+
+
+@pytest.mark.parametrize('shape,dtype,J,qshift', [((12, 3, 512, 512), torch.float32, 3, 'qshift_d'), ((22, 3, 256, 256), torch.float32, 2, 'qshift_d'),
+                                                  ((6, 3, 1024, 1024), torch.float32, 3, 'qshift_d'), ((12, 3, 512, 512), torch.float16, 2, 'qshift_d')])
+def test_qshift_d_on_the_streaming_level2_kernels(shape, dtype, J, qshift):
+    """Round 6: the 18-tap q-shift filters on the lean level >= 2 forward (WlDtFwd12Strip<.., 18, 4>) and the streaming level >= 2
+    inverse (WlDtInv2Strip<T, 18>): near_sym_b / qshift_d pyramids against the oracle."""
+    import _nearsymb_cases as NB
+    kf, ki, kb, _ = NB.check_dtcwt_near_sym_b(DEV, shape, dtype, J=J, qshift=qshift)
+    assert any('WlDtFwd12Strip<' in k and NB._args(k)[3:5] == ['18', '4'] for k in kf), kf
+    assert any('WlDtInv2Strip<' in k and NB._args(k)[1] == '18' for k in ki), ki
