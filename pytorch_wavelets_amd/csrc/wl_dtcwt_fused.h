@@ -66,6 +66,7 @@ struct WlDtFusedArgs {
     int l1_off, l1_pitch;          // LL1 ring: 2 slots x 4 rows x l1_pitch bytes
     int w2_off;                    // level-2 windows: LQ rows x 256 lanes x 16 bytes
     int lds_bytes;
+    const float* h2; int L2;       // MODE 6: the band-pass filter of the diagonal sub-band ('near_sym_b_bp'), L2 <= 2 M + 1 taps
 };
 
 // MODE 2: levels 1 + 2 (above).  The same stagers and level-1 lanes without the level-2 waves are the lean level-1 kernels:
@@ -76,6 +77,9 @@ struct WlDtFusedArgs {
 // MODE 4: fwd_j2plus alone - the stagers put the rows of the level's input (and their mirrored cells: exact, no symmetry
 // assumed) straight into the ring the level-2 lanes read; no level-1 waves.  MODE 5: MODE 4 with ScatLayerj2's epilogue (the
 // 2x2-averaged lowpass and the smoothed magnitudes instead of LL2 and the band-pass coefficients).
+// MODE 6 (round 6): MODE 1 for the rotationally symmetric filters ('near_sym_b_bp': ScatLayerj1_rot_f.forward, scatternet/lowlevel.py:
+// 140-182; fwd_j1_rot, dtcwt/transform_funcs.py:124-149) - a third row filter ba = R_h2 x (both columns of the quad in ONE packed FMA per
+// tap: (ba0, ba1) += (h2[t], h2[t - 1]) x[t], the tap pairs in vector registers), a third window, hh = C_h2 ba instead of C_h1 hi.
 // PP = 2 (lean level-1 kernels, planes of up to 256 columns): a workgroup owns TWO consecutive planes - level-1 waves 0, 1 the
 // first, 2, 3 the second, every stager wave its row of both (the staged rows lie side by side) - so that all four level-1
 // waves of the wide-plane kernel work (with one 256-column plane per workgroup of two level-1 waves + two stagers ScatLayer
@@ -86,6 +90,7 @@ struct WlDtFwd12Strip {
     typedef WlDtFusedArgs<T> Args;
     static const bool kL2 = MODE == 4 || MODE == 5;    // fwd_j2plus alone (5: with ScatLayerj2's epilogue)
     static_assert(PP == 1 || ((PP == 2 || PP == 4) && CW_ == 4 && MODE != 2 && MODE != 4 && MODE != 5), "several planes per workgroup: lean level-1 kernels only");
+    static const bool kRot = MODE == 6;
 #ifndef WL_DT12_SW
 #define WL_DT12_SW 4
 #endif
@@ -99,7 +104,7 @@ struct WlDtFwd12Strip {
 #define WL_DT12_MINW1 6
 #endif
     // two workgroups of 10 (12) waves per CU, or three of 8: at most 96 (80) registers
-    static const bool kScat = MODE == 1 || MODE == 3;
+    static const bool kScat = MODE == 1 || MODE == 3 || MODE == 6;
     // (MODE 3, the training forward, keeps 19 output streams' addresses and values live: at the 80 registers of six waves per
     // SIMD it spilled 88 bytes per lane and ran 0.354 ms at config 4's shape; at 128 registers (four waves, two workgroups per
     // CU) nothing spills: 0.235 ms.  The inference kernel fits 78 registers and is faster at six.)
@@ -273,7 +278,32 @@ struct WlDtFwd12Strip {
         wl_v2 tr[2 * M + 1];               // row-filter tap pairs (h0[t], h1[t]), both centred in 2M+1 slots (zeros outside)
         wl_v2 c0[kLong ? 1 : (L0 + 1) / 2];   // column taps, two to a pair: (h0[2u], h0[2u+1])
         wl_v2 c1[kLong ? 1 : (L1 + 1) / 2];   // (kLong: 36 pairs overflow the scalar file - the column filters read the halves of tr)
+        wl_v2 t2[kRot ? 2 * M + 2 : 1];       // MODE 6: (h2c[t], h2c[t - 1]) of the centred, zero-padded band-pass filter - vector registers
     };
+    // MODE 6: ba = R_h2 x of both columns of the quad: (ba0, ba1) += (h2c[t], h2c[t - 1]) * x[t], t = 0 .. 2 M + 1 (two chains)
+    static WL_DEV wl_v2 row_filter_ba(const Taps1& R, const wl_v2 (&s)[NC2]) {
+        wl_v2 a0 = wl_v2{0.f, 0.f}, a1 = wl_v2{0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2 * M + 2; ++t) {
+            wl_v2& acc = (t & 2) ? a1 : a0;
+            if (t & 1) wl_pk_fma_y_v(acc, R.t2[t], s[t / 2]); else wl_pk_fma_x_v(acc, R.t2[t], s[t / 2]);
+        }
+        return a0 + a1;
+    }
+    // ... and hh = C_h2 ba of the row whose window is centred on slot `c`, both columns
+    static WL_DEV wl_v2 col_filter_ba(const Taps1& R, const wl_v2 (&w)[LW], int c) {
+        wl_v2 a0 = wl_v2{0.f, 0.f}, a1 = wl_v2{0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2 * M + 1; ++t) {
+            wl_v2& acc = (t & 1) ? a1 : a0;
+#if defined(__HIPCC__)
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w[(c + LW - M + t) % LW]), "v"(R.t2[t]));
+#else
+            acc.x = __builtin_fmaf(w[(c + LW - M + t) % LW].x, R.t2[t].x, acc.x); acc.y = __builtin_fmaf(w[(c + LW - M + t) % LW].y, R.t2[t].x, acc.y);
+#endif
+        }
+        return a0 + a1;
+    }
     // row filter pair of column COL of the quad: samples COL .. COL + 2M of the lane's NS -> (lo, hi)
     template <int COL> static WL_DEV wl_v2 row_filter(const Taps1& R, const wl_v2 (&s)[NC2]) {
         wl_v2 a0 = (COL & 1) ? wl_pk_mul_y(R.tr[0], s[0]) : wl_pk_mul_x(R.tr[0], s[0]);
@@ -344,6 +374,20 @@ struct WlDtFwd12Strip {
         for (int u = 0; u < (kLong ? 0 : (L0 + 1) / 2); ++u) R.c0[u] = wl_uniform_v2(wl_v2{(float)f.h0[2 * u], 2 * u + 1 < L0 ? (float)f.h0[2 * u + 1 < L0 ? 2 * u + 1 : 0] : 0.f});
 #pragma unroll
         for (int u = 0; u < (kLong ? 0 : (L1 + 1) / 2); ++u) R.c1[u] = wl_uniform_v2(wl_v2{(float)f.h1[2 * u], 2 * u + 1 < L1 ? (float)f.h1[2 * u + 1 < L1 ? 2 * u + 1 : 0] : 0.f});
+        if (kRot) {
+            const int off2 = M - a.L2 / 2;
+#pragma unroll
+            for (int t = 0; t < 2 * M + 2; ++t) {
+                const int u0 = t - off2, u1 = t - 1 - off2;
+                wl_v2 p;
+                p.x = (t <= 2 * M && u0 >= 0 && u0 < a.L2) ? a.h2[u0 >= 0 && u0 < a.L2 ? u0 : 0] : 0.f;
+                p.y = (t >= 1 && u1 >= 0 && u1 < a.L2) ? a.h2[u1 >= 0 && u1 < a.L2 ? u1 : 0] : 0.f;
+#if defined(__HIPCC__)
+                asm volatile("" : "+v"(p));                    // (per-lane copies: 39 tap pairs do not fit the scalar file)
+#endif
+                R.t2[t] = p;
+            }
+        }
         const int soff = 16 + 8 * (active ? q - s.qa : 0) + (PP > 1 ? sub * (a.st_pitch / PP) : 0);
         // LL1 ring: cell 0 = pixel column 2 q0 - HQ.  At the plane's edges the mirrored copies go out with the pixel pair.
         const int Q = f.W / 2;
@@ -367,9 +411,11 @@ struct WlDtFwd12Strip {
         const size_t zmag = (size_t)f.z_mag_off * SZ;
         const long zll = (long)f.z_ll_off * SZ;                                 // (negative: no lowpass entry)
         const size_t dbase = ((size_t)n_img * 6 * f.C + c_img) * ((size_t)(f.H / 2) * Q) * SZ;
-        wl_v2 wa[LW], wb[LW];
+        wl_v2 wa[LW], wb[LW], wc[kRot ? LW : 1];               // (MODE 6: wc = (ba of column 2q, ba of column 2q + 1))
 #pragma unroll
         for (int t = 0; t < LW; ++t) wa[t] = wb[t] = wl_v2{0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < (kRot ? LW : 1); ++t) wc[t] = wl_v2{0.f, 0.f};
         char* const smem = ctx.smem;
         unsigned long long tbar = 0;
         const unsigned long long tstart = WL_DT12_TICK();
@@ -395,6 +441,7 @@ struct WlDtFwd12Strip {
                 const int o0 = s.o_base + 4 * hb;              // LL1 rows o0 .. o0 + 3 are completed in this half-batch
                 const bool outp = MODE == 2 && (o0 < 0 || o0 >= f.H);   // all four above / below the plane (o0, H: multiples of 4)
                 wl_v2 pL[2], pH[2];                            // the quad's upper row: (ll, hl), (lh, hh) of its two columns
+                wl_v2 pC = wl_v2{0.f, 0.f};                    // (MODE 6: its hh = C_h2 ba, both columns)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int w = (4 * ph + i) % LW;           // slot of the new input row e = o + M
@@ -407,6 +454,7 @@ struct WlDtFwd12Strip {
                     }
                     wa[w] = row_filter<0>(R, sr[kRowLoads ? 0 : i]);
                     wb[w] = row_filter<1>(R, sr[kRowLoads ? 0 : i]);
+                    if constexpr (kRot) wc[w] = row_filter_ba(R, sr[kRowLoads ? 0 : i]);
                     wl_v2 aL, aH, bL, bH;
                     if (outp) {                                // (wave-uniform; such rows own no band-pass output)
                         col_filter_rev(R, wa, (w + LW - M) % LW, aL);
@@ -430,13 +478,15 @@ struct WlDtFwd12Strip {
                         Pair z; z.a = (T)aL.x; z.b = (T)bL.x;
                         *reinterpret_cast<Pair*>(lbase + (size_t)((unsigned)o * (unsigned)f.W * SZ) + 2 * voff1) = z;
                     }
-                    if (!(i & 1)) { pL[0] = aL; pL[1] = bL; pH[0] = aH; pH[1] = bH; continue; }
+                    wl_v2 cH = wl_v2{0.f, 0.f};
+                    if constexpr (kRot) cH = col_filter_ba(R, wc, (w + LW - M) % LW);
+                    if (!(i & 1)) { pL[0] = aL; pL[1] = bL; pH[0] = aH; pH[1] = bH; pC = cH; continue; }
                     // the quad (rows o - 1, o; columns 2q, 2q + 1) is complete: q2c of lh, hh, hl (reference
                     // transform_funcs.py:61-72: p = (upper left, upper right, lower left, lower right))
                     if (!own || (WL_DT12_ABLATE & 2)) continue;
                     const float k = (float)WL_SQRT1_2;
                     const float lh0 = pH[0].x, lh1 = pH[1].x, lh2 = aH.x, lh3 = bH.x;
-                    const float hh0 = pH[0].y, hh1 = pH[1].y, hh2 = aH.y, hh3 = bH.y;
+                    const float hh0 = kRot ? pC.x : pH[0].y, hh1 = kRot ? pC.y : pH[1].y, hh2 = kRot ? cH.x : aH.y, hh3 = kRot ? cH.y : bH.y;
                     const float hl0 = pL[0].y, hl1 = pL[1].y, hl2 = aL.y, hl3 = bL.y;
                     const unsigned qrow = (unsigned)((o - 1) / 2) * (unsigned)Q;
                     if (!kScat) {

@@ -112,3 +112,44 @@ def check_scat_near_sym_b(dev, shape, dtype, tol=1e-5, expect_stream=True):
         assert any('WlDtFwd12Strip<' in k and _args(k)[1:3] == ['13', '19'] and _args(k)[4] == '3' for k in k1), k1
         assert any('WlDtInv1Strip<' in k and _args(k)[1:4] == ['13', '19', '1'] for k in kb), kb
     return k0, k1, kb
+
+
+def check_scat_rot_lean(dev, shape, dtype, tol=1e-5, expect_stream=True):
+    """ScatLayer(biort='near_sym_b_bp') inference on the lean kernel with the third (band-pass) row filter and window
+    (WlDtFwd12Strip<T, 13, 19, 10, 6, ..>) against the oracle's single-axis filters (fwd_j1_rot + the magnitudes of
+    ScatLayerj1_rot_f.forward, scatternet/lowlevel.py:140-182) and, elementwise, against the tile kernel WlDtFwd1Rot."""
+    import _ext_cases as E
+    from pytorch_wavelets_amd import ops
+    from pytorch_wavelets_amd.dtcwt import lowlevel as dl
+    rng = np.random.RandomState(13)
+    x = rng.randn(*shape)
+    if dtype == torch.float16:
+        x = np.float16(x).astype(np.float64)
+    h0o, _, h1o, _, h2o, _ = F.biort('near_sym_b_bp')
+    hn = [dl.prep_filt(v, 1).to(torch.float64).numpy().ravel() for v in (h0o, h1o, h2o)]
+    ll, re, im = E.rot_level1_reference(x, *hn, 'symmetric')
+    pool = ll.reshape(ll.shape[0], ll.shape[1], ll.shape[2] // 2, 2, ll.shape[3] // 2, 2).mean(axis=(3, 5))
+    want = np.concatenate([pool[:, None], np.sqrt(re ** 2 + im ** 2 + 1e-4) - 0.01], 1)
+    sl = pw.ScatLayer(biort='near_sym_b_bp').to(dev).to(dtype)
+    xt = torch.tensor(x, dtype=dtype, device=dev)
+    t = 4e-3 if dtype == torch.float16 else tol
+    with torch.no_grad():
+        c0 = pw.launch_count()
+        z = sl(xt)
+        k0 = pw.kernels_since(c0)
+        try:
+            ops.set_option('no_stream', 1)
+            c0 = pw.launch_count()
+            z1 = sl(xt)
+            k1 = pw.kernels_since(c0)
+        finally:
+            ops.set_option('no_stream', 0)
+    n, _, c, h, w = want.shape
+    assert z.shape == (n, 7 * c, h, w)
+    assert _rel(_npy(z).reshape(want.shape), want) <= t, (shape, k0)
+    assert _rel(_npy(z1).reshape(want.shape), want) <= t, (shape, k1)
+    assert float((z.float() - z1.float()).abs().max()) <= (t if dtype == torch.float16 else 3e-6) * float(z1.float().abs().max())
+    assert all(k.startswith('WlDtFwd1Rot<') for k in k1), k1
+    if expect_stream:
+        assert len(k0) == 1 and 'WlDtFwd12Strip<' in k0[0] and _args(k0[0])[1:3] == ['13', '19'] and _args(k0[0])[4] == '6', k0
+    return k0

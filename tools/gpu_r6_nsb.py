@@ -75,6 +75,13 @@ dt((512, 3, 128, 128), 1, 'near_sym_b', 'qshift_b')
 dt((64, 3, 512, 512), 3, 'near_sym_b', 'qshift_b', torch.float16)
 dt((64, 3, 512, 512), 3, 'legall', 'qshift_06')
 dt((64, 3, 512, 512), 3, 'antonini', 'qshift_c')
+scat((64, 3, 256, 256), 'near_sym_a')
+scat((64, 3, 256, 256), 'near_sym_b')
+scat((64, 3, 256, 256), 'near_sym_b_bp')
+scat((256, 3, 256, 256), 'near_sym_b_bp')
+scat((64, 3, 512, 512), 'near_sym_b_bp')
+scat((16, 3, 1024, 1024), 'near_sym_b_bp')
+scat((256, 3, 256, 256), 'near_sym_b_bp', torch.float16)
 scat((256, 3, 256, 256), 'near_sym_a')
 scat((256, 3, 256, 256), 'near_sym_b')
 scat((64, 3, 512, 512), 'near_sym_b')
