@@ -592,7 +592,21 @@ def other_configs(pw, dev, sync):
         tsw = time_seq_fn(lambda: slw(xd), 30, sync)
         other['scatlayer_64x3x512x512_fp32'] = {'fwd_ms': round(tsw, 4), 'frac_of_hbm_peak_at_11B_per_px': frac(11 * xd.numel(), tsw),
                                                'fwd_kernels': names(lambda: slw(xd))}
-        del xd, dyl, dyh
+        # round 6 (late): the 13 / 19-tap level-1 pair (near_sym_b; 14-tap q-shifts below) on the streaming level-1 kernels, and the
+        # band-pass variant of the ScatLayer (near_sym_b_bp: 13 / 19 / 19 taps) on the lean kernel
+        bx, bi = pw.DTCWTForward(J=3, biort='near_sym_b', qshift='qshift_b').to(dev), pw.DTCWTInverse(biort='near_sym_b', qshift='qshift_b').to(dev)
+        byl, byh = bx(xd)
+        tf, ti = time_seq_fn(lambda: bx(xd), 30, sync), time_seq_fn(lambda: bi((byl, byh)), 30, sync)
+        other['dtcwt_j3_near_sym_b_qshift_b_64x3x512x512_fp32'] = {
+            'fwd_ms': round(tf, 4), 'inv_ms': round(ti, 4), 'fwd_frac_of_hbm_peak_at_20B_per_px': frac(20 * xd.numel(), tf),
+            'inv_frac_of_hbm_peak_at_20B_per_px': frac(20 * xd.numel(), ti),
+            'fwd_kernels': names(lambda: bx(xd)), 'inv_kernels': names(lambda: bi((byl, byh)))}
+        for tag, biort in (('near_sym_b', 'near_sym_b'), ('near_sym_b_bp', 'near_sym_b_bp')):
+            slb = pw.ScatLayer(biort=biort).to(dev)
+            tsb = time_seq_fn(lambda: slb(xd), 30, sync)
+            other['scatlayer_%s_64x3x512x512_fp32' % tag] = {'fwd_ms': round(tsb, 4), 'frac_of_hbm_peak_at_11B_per_px': frac(11 * xd.numel(), tsb),
+                                                            'fwd_kernels': names(lambda: slb(xd))}
+        del xd, dyl, dyh, byl, byh
     # ---- training steps (forward + backward to the input): rows f1 of SURVEY 8(f).  Algorithmic bytes: the forward's, and for
     # the backward the gradients of every output read once + the input gradient written once (= the forward's number again);
     # ScatLayer also writes (forward) and reads (backward) the saved (re, im) / r: 6 planes of P/4 each, twice
