@@ -152,6 +152,58 @@ def scat_layer_j2(x, h0o, h1o, h0a, h0b, h1a, h1b, mode, bias, combine_colour):
     return torch.cat((s0[:, None], Z2[:, 0].reshape(n, 6, c, h, w), s1_j2, Z2[:, 1:].reshape(n, 36, c, h, w)), dim=1)
 
 
+def _scat_bwd1_any(dZ, drdx, drdy, h0o, h1o, mode):
+    """ScatLayerj1_f.backward without colour combination: the fused launch, or (taps / dtypes it has no kernel for) the prologue
+    in the tensor library + the level-1 inverse."""
+    dX = ops.scat_bwd1(dZ, drdx, drdy, h0o, h1o, mode, False)
+    if dX is None:
+        ll = 0.25 * F.interpolate(dZ[:, 0], scale_factor=2, mode="nearest")
+        dr = dZ[:, 1:]
+        highs = torch.stack((dr * drdx, dr * drdy), dim=-1).permute(0, 2, 1, 3, 4, 5).contiguous()
+        dX = ops.dtcwt_inv1(ll, highs, h0o, h1o, mode)
+    return dX
+
+
+class ScatLayerj1_rot_train_f(Function):
+    """The TRAINING step of ScatLayerj1_rot_f (reference scatternet/lowlevel.py:140-203; no colour combination) on the fused
+    ScatLayer kernels, two launches per direction (round 6).  fwd_j1_rot differs from fwd_j1 in ONE sub-band: hh = C_h2 R_h2 x
+    instead of C_h1 R_h1 x (dtcwt/transform_funcs.py:124-149) - and the plain fused kernel run with the pair (h0o, h2o) computes
+    exactly that as ITS hh.  So: launch A with (h0o, h1o) gives the pooled lowpass and the orientations of lh and hl (15, 75, 105,
+    165 deg), launch B with (h0o, h2o) the orientations of hh (45, 135 deg: entries 2 and 5 of Z, 1 and 4 of the saved
+    (re, im) / r).  The layer is a sum over sub-bands, so its backward is the fused backward A of dZ without those two entries
+    plus the fused backward B of those two alone.  With the 13 / 19 / 19-tap tables all four launches are the streaming
+    kernels of the 13 / 19 pair (WlDtFwd12Strip<T, 13, 19, 10, 3>, WlDtInv1Strip<T, 13, 19, 1>)."""
+    @staticmethod
+    def forward(ctx, x, h0o, h1o, h2o, mode, bias):
+        int_to_mode(mode)
+        ctx.mode = mode
+        Z, drdx, drdy = ops.scat_fwd1(x, h0o, h1o, mode, bias, False, save=True)
+        Zb, bx, by = ops.scat_fwd1(x, h0o, h2o, mode, bias, False, save=True)
+        for o in (1, 4):
+            Z[:, 1 + o] = Zb[:, 1 + o]
+            drdx[:, o] = bx[:, o]
+            drdy[:, o] = by[:, o]
+        ctx.save_for_backward(h0o, h1o, h2o, drdx, drdy)
+        return Z
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dZ):
+        dX = None
+        if ctx.needs_input_grad[0]:
+            h0o, h1o, h2o, drdx, drdy = ctx.saved_tensors
+            dA = dZ.clone()
+            dB = torch.zeros_like(dZ)
+            for o in (1, 4):
+                dB[:, 1 + o] = dZ[:, 1 + o]
+                dA[:, 1 + o] = 0
+            dX = _scat_bwd1_any(dA, drdx, drdy, h0o, h1o, ctx.mode) + _scat_bwd1_any(dB, drdx, drdy, h0o, h2o, ctx.mode)
+        return (dX,) + (None,) * 5
+
+
+ROT_TRAIN_FUSED = True   # tests switch it off to get the chain of differentiable pieces
+
+
 def scat_layer_j1_rot(x, h0o, h1o, h2o, mode, bias, combine_colour):
     """ScatLayerj1_rot_f (reference scatternet/lowlevel.py:140-203): the ScatLayer with the rotationally symmetric
     13/19-tap filters (third band-pass pair for the diagonals), as a chain of differentiable pieces."""
@@ -162,6 +214,10 @@ def scat_layer_j1_rot(x, h0o, h1o, h2o, mode, bias, combine_colour):
         z = ops.dtcwt_fwd1_rot(x, h0o, h1o, h2o, int_to_mode(mode) == 'symmetric', scat=True, magbias=bias)
         if z is not None:
             return z
+    if ROT_TRAIN_FUSED and _tf.FUSED_ROT and not combine_colour and x.shape[-2] % 2 == 0 and x.shape[-1] % 2 == 0 \
+            and h1o.numel() == h2o.numel():
+        # training: two launches of the fused ScatLayer kernels per direction (above)
+        return ScatLayerj1_rot_train_f.apply(x, h0o, h1o, h2o, mode, bias)
     ll, reals, imags = FWD_J1_ROT.apply(x, h0o, h1o, h2o, mode)
     ll = F.avg_pool2d(ll, 2)
     if combine_colour:

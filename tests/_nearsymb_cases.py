@@ -153,3 +153,44 @@ def check_scat_rot_lean(dev, shape, dtype, tol=1e-5, expect_stream=True):
     if expect_stream:
         assert len(k0) == 1 and 'WlDtFwd12Strip<' in k0[0] and _args(k0[0])[1:3] == ['13', '19'] and _args(k0[0])[4] == '6', k0
     return k0
+
+
+def check_scat_rot_training(dev, shape, dtype, tol=2e-5, expect_stream=True):
+    """The training step of ScatLayer(biort='near_sym_b_bp') on two launches of the fused ScatLayer kernels per direction
+    (scatternet/lowlevel.py ScatLayerj1_rot_train_f) against the chain of differentiable pieces it replaces (FWD_J1_ROT + the
+    tensor library's magnitudes; pinned to the reference's Z and dx by the goldens ext_rot_*) and against the oracle's Z."""
+    import _ext_cases as E
+    from pytorch_wavelets_amd.dtcwt import lowlevel as dl
+    from pytorch_wavelets_amd.scatternet import lowlevel as sl_ll
+    rng = np.random.RandomState(17)
+    x = rng.randn(*shape)
+    if dtype == torch.float16:
+        x = np.float16(x).astype(np.float64)
+    h0o, _, h1o, _, h2o, _ = F.biort('near_sym_b_bp')
+    hn = [dl.prep_filt(v, 1).to(torch.float64).numpy().ravel() for v in (h0o, h1o, h2o)]
+    ll, re, im = E.rot_level1_reference(x, *hn, 'symmetric')
+    pool = ll.reshape(ll.shape[0], ll.shape[1], ll.shape[2] // 2, 2, ll.shape[3] // 2, 2).mean(axis=(3, 5))
+    want = np.concatenate([pool[:, None], np.sqrt(re ** 2 + im ** 2 + 1e-4) - 0.01], 1)
+    sl = pw.ScatLayer(biort='near_sym_b_bp').to(dev).to(dtype)
+    gz = torch.tensor(rng.randn(want.shape[0], 7 * want.shape[2], *want.shape[3:]), dtype=dtype, device=dev)
+    out = {}
+    for fused in (True, False):
+        sl_ll.ROT_TRAIN_FUSED = fused
+        try:
+            xg = torch.tensor(x, dtype=dtype, device=dev).requires_grad_(True)
+            c0 = pw.launch_count()
+            z = sl(xg)
+            g, = torch.autograd.grad(z, xg, gz)
+            out[fused] = (z.detach(), g, pw.kernels_since(c0))
+        finally:
+            sl_ll.ROT_TRAIN_FUSED = True
+    t = 1e-2 if dtype == torch.float16 else tol
+    assert _rel(_npy(out[True][0]).reshape(want.shape), want) <= (4e-3 if dtype == torch.float16 else 1e-5), shape
+    for a, b in zip(out[True][:2], out[False][:2]):
+        assert a.shape == b.shape and float((a.float() - b.float()).abs().max()) <= t * float(b.float().abs().max()), (shape, out[True][2])
+    ks = out[True][2]
+    assert len(ks) == 4, ks
+    if expect_stream:
+        assert sum('WlDtFwd12Strip<' in k and _args(k)[1:3] == ['13', '19'] and _args(k)[4] == '3' for k in ks) == 2, ks
+        assert sum('WlDtInv1Strip<' in k and _args(k)[1:4] == ['13', '19', '1'] for k in ks) == 2, ks
+    return ks

@@ -656,3 +656,13 @@ def test_rotationally_symmetric_scatlayer_on_the_lean_kernel(shape, dtype):
     import _nearsymb_cases as NB
     with emu_backend.emulated():
         NB.check_scat_rot_lean('cpu', shape, dtype)
+
+
+@pytest.mark.parametrize('shape,dtype,stream', [((2, 3, 40, 256), torch.float32, True), ((1, 2, 44, 512), torch.float32, True), ((2, 2, 24, 40), torch.float32, False),
+                                                ((1, 2, 40, 512), torch.float16, True)])
+def test_rotationally_symmetric_scatlayer_training_step(shape, dtype, stream):
+    """Round 6: the training step of ScatLayer(biort='near_sym_b_bp') = two launches of the fused ScatLayer kernels per direction (the
+    pair (h0o, h2o) makes the plain kernel's hh the band-pass diagonal) against the chain of differentiable pieces and the oracle."""
+    import _nearsymb_cases as NB
+    with emu_backend.emulated():
+        NB.check_scat_rot_training('cpu', shape, dtype, expect_stream=stream)

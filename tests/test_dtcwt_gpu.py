@@ -552,3 +552,11 @@ def test_rotationally_symmetric_scatlayer_on_the_lean_kernel(shape, dtype):
     """Round 6: ScatLayer(biort='near_sym_b_bp') inference on the lean streaming kernel (MODE 6) against the oracle and the tile kernel."""
     import _nearsymb_cases as NB
     NB.check_scat_rot_lean(DEV, shape, dtype)
+
+
+@pytest.mark.parametrize('shape,dtype,stream', [((22, 3, 256, 256), torch.float32, True), ((12, 3, 512, 512), torch.float32, True), ((5, 3, 64, 72), torch.float32, False),
+                                                ((12, 3, 512, 512), torch.float16, True)])
+def test_rotationally_symmetric_scatlayer_training_step(shape, dtype, stream):
+    """Round 6: the training step of ScatLayer(biort='near_sym_b_bp') on two launches of the fused ScatLayer kernels per direction."""
+    import _nearsymb_cases as NB
+    NB.check_scat_rot_training(DEV, shape, dtype, expect_stream=stream)
