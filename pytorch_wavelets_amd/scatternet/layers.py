@@ -20,8 +20,9 @@ class ScatLayer(nn.Module):
         self.magbias = magbias
         self.combine_colour = combine_colour
         if biort == 'near_sym_b_bp':
-            # rotationally symmetric variant: a third (band-pass) pair filters the diagonal sub-band; it runs on the
-            # single-axis kernels (seven filter launches per level), not on the fused ScatLayer kernel
+            # rotationally symmetric variant: a third (band-pass) pair filters the diagonal sub-band.  Inference: one launch (the lean
+            # streaming kernel with a third row filter and window, or the tile kernel WlDtFwd1Rot); training: two launches of the plain
+            # fused ScatLayer kernels per direction (scatternet/lowlevel.py: ScatLayerj1_rot_train_f); combine_colour: the chain
             self.bandpass_diag = True
             h0o, _, h1o, _, h2o, _ = _biort(biort)
             self.h2o = torch.nn.Parameter(prep_filt(h2o, 1), False)
