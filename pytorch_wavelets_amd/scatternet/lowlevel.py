@@ -243,9 +243,15 @@ def scat_layer_j2_rot(x, h0o, h1o, h2o, h0a, h0b, h1a, h1b, h2a, h2b, mode, bias
     s0, reals, imags = FWD_J2PLUS_ROT.apply(s0, h0a, h1a, h0b, h1b, h2a, h2b, mode)
     s1_j2 = _smooth_mag(reals, imags, bias, sum_dim=2 if combine_colour else None)
     s0 = F.avg_pool2d(s0, 2)
-    s1_ll, reals, imags = FWD_J1_ROT.apply(s1_j1, h0o, h1o, h2o, mode)
-    s2_j1 = _smooth_mag(reals, imags, bias)                                         # (N,6,6C',h,w)
-    s1p = F.avg_pool2d(s1_ll, 2)
+    # second order: the first-order band-pass layer on the 6 C' magnitude planes - pooled lowpass + 36 magnitudes from ITS launches
+    # (inference: one launch of the lean kernel or of WlDtFwd1Rot; training: ScatLayerj1_rot_train_f)
+    if ROT_TRAIN_FUSED:
+        Z2 = scat_layer_j1_rot(s1_j1, h0o, h1o, h2o, mode, bias, False)             # (N,7,6C',h,w)
+        s1p, s2_j1 = Z2[:, 0], Z2[:, 1:]
+    else:                                                                           # (the chain of round 4: A/B probes, tests)
+        s1_ll, reals, imags = FWD_J1_ROT.apply(s1_j1, h0o, h1o, h2o, mode)
+        s2_j1 = _smooth_mag(reals, imags, bias)                                     # (N,6,6C',h,w)
+        s1p = F.avg_pool2d(s1_ll, 2)
     h, w = s1p.shape[-2:]
     if combine_colour:
         return torch.cat((s0, s1p, s1_j2[:, :, 0], s2_j1.reshape(n, 36, h, w)), dim=1)

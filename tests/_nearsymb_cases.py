@@ -194,3 +194,31 @@ def check_scat_rot_training(dev, shape, dtype, tol=2e-5, expect_stream=True):
         assert sum('WlDtFwd12Strip<' in k and _args(k)[1:3] == ['13', '19'] and _args(k)[4] == '3' for k in ks) == 2, ks
         assert sum('WlDtInv1Strip<' in k and _args(k)[1:4] == ['13', '19', '1'] for k in ks) == 2, ks
     return ks
+
+
+def check_scatj2_rot(dev, shape, dtype, tol=3e-5):
+    """ScatLayerj2(biort='near_sym_b_bp', qshift='qshift_b_bp'): its second-order block through the first-order band-pass layer's own
+    launches (inference: lean MODE 6 / WlDtFwd1Rot; training: ScatLayerj1_rot_train_f) against the chain of round 4 (pinned to the
+    reference's Z and dx by the goldens ext_rot_3 / ext_rot_4) - output and input gradient."""
+    from pytorch_wavelets_amd.scatternet import lowlevel as sl_ll
+    torch.manual_seed(19)
+    x = torch.randn(*shape, device=dev).to(dtype)
+    sl = pw.ScatLayerj2(biort='near_sym_b_bp', qshift='qshift_b_bp').to(dev).to(dtype)
+    out = {}
+    for fused in (True, False):
+        sl_ll.ROT_TRAIN_FUSED = fused
+        try:
+            with torch.no_grad():
+                c0 = pw.launch_count()
+                z0 = sl(x)
+                k0 = pw.kernels_since(c0)
+            xg = x.clone().requires_grad_(True)
+            z = sl(xg)
+            g, = torch.autograd.grad(z, xg, torch.ones_like(z) + 0.5 * z.detach())
+            out[fused] = (z0, z.detach(), g, k0)
+        finally:
+            sl_ll.ROT_TRAIN_FUSED = True
+    t = 1e-2 if dtype == torch.float16 else tol
+    for a, b in zip(out[True][:3], out[False][:3]):
+        assert a.shape == b.shape and float((a.float() - b.float()).abs().max()) <= t * float(b.float().abs().max()), (shape, out[True][3])
+    return out[True][3]

@@ -666,3 +666,12 @@ def test_rotationally_symmetric_scatlayer_training_step(shape, dtype, stream):
     import _nearsymb_cases as NB
     with emu_backend.emulated():
         NB.check_scat_rot_training('cpu', shape, dtype, expect_stream=stream)
+
+
+@pytest.mark.parametrize('shape,dtype', [((1, 2, 96, 512), torch.float32), ((2, 1, 64, 80), torch.float32)])
+def test_rotationally_symmetric_scatlayerj2_second_order_through_the_layer(shape, dtype):
+    import _nearsymb_cases as NB
+    with emu_backend.emulated():
+        ks = NB.check_scatj2_rot('cpu', shape, dtype)
+    if shape[-1] >= 512:
+        assert any('WlDtFwd12Strip<' in k and NB._args(k)[4] == '6' for k in ks), ks

@@ -560,3 +560,12 @@ def test_rotationally_symmetric_scatlayer_training_step(shape, dtype, stream):
     """Round 6: the training step of ScatLayer(biort='near_sym_b_bp') on two launches of the fused ScatLayer kernels per direction."""
     import _nearsymb_cases as NB
     NB.check_scat_rot_training(DEV, shape, dtype, expect_stream=stream)
+
+
+@pytest.mark.parametrize('shape,dtype', [((16, 3, 256, 256), torch.float32), ((8, 3, 512, 512), torch.float32), ((4, 3, 72, 88), torch.float32)])
+def test_rotationally_symmetric_scatlayerj2_second_order_through_the_layer(shape, dtype):
+    """Round 6: ScatLayerj2 with the band-pass tables - the second-order block on the first-order layer's own launches against the chain."""
+    import _nearsymb_cases as NB
+    ks = NB.check_scatj2_rot(DEV, shape, dtype)
+    if shape[-1] >= 256:
+        assert any('WlDtFwd12Strip<' in k and NB._args(k)[4] == '6' for k in ks), ks

@@ -27,3 +27,25 @@ for shape in ((64, 3, 256, 256), (256, 3, 256, 256), (64, 3, 512, 512), (16, 3, 
             rec[tag + '_fwdbwd_ms'] = round(t, 4)
             rec[tag + '_k'] = short(ks)
     print(json.dumps(rec), flush=True)
+
+# ScatLayerj2 with the band-pass tables: its second-order block (the first-order layer on 6 C magnitude planes) through the same launches
+for shape in ((64, 3, 256, 256), (32, 3, 512, 512)):
+    x = torch.randn(*shape, device=dev)
+    rec = {'shape': shape, 'layer': 'ScatLayerj2(near_sym_b_bp, qshift_b_bp)'}
+    sl = pw.ScatLayerj2(biort='near_sym_b_bp', qshift='qshift_b_bp').to(dev)
+    for fused in (True, False):
+        sl_ll.ROT_TRAIN_FUSED = fused
+        try:
+            with torch.no_grad():
+                c0 = pw.launch_count(); sl(x); ks = pw.kernels_since(c0)
+                ti = min(bench.time_seq_fn(lambda: sl(x), 20, sync) for _ in range(2))
+            xg = x.clone().requires_grad_(True)
+            def step():
+                z = sl(xg)
+                torch.autograd.grad(z, xg, z)
+            tt = min(bench.time_seq_fn(step, 10, sync) for _ in range(2))
+        finally:
+            sl_ll.ROT_TRAIN_FUSED = True
+        tag = 'layer' if fused else 'chain'
+        rec[tag + '_inference_ms'] = round(ti, 4); rec[tag + '_fwdbwd_ms'] = round(tt, 4); rec[tag + '_k'] = short(ks)
+    print(json.dumps(rec), flush=True)
