@@ -173,22 +173,34 @@ class ScatLayerj1_rot_train_f(Function):
     (re, im) / r).  The layer is a sum over sub-bands, so its backward is the fused backward A of dZ without those two entries
     plus the fused backward B of those two alone.  With the 13 / 19 / 19-tap tables all four launches are the streaming
     kernels of the 13 / 19 pair (WlDtFwd12Strip<T, 13, 19, 10, 3>, WlDtInv1Strip<T, 13, 19, 1>)."""
+    # ``apply(x, h0o, h1o, h2o, mode_int, bias, want_ll) -> (ll, Z)``: ll = the full-resolution level-1 lowpass (ScatLayerj2's second
+    # scale filters it; an empty tensor unless want_ll), Z (N, 7, C, H/2, W/2).  Also the inference form of that pair (no gradient
+    # wanted: nothing is saved).
     @staticmethod
-    def forward(ctx, x, h0o, h1o, h2o, mode, bias):
+    def forward(ctx, x, h0o, h1o, h2o, mode, bias, want_ll=False):
         int_to_mode(mode)
         ctx.mode = mode
-        Z, drdx, drdy = ops.scat_fwd1(x, h0o, h1o, mode, bias, False, save=True)
-        Zb, bx, by = ops.scat_fwd1(x, h0o, h2o, mode, bias, False, save=True)
+        save = x.requires_grad
+        res = ops.scat_fwd1(x, h0o, h1o, mode, bias, False, save=save, want_ll=want_ll)
+        Z, drdx, drdy = res[:3]
+        ll = res[3] if want_ll else x.new_zeros([])
+        Zb, bx, by = ops.scat_fwd1(x, h0o, h2o, mode, bias, False, save=save)
         for o in (1, 4):
             Z[:, 1 + o] = Zb[:, 1 + o]
-            drdx[:, o] = bx[:, o]
-            drdy[:, o] = by[:, o]
-        ctx.save_for_backward(h0o, h1o, h2o, drdx, drdy)
-        return Z
+            if save:
+                drdx[:, o] = bx[:, o]
+                drdy[:, o] = by[:, o]
+        if save:
+            ctx.save_for_backward(h0o, h1o, h2o, drdx, drdy)
+        else:
+            z = x.new_zeros(1)
+            ctx.save_for_backward(h0o, h1o, h2o, z, z)
+        ctx.want_ll = want_ll
+        return ll, Z
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dZ):
+    def backward(ctx, dll, dZ):
         dX = None
         if ctx.needs_input_grad[0]:
             h0o, h1o, h2o, drdx, drdy = ctx.saved_tensors
@@ -198,7 +210,9 @@ class ScatLayerj1_rot_train_f(Function):
                 dB[:, 1 + o] = dZ[:, 1 + o]
                 dA[:, 1 + o] = 0
             dX = _scat_bwd1_any(dA, drdx, drdy, h0o, h1o, ctx.mode) + _scat_bwd1_any(dB, drdx, drdy, h0o, h2o, ctx.mode)
-        return (dX,) + (None,) * 5
+            if ctx.want_ll:    # the level-1 inverse is linear in (lowpass, highpasses): the lowpass's gradient alone
+                dX = dX + ops.dtcwt_inv1(dll.contiguous(), None, h0o, h1o, ctx.mode)
+        return (dX,) + (None,) * 6
 
 
 ROT_TRAIN_FUSED = True   # tests switch it off to get the chain of differentiable pieces
@@ -217,7 +231,7 @@ def scat_layer_j1_rot(x, h0o, h1o, h2o, mode, bias, combine_colour):
     if ROT_TRAIN_FUSED and _tf.FUSED_ROT and not combine_colour and x.shape[-2] % 2 == 0 and x.shape[-1] % 2 == 0 \
             and h1o.numel() == h2o.numel():
         # training: two launches of the fused ScatLayer kernels per direction (above)
-        return ScatLayerj1_rot_train_f.apply(x, h0o, h1o, h2o, mode, bias)
+        return ScatLayerj1_rot_train_f.apply(x, h0o, h1o, h2o, mode, bias, False)[1]
     ll, reals, imags = FWD_J1_ROT.apply(x, h0o, h1o, h2o, mode)
     ll = F.avg_pool2d(ll, 2)
     if combine_colour:
@@ -229,11 +243,28 @@ def scat_layer_j1_rot(x, h0o, h1o, h2o, mode, bias, combine_colour):
 def scat_layer_j2_rot(x, h0o, h1o, h2o, h0a, h0b, h1a, h1b, h2a, h2b, mode, bias, combine_colour):
     """ScatLayerj2_rot_f (reference scatternet/lowlevel.py:401-599), same chain as scat_layer_j2 on the band-pass
     level functions."""
-    from ..dtcwt.transform_funcs import FWD_J1_ROT, FWD_J2PLUS_ROT
+    from ..dtcwt.transform_funcs import FWD_J1_ROT, FWD_J2PLUS_ROT, FWD_J2PLUS
+    from ..dtcwt import transform_funcs as _tf
     if int_to_mode(mode) != 'symmetric':
         raise NotImplementedError()
-    s0, reals, imags = FWD_J1_ROT.apply(x, h0o, h1o, h2o, mode)
     n = x.shape[0]
+    if ROT_TRAIN_FUSED and _tf.FUSED_ROT and not combine_colour and h1o.numel() == h2o.numel() and h1a.numel() == h2a.numel() \
+            and h1b.numel() == h2b.numel():
+        # Round 6: every band-pass level function differs from the plain one in ONE sub-band - hh is filtered by the third pair on both
+        # axes - and the plain fused kernels run with that pair in place of the highpass pair compute it as THEIR hh: each scale is two
+        # launches of the plain kernels, the 45 / 135 degree orientations (entries 1 and 4) taken from the second (ScatLayerj1_rot_train_f).
+        c = x.shape[1]
+        s0, Z1 = ScatLayerj1_rot_train_f.apply(x, h0o, h1o, h2o, mode, bias, True)      # full-resolution lowpass, (N,7,C,H/2,W/2)
+        s1_j1 = Z1[:, 1:].reshape(n, 6 * c, Z1.shape[3], Z1.shape[4])
+        ll2, ha = FWD_J2PLUS.apply(s0, h0a, h1a, h0b, h1b, False, 1, -1, mode)          # highs (N,6,C,h,w,2)
+        _, hb = FWD_J2PLUS.apply(s0, h0a, h2a, h0b, h2b, False, 1, -1, mode)
+        highs = torch.cat((ha[:, 0:1], hb[:, 1:2], ha[:, 2:4], hb[:, 4:5], ha[:, 5:6]), dim=1)
+        s1_j2 = _smooth_mag(highs[..., 0], highs[..., 1], bias)                          # (N,6,C,h,w)
+        s0 = F.avg_pool2d(ll2, 2)
+        Z2 = scat_layer_j1_rot(s1_j1, h0o, h1o, h2o, mode, bias, False)                  # (N,7,6C,h,w)
+        h, w = Z2.shape[-2:]
+        return torch.cat((s0[:, None], Z2[:, 0].reshape(n, 6, c, h, w), s1_j2, Z2[:, 1:].reshape(n, 36, c, h, w)), dim=1)
+    s0, reals, imags = FWD_J1_ROT.apply(x, h0o, h1o, h2o, mode)
     if combine_colour:
         s1_j1 = _smooth_mag(reals, imags, bias, sum_dim=2)[:, :, 0]                 # (N,6,H/2,W/2)
     else:
