@@ -152,13 +152,17 @@ def scat_layer_j2(x, h0o, h1o, h0a, h0b, h1a, h1b, mode, bias, combine_colour):
     return torch.cat((s0[:, None], Z2[:, 0].reshape(n, 6, c, h, w), s1_j2, Z2[:, 1:].reshape(n, 36, c, h, w)), dim=1)
 
 
-def _scat_bwd1_any(dZ, drdx, drdy, h0o, h1o, mode):
-    """ScatLayerj1_f.backward without colour combination: the fused launch, or (taps / dtypes it has no kernel for) the prologue
-    in the tensor library + the level-1 inverse."""
-    dX = ops.scat_bwd1(dZ, drdx, drdy, h0o, h1o, mode, False)
+def _scat_bwd1_any(dZ, drdx, drdy, h0o, h1o, mode, combine_colour=False):
+    """ScatLayerj1_f.backward: the fused launch, or (taps / dtypes it has no kernel for) the prologue in the tensor library + the
+    level-1 inverse."""
+    dX = ops.scat_bwd1(dZ, drdx, drdy, h0o, h1o, mode, combine_colour)
     if dX is None:
-        ll = 0.25 * F.interpolate(dZ[:, 0], scale_factor=2, mode="nearest")
-        dr = dZ[:, 1:]
+        if combine_colour:
+            dYl, dr = dZ[:, :3], dZ[:, 3:]
+            dr = dr[:, :, None]
+        else:
+            dYl, dr = dZ[:, 0], dZ[:, 1:]
+        ll = 0.25 * F.interpolate(dYl, scale_factor=2, mode="nearest")
         highs = torch.stack((dr * drdx, dr * drdy), dim=-1).permute(0, 2, 1, 3, 4, 5).contiguous()
         dX = ops.dtcwt_inv1(ll, highs, h0o, h1o, mode)
     return dX
@@ -177,16 +181,18 @@ class ScatLayerj1_rot_train_f(Function):
     # scale filters it; an empty tensor unless want_ll), Z (N, 7, C, H/2, W/2).  Also the inference form of that pair (no gradient
     # wanted: nothing is saved).
     @staticmethod
-    def forward(ctx, x, h0o, h1o, h2o, mode, bias, want_ll=False):
+    def forward(ctx, x, h0o, h1o, h2o, mode, bias, want_ll=False, combine_colour=False):
         int_to_mode(mode)
         ctx.mode = mode
+        ctx.combine_colour = combine_colour
+        ctx.e0 = e0 = 3 if combine_colour else 1              # entry of orientation 0: Z is (N, 3 + 6, h, w) when combining colour
         save = x.requires_grad
-        res = ops.scat_fwd1(x, h0o, h1o, mode, bias, False, save=save, want_ll=want_ll)
+        res = ops.scat_fwd1(x, h0o, h1o, mode, bias, combine_colour, save=save, want_ll=want_ll)
         Z, drdx, drdy = res[:3]
         ll = res[3] if want_ll else x.new_zeros([])
-        Zb, bx, by = ops.scat_fwd1(x, h0o, h2o, mode, bias, False, save=save)
+        Zb, bx, by = ops.scat_fwd1(x, h0o, h2o, mode, bias, combine_colour, save=save)
         for o in (1, 4):
-            Z[:, 1 + o] = Zb[:, 1 + o]
+            Z[:, e0 + o] = Zb[:, e0 + o]
             if save:
                 drdx[:, o] = bx[:, o]
                 drdy[:, o] = by[:, o]
@@ -207,12 +213,13 @@ class ScatLayerj1_rot_train_f(Function):
             dA = dZ.clone()
             dB = torch.zeros_like(dZ)
             for o in (1, 4):
-                dB[:, 1 + o] = dZ[:, 1 + o]
-                dA[:, 1 + o] = 0
-            dX = _scat_bwd1_any(dA, drdx, drdy, h0o, h1o, ctx.mode) + _scat_bwd1_any(dB, drdx, drdy, h0o, h2o, ctx.mode)
+                dB[:, ctx.e0 + o] = dZ[:, ctx.e0 + o]
+                dA[:, ctx.e0 + o] = 0
+            dX = _scat_bwd1_any(dA, drdx, drdy, h0o, h1o, ctx.mode, ctx.combine_colour) \
+                + _scat_bwd1_any(dB, drdx, drdy, h0o, h2o, ctx.mode, ctx.combine_colour)
             if ctx.want_ll:    # the level-1 inverse is linear in (lowpass, highpasses): the lowpass's gradient alone
                 dX = dX + ops.dtcwt_inv1(dll.contiguous(), None, h0o, h1o, ctx.mode)
-        return (dX,) + (None,) * 6
+        return (dX,) + (None,) * 7
 
 
 ROT_TRAIN_FUSED = True   # tests switch it off to get the chain of differentiable pieces
@@ -228,10 +235,9 @@ def scat_layer_j1_rot(x, h0o, h1o, h2o, mode, bias, combine_colour):
         z = ops.dtcwt_fwd1_rot(x, h0o, h1o, h2o, int_to_mode(mode) == 'symmetric', scat=True, magbias=bias)
         if z is not None:
             return z
-    if ROT_TRAIN_FUSED and _tf.FUSED_ROT and not combine_colour and x.shape[-2] % 2 == 0 and x.shape[-1] % 2 == 0 \
-            and h1o.numel() == h2o.numel():
-        # training: two launches of the fused ScatLayer kernels per direction (above)
-        return ScatLayerj1_rot_train_f.apply(x, h0o, h1o, h2o, mode, bias, False)[1]
+    if ROT_TRAIN_FUSED and _tf.FUSED_ROT and x.shape[-2] % 2 == 0 and x.shape[-1] % 2 == 0 and h1o.numel() == h2o.numel():
+        # training (and, when combining colour, inference): two launches of the fused ScatLayer kernels per direction (above)
+        return ScatLayerj1_rot_train_f.apply(x, h0o, h1o, h2o, mode, bias, False, combine_colour)[1]
     ll, reals, imags = FWD_J1_ROT.apply(x, h0o, h1o, h2o, mode)
     ll = F.avg_pool2d(ll, 2)
     if combine_colour:
@@ -248,21 +254,22 @@ def scat_layer_j2_rot(x, h0o, h1o, h2o, h0a, h0b, h1a, h1b, h2a, h2b, mode, bias
     if int_to_mode(mode) != 'symmetric':
         raise NotImplementedError()
     n = x.shape[0]
-    if ROT_TRAIN_FUSED and _tf.FUSED_ROT and not combine_colour and h1o.numel() == h2o.numel() and h1a.numel() == h2a.numel() \
-            and h1b.numel() == h2b.numel():
+    if ROT_TRAIN_FUSED and _tf.FUSED_ROT and h1o.numel() == h2o.numel() and h1a.numel() == h2a.numel() and h1b.numel() == h2b.numel():
         # Round 6: every band-pass level function differs from the plain one in ONE sub-band - hh is filtered by the third pair on both
         # axes - and the plain fused kernels run with that pair in place of the highpass pair compute it as THEIR hh: each scale is two
         # launches of the plain kernels, the 45 / 135 degree orientations (entries 1 and 4) taken from the second (ScatLayerj1_rot_train_f).
         c = x.shape[1]
-        s0, Z1 = ScatLayerj1_rot_train_f.apply(x, h0o, h1o, h2o, mode, bias, True)      # full-resolution lowpass, (N,7,C,H/2,W/2)
-        s1_j1 = Z1[:, 1:].reshape(n, 6 * c, Z1.shape[3], Z1.shape[4])
+        s0, Z1 = ScatLayerj1_rot_train_f.apply(x, h0o, h1o, h2o, mode, bias, True, combine_colour)   # full-resolution lowpass; (N,7,C,H/2,W/2) | (N,9,H/2,W/2)
+        s1_j1 = Z1[:, 3:] if combine_colour else Z1[:, 1:].reshape(n, 6 * c, Z1.shape[3], Z1.shape[4])
         ll2, ha = FWD_J2PLUS.apply(s0, h0a, h1a, h0b, h1b, False, 1, -1, mode)          # highs (N,6,C,h,w,2)
         _, hb = FWD_J2PLUS.apply(s0, h0a, h2a, h0b, h2b, False, 1, -1, mode)
         highs = torch.cat((ha[:, 0:1], hb[:, 1:2], ha[:, 2:4], hb[:, 4:5], ha[:, 5:6]), dim=1)
-        s1_j2 = _smooth_mag(highs[..., 0], highs[..., 1], bias)                          # (N,6,C,h,w)
+        s1_j2 = _smooth_mag(highs[..., 0], highs[..., 1], bias, sum_dim=2 if combine_colour else None)   # (N,6,C | 1,h,w)
         s0 = F.avg_pool2d(ll2, 2)
-        Z2 = scat_layer_j1_rot(s1_j1, h0o, h1o, h2o, mode, bias, False)                  # (N,7,6C,h,w)
+        Z2 = scat_layer_j1_rot(s1_j1, h0o, h1o, h2o, mode, bias, False)                  # (N,7,6C | 6,h,w)
         h, w = Z2.shape[-2:]
+        if combine_colour:
+            return torch.cat((s0, Z2[:, 0], s1_j2[:, :, 0], Z2[:, 1:].reshape(n, 36, h, w)), dim=1)
         return torch.cat((s0[:, None], Z2[:, 0].reshape(n, 6, c, h, w), s1_j2, Z2[:, 1:].reshape(n, 36, c, h, w)), dim=1)
     s0, reals, imags = FWD_J1_ROT.apply(x, h0o, h1o, h2o, mode)
     if combine_colour:

@@ -222,3 +222,30 @@ def check_scatj2_rot(dev, shape, dtype, tol=3e-5):
     for a, b in zip(out[True][:3], out[False][:3]):
         assert a.shape == b.shape and float((a.float() - b.float()).abs().max()) <= t * float(b.float().abs().max()), (shape, out[True][3])
     return out[True][3]
+
+
+def check_rot_combine_colour(dev, shape, dtype, tol=3e-5):
+    """combine_colour=True with the band-pass tables (ScatLayer and ScatLayerj2): the pairs of plain launches against the chain of round 4
+    (pinned to the reference by the goldens ext_rot_1 / ext_rot_4) - output and input gradient."""
+    from pytorch_wavelets_amd.scatternet import lowlevel as sl_ll
+    torch.manual_seed(23)
+    x = torch.randn(*shape, device=dev).to(dtype)
+    for mod in (pw.ScatLayer(biort='near_sym_b_bp', combine_colour=True), pw.ScatLayerj2(biort='near_sym_b_bp', qshift='qshift_b_bp', combine_colour=True)):
+        mod = mod.to(dev).to(dtype)
+        out = {}
+        for fused in (True, False):
+            sl_ll.ROT_TRAIN_FUSED = fused
+            try:
+                with torch.no_grad():
+                    z0 = mod(x)
+                xg = x.clone().requires_grad_(True)
+                c0 = pw.launch_count()
+                z = mod(xg)
+                g, = torch.autograd.grad(z, xg, torch.ones_like(z) + 0.5 * z.detach())
+                out[fused] = (z0, z.detach(), g, pw.kernels_since(c0))
+            finally:
+                sl_ll.ROT_TRAIN_FUSED = True
+        assert not any('WlCorr1d' in k or 'WlDtFwd1Rot' in k for k in out[True][3]), out[True][3]
+        assert any('WlCorr1d' in k for k in out[False][3]), out[False][3]
+        for a, b in zip(out[True][:3], out[False][:3]):
+            assert a.shape == b.shape and float((a.float() - b.float()).abs().max()) <= tol * float(b.float().abs().max()), (shape, type(mod).__name__)

@@ -675,3 +675,9 @@ def test_rotationally_symmetric_scatlayerj2_second_order_through_the_layer(shape
         ks = NB.check_scatj2_rot('cpu', shape, dtype)
     if shape[-1] >= 512:
         assert any('WlDtFwd12Strip<' in k and NB._args(k)[4] == '6' for k in ks), ks
+
+
+def test_rotationally_symmetric_layers_with_colour_combination():
+    import _nearsymb_cases as NB
+    with emu_backend.emulated():
+        NB.check_rot_combine_colour('cpu', (2, 3, 48, 72), torch.float32)

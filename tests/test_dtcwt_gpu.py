@@ -569,3 +569,9 @@ def test_rotationally_symmetric_scatlayerj2_second_order_through_the_layer(shape
     ks = NB.check_scatj2_rot(DEV, shape, dtype)
     if shape[-1] >= 256:
         assert any('WlDtFwd12Strip<' in k and NB._args(k)[4] == '6' for k in ks), ks
+
+
+@pytest.mark.parametrize('shape', [(8, 3, 256, 256), (3, 3, 72, 88)])
+def test_rotationally_symmetric_layers_with_colour_combination(shape):
+    import _nearsymb_cases as NB
+    NB.check_rot_combine_colour(DEV, shape, torch.float32)
