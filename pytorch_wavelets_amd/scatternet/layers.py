@@ -22,7 +22,7 @@ class ScatLayer(nn.Module):
         if biort == 'near_sym_b_bp':
             # rotationally symmetric variant: a third (band-pass) pair filters the diagonal sub-band.  Inference: one launch (the lean
             # streaming kernel with a third row filter and window, or the tile kernel WlDtFwd1Rot); training: two launches of the plain
-            # fused ScatLayer kernels per direction (scatternet/lowlevel.py: ScatLayerj1_rot_train_f); combine_colour: the chain
+            # fused ScatLayer kernels per direction (scatternet/lowlevel.py: ScatLayerj1_rot_train_f), also with combine_colour
             self.bandpass_diag = True
             h0o, _, h1o, _, h2o, _ = _biort(biort)
             self.h2o = torch.nn.Parameter(prep_filt(h2o, 1), False)
