@@ -82,7 +82,8 @@ def _run_bench_emulated(extra):
            '--warmup', '1', '--emulate'] + extra
     env = dict(os.environ, OMP_NUM_THREADS='2')
     res = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
-    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    err = res.stderr.decode()
+    assert res.returncode == 0, err[max(0, err.find('Traceback')):][:3000] + '\n...\n' + err[-1500:]
     lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith('{')]
     assert len(lines) == 1, lines   # rank 0 only
     return json.loads(lines[0])
