@@ -644,6 +644,12 @@ def other_configs(pw, dev, sync):
     b = 46 * xt.numel()          # forward 4 (1 + 7/4 + 3) P, backward the same
     other['train_scatlayer_256x3x256x256_fp32'] = {'fwd_bwd_ms': round(t, 4), 'frac_of_hbm_peak_at_46B_per_px': frac(b, t),
                                                    'algorithmic_bytes': b, 'kernels': names(st)}
+    for tag in ('near_sym_b', 'near_sym_b_bp'):    # round 6 (late): the 13 / 19-tap pair, and the band-pass layer on pairs of plain launches
+        m = pw.ScatLayer(biort=tag).to(dev)
+        st = train_step(m, xt, lambda r: [r])
+        t = time_seq_fn(st, 20, sync)
+        other['train_scatlayer_%s_256x3x256x256_fp32' % tag] = {'fwd_bwd_ms': round(t, 4), 'frac_of_hbm_peak_at_46B_per_px': frac(b, t),
+                                                                'algorithmic_bytes': b, 'kernels': names(st)}
     del xt
     with torch.no_grad():
         xs = torch.randn(256, 3, 256, 256, device=dev)
@@ -665,6 +671,11 @@ def other_configs(pw, dev, sync):
         other['scatlayer_rot_near_sym_b_bp_64x3x256x256_fp32'] = {
             'fwd_ms': round(tr, 4), 'mpix_s': round(xs2.numel() / tr / 1e3, 1),
             'frac_of_hbm_peak_at_11B_per_px': frac(11 * xs2.numel(), tr), 'fwd_kernels': names(lambda: sr(xs2))}
+        s2r = pw.ScatLayerj2(biort='near_sym_b_bp', qshift='qshift_b_bp').to(dev)
+        t2r = time_seq_fn(lambda: s2r(xs2), 20, sync)
+        other['scatlayerj2_rot_near_sym_b_bp_64x3x256x256_fp32'] = {'fwd_ms': round(t2r, 4), 'mpix_s': round(xs2.numel() / t2r / 1e3, 1),
+                                                                     'frac_of_hbm_peak_at_16_25B_per_px': frac(16.25 * xs2.numel(), t2r),
+                                                                     'fwd_kernels': names(lambda: s2r(xs2))}
         del xs, xs2
         # f3: 1-D DWT and the stationary transform (generic single-axis kernels)
         x1 = torch.randn(64, 16, 65536, device=dev)
